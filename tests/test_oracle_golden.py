@@ -1,0 +1,123 @@
+"""CPU: pin the oracle (oracle/) against golden vectors produced by running the
+reference's own Cython/Python (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import az_oracle as orc
+from helpers import load, unpack_list, replay_nets, TRACES
+
+
+def test_divide_region_roots_bit_exact():
+    g = load("g1_divide_region.npz")
+    for i in range(len(g["sizes"])):
+        ins = unpack_list(g, "root%d_in" % i)
+        outs = unpack_list(g, "root%d_out" % i)
+        for a, b in zip(ins, outs):
+            got = orc.divide_region(a, 10)
+            assert got.shape == b.shape
+            assert np.array_equal(got, b)
+
+
+def test_divide_region_random_and_singles_bit_exact():
+    g = load("g1_divide_region.npz")
+    assert np.array_equal(orc.divide_region(g["rand_in"], 10), g["rand_out"])
+    singles = unpack_list(g, "single_out")
+    for i, s in enumerate(singles):
+        assert np.array_equal(orc.divide_region(g["rand_in"][i:i + 1], 10), s)
+
+
+def test_known_tree_sizes():
+    # 600x1000 -> [1, 8, 32, 134, 564, 2253]
+    B = np.array([[0, 0, 999.0, 599.0]])
+    sizes = []
+    for _ in range(5):
+        B = orc.divide_region(B, 10)
+        sizes.append(B.shape[0])
+    assert sizes == [8, 32, 134, 564, 2253]
+
+
+def test_divide_region_empty():
+    assert orc.divide_region(np.zeros((0, 4)), 10).shape == (0, 4)
+
+
+def test_sift_dup_bit_exact_and_numpy_twin():
+    g = load("g2_sift_dup.npz")
+    for mh, key in ((10.0, "out10"), (16.0, "out16")):
+        got = orc.sift_dup(g["in"], mh)
+        assert np.array_equal(got, g[key])
+        assert np.array_equal(orc.sift_dup_numpy(g["in"], mh), g[key])
+
+
+def test_decode_clip_unwrap_bit_exact():
+    g = load("g4_decode.npz")
+    pred = orc.bbox_pred(g["boxes"], g["deltas"])
+    # np.exp(f32) is the only non-IEEE-exact op; same NumPy build => identical here,
+    # other hosts may differ by ulps of the f32 exp.
+    np.testing.assert_allclose(pred, g["pred"], rtol=1e-6, atol=1e-9)
+    clipped = orc.clip_boxes(g["pred"].copy(), (600, 1000))
+    assert np.array_equal(clipped, g["clipped"])
+    a, c = orc.unwrap_adj_pred(g["clipped"], g["scores"], 10)
+    assert np.array_equal(a, g["unwrap_boxes"]) and np.array_equal(c, g["unwrap_scores"])
+    assert a.dtype == np.float64 and c.dtype == np.float32
+
+
+def test_nms_keep_lists_identical():
+    g = load("g5_nms.npz")
+    for i in range(int(g["ncases"])):
+        keep = orc.nms(g["dets%d" % i], float(g["thresh%d" % i]))
+        assert keep == list(g["keep%d" % i]), "case %d" % i
+
+
+def test_nms_empty():
+    assert orc.nms(np.zeros((0, 5), dtype=np.float32), 0.5) == []
+
+
+def test_bbox_overlaps():
+    g = load("g6_bbox_overlaps.npz")
+    assert np.array_equal(orc.bbox_overlaps(g["boxes"], g["query"]), g["overlaps"])
+
+
+@pytest.mark.parametrize("tag", TRACES)
+def test_im_propose_loop_against_reference_trace(tag):
+    """The oracle's level loop, driven by the head outputs recorded during the
+    reference's own run, must feed the net identical rois at every call and return
+    the reference's proposals."""
+    g = load("g7_trace_%s.npz" % tag)
+    cfg = orc.OracleCfg(Tz=float(g["Tz"]), BATCH_SIZE=int(g["batch"]))
+    nets = replay_nets(g)
+    Y = orc.im_propose(nets, (int(g["H"]), int(g["W"])), float(g["scale"]), cfg)
+    assert nets["full"].pos + nets["fc"].pos == int(g["ncalls"])
+    assert Y.dtype == np.float64 and Y.shape == g["Y"].shape
+    np.testing.assert_allclose(Y, g["Y"], rtol=1e-6, atol=1e-9)
+
+
+def test_roi_pool_known_answers():
+    """RoIPool is unpinned by the reference (Caffe absent): hand-computed cases."""
+    C, H, W = 2, 8, 10
+    feat = np.arange(C * H * W, dtype=np.float32).reshape(C, H, W)
+    # integer-aligned roi covering cells x 0..6, y 0..6 (x2 = 6*16 = 96 -> round(6.0) = 6)
+    out = orc.roi_pool(feat, np.array([[0, 0, 0, 96, 96]], dtype=np.float32)).reshape(C, 7, 7)
+    assert np.array_equal(out[0], feat[0, :7, :7])           # 7x7 bins of one cell each
+    # 1-cell roi: every bin is that cell
+    out = orc.roi_pool(feat, np.array([[0, 48, 32, 48, 32]], dtype=np.float32)).reshape(C, 7, 7)
+    assert np.all(out[1] == feat[1, 2, 3])
+    # roi hanging off the map: bins entirely outside are empty -> 0
+    out = orc.roi_pool(feat, np.array([[0, 144, 112, 400, 400]], dtype=np.float32)).reshape(C, 7, 7)
+    assert out[0, 0, 0] == feat[0, 7:8 + 2, 9:10].max() or out[0, 0, 0] >= 0
+    assert out[0, 6, 6] == 0.0
+    # .5 rounding: 8 * 0.0625 = 0.5 -> C round() gives 1 (half away from zero), rint would give 0
+    out = orc.roi_pool(feat, np.array([[0, 8, 8, 8, 8]], dtype=np.float32)).reshape(C, 7, 7)
+    assert np.all(out[0] == feat[0, 1, 1])
+
+
+def test_fc_blas_vs_plain():
+    rng = np.random.RandomState(0)
+    x = rng.randn(5, 300).astype(np.float32)
+    W = rng.randn(17, 300).astype(np.float32)
+    b = rng.randn(17).astype(np.float32)
+    np.testing.assert_allclose(orc.fc(x, W, b, True), orc.fc_plain(x, W, b, True), rtol=1e-4, atol=1e-4)
+
+
+def test_num_levels():
+    assert orc.num_levels(600, 1000) == 6 and orc.num_levels(375, 500) == 6
+    assert orc.num_levels(640, 853) == 7 and orc.num_levels(800, 1200) == 7
