@@ -1,0 +1,722 @@
+// az_capi.hip -- the C ABI of libaznet_hip.so (include/aznet_hip.h): context, HBM buffers,
+// the level loop of im_propose as one stream-ordered launch sequence, and the unit entry
+// points.  There is no CPU fallback anywhere in this library: without a gfx950 device
+// az_create fails with AZ_ERR_NO_DEVICE.
+#include "az_dev.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define AZ_VERSION_STR "aznet_hip 0.1 (gfx950)"
+
+struct AzEventRec { std::string name; int level; hipEvent_t a, b; };
+
+struct az_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int maxR = 16384, maxCand = 16384 * AZ_NSUB, maxCh = 65536;
+    bool head_loaded = false, launched = false;
+    AzHeadDims d{};
+    int S6 = 1, S7 = 1;
+    float spatial_scale = 0.0625f;                 // test_fc.prototxt:22
+    // weights (HBM)
+    float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
+    // feature map
+    const float *feat = nullptr;
+    float *feat_owned = nullptr;
+    size_t feat_owned_elems = 0;
+    // level-loop buffers (HBM)
+    AzCounts *cnt = nullptr;
+    double *B[2] = {nullptr, nullptr};
+    float *rois = nullptr, *urois = nullptr;
+    long long *key = nullptr, *ckey = nullptr;
+    int *grp = nullptr, *index = nullptr, *inv = nullptr, *choff = nullptr, *bc_c = nullptr, *bc_z = nullptr;
+    unsigned char *first = nullptr, *cflag = nullptr, *zflag = nullptr;
+    double *ubox = nullptr, *pred_u = nullptr, *Yall = nullptr, *Z = nullptr, *child = nullptr, *Yout = nullptr;
+    float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr;
+    float *zoom_u = nullptr, *score_u = nullptr, *delta_u = nullptr, *Sall = nullptr, *Sout = nullptr;
+    int *sel_idx = nullptr;
+    // nms scratch (grown on demand)
+    int nms_cap = 0;
+    float *nms_dets = nullptr, *nms_sdets = nullptr;
+    int *nms_order = nullptr;
+    unsigned long long *nms_mask = nullptr;
+    long long *nms_keep = nullptr;
+    // pinned host staging
+    AzCounts *h_cnt = nullptr;
+    double *h_Y = nullptr;
+    float *h_S = nullptr;
+    int h_cap = 0;
+    // last launch
+    az_params last{};
+    int last_nlev = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<AzEventRec> events;
+    std::vector<void *> allocs;        // head-sized buffers (az_load_head)
+    std::vector<void *> allocs_geom;   // geometry buffers (first use)
+    bool geom_ready = false;
+};
+
+namespace {
+
+int fail(az_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), AZ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int dalloc(az_ctx *c, T **p, size_t n, bool geom = false)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+    if (e != hipSuccess)
+        return fail(c, AZ_ERR_HIP, std::string("hipMalloc(") + std::to_string(n * sizeof(T)) + " B): " +
+                                       hipGetErrorString(e));
+    (geom ? c->allocs_geom : c->allocs).push_back(q);
+    *p = (T *)q;
+    return AZ_OK;
+}
+
+void free_all(az_ctx *c)
+{
+    for (void *p : c->allocs) hipFree(p);
+    c->allocs.clear();
+}
+
+
+// Buffers that depend only on the ctx limits (region / candidate capacity).
+int ensure_geom(az_ctx *c)
+{
+    if (c->geom_ready) return AZ_OK;
+    hipError_t e0 = hipSetDevice(c->device);
+    if (e0 != hipSuccess) return fail(c, AZ_ERR_HIP, "hipSetDevice failed");
+    const size_t R = (size_t)c->maxR, CAND = (size_t)c->maxCand, CH = (size_t)c->maxCh;
+    int rc;
+#define A(p, n) if ((rc = dalloc(c, &c->p, (n), true)) != AZ_OK) return rc
+    A(cnt, 1); A(B[0], R * 4); A(B[1], R * 4); A(rois, R * 5); A(urois, R * 5); A(key, R); A(ckey, CH);
+    A(grp, R); A(index, R); A(inv, R); A(choff, R); A(bc_c, (R * AZ_NSUB + 255) / 256 + 1);
+    A(bc_z, (R * AZ_NSUB + 255) / 256 + 1);
+    A(first, CH > R ? CH : R); A(cflag, R * AZ_NSUB); A(zflag, R);
+    A(ubox, R * 4); A(pred_u, R * AZ_NSUB * 4); A(Yall, CAND * 4); A(Z, R * 4); A(child, CH * 4);
+    A(Yout, CAND * 4); A(Sout, CAND); A(sel_idx, CAND);
+    A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
+#undef A
+    if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
+    c->geom_ready = true;
+    return AZ_OK;
+}
+
+struct Timed {
+    az_ctx *c; bool on; hipEvent_t a{}, b{}; const char *name; int level;
+    Timed(az_ctx *c_, const char *n, int l) : c(c_), on(c_->profiling), name(n), level(l)
+    {
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~Timed()
+    {
+        if (on) { hipEventRecord(b, c->stream); c->events.push_back({name, level, a, b}); }
+    }
+};
+
+void clear_events(az_ctx *c)
+{
+    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    c->events.clear();
+}
+
+// K of lib/detect/test.py:365-368 (Python-2 integer division when MIN_SIDE is integral).
+int num_levels(int h, int w, double min_side)
+{
+    const int side = h < w ? h : w;
+    double q;
+    if (min_side == std::floor(min_side) && min_side >= 1.0) q = (double)(side / (int)min_side);
+    else q = (double)side / min_side;
+    if (!(q >= 1.0)) return 0;
+    return (int)(std::log2(q) + 1.0);
+}
+
+int ensure_host(az_ctx *c, int cap)
+{
+    if (cap <= c->h_cap) return AZ_OK;
+    if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
+    HIPCHK(c, hipHostMalloc((void **)&c->h_Y, (size_t)cap * 4 * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_S, (size_t)cap * sizeof(float)));
+    c->h_cap = cap;
+    return AZ_OK;
+}
+
+int set_count(az_ctx *c, int *dptr, int v)
+{
+    HIPCHK(c, hipMemcpyAsync(dptr, &v, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // v lives on this frame
+    return AZ_OK;
+}
+
+// One forward of the head on the `U` unique rois in ctx->urois / ctx->ubox.
+void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps)
+{
+    const AzHeadDims &d = c->d;
+    { Timed t(c, "roi_pool", level);
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5); }
+    { Timed t(c, "fc6", level);
+      azk_fc(c->stream, c->pool5, d.K6, c->W6, d.K6, c->b6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part, c->h6,
+             d.n6, 1); }
+    { Timed t(c, "fc7", level);
+      azk_fc(c->stream, c->h6, d.n6, c->W7, d.n6, c->b7, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part, c->h7,
+             d.n7, 1); }
+    { Timed t(c, "head_tail", level);
+      azk_head_tail(c->stream, c->h7, d, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, c->zoom_u,
+                    c->score_u, c->delta_u, c->pred_u); }
+}
+
+int check_geom(az_ctx *c)
+{
+    if (!c) return AZ_ERR_INVALID;
+    return ensure_geom(c);
+}
+
+int check_ready(az_ctx *c, bool need_feat)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "az_load_head has not been called");
+    if (need_feat && !c->feat) return fail(c, AZ_ERR_STATE, "no feature map set");
+    return AZ_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+const char *az_version(void) { return AZ_VERSION_STR; }
+
+int az_create(int device, az_ctx **out)
+{
+    if (!out) return AZ_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AZ_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return AZ_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AZ_ERR_NO_DEVICE;   // gfx950 code objects only
+    if (hipSetDevice(device) != hipSuccess) return AZ_ERR_NO_DEVICE;
+    az_ctx *c = new az_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AZ_ERR_HIP; }
+    if (hipHostMalloc((void **)&c->h_cnt, sizeof(AzCounts)) != hipSuccess) { delete c; return AZ_ERR_HIP; }
+    *out = c;
+    return AZ_OK;
+}
+
+int az_destroy(az_ctx *c)
+{
+    if (!c) return AZ_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    clear_events(c);
+    free_all(c);
+    for (void *p : c->allocs_geom) hipFree(p);
+    c->allocs_geom.clear();
+    if (c->feat_owned) hipFree(c->feat_owned);
+    if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
+    if (c->h_cnt) hipHostFree(c->h_cnt);
+    if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return AZ_OK;
+}
+
+const char *az_last_error(const az_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+void *az_stream(az_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int az_set_limits(az_ctx *c, int max_regions, int max_candidates)
+{
+    if (!c || max_regions < 64 || max_candidates < max_regions) return fail(c, AZ_ERR_INVALID, "bad limits");
+    if (c->head_loaded || c->geom_ready) return fail(c, AZ_ERR_STATE, "az_set_limits must precede the first use of the context");
+    c->maxR = max_regions;
+    c->maxCand = max_candidates;
+    c->maxCh = 4 * max_regions;
+    return AZ_OK;
+}
+
+int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, const float *b6,
+                 const float *W71, const float *b71, const float *W72, const float *b72, const float *Was,
+                 const float *bas, const float *Wab, const float *bab, const float *Wz, const float *bz)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (!W6 || !b6 || !W71 || !b71 || !W72 || !b72 || !Was || !bas || !Wab || !bab || !Wz || !bz)
+        return fail(c, AZ_ERR_INVALID, "az_load_head: null weight pointer");
+    if (C <= 0 || (C & 3) || n6 <= 0 || (n6 & 3) || n71 <= 0 || (n71 & 3) || n72 <= 0 || (n72 & 3))
+        return fail(c, AZ_ERR_INVALID, "az_load_head: C, n6, n71, n72 must be positive multiples of 4");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_all(c);
+    c->head_loaded = false;
+    {
+        int rg = ensure_geom(c);
+        if (rg) return rg;
+    }
+    AzHeadDims &d = c->d;
+    d.C = C; d.pooled = 7; d.K6 = C * 49; d.n6 = n6; d.n71 = n71; d.n72 = n72; d.n7 = n71 + n72;
+    d.H = d.W = 0;
+    c->S6 = azk_fc_split(d.K6);
+    c->S7 = azk_fc_split(d.n6);
+    const int ldt = n71 > n72 ? n71 : n72;
+    const size_t R = (size_t)c->maxR;
+    int rc;
+#define A(p, n) if ((rc = dalloc(c, &c->p, (n))) != AZ_OK) return rc
+    A(W6, (size_t)n6 * d.K6); A(b6, n6); A(W7, (size_t)d.n7 * n6); A(b7, d.n7);
+    A(Wt, (size_t)56 * ldt); A(bt, 56);
+    A(pool5, R * d.K6);
+    {
+        const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7;
+        A(part, p6 > p7 ? p6 : p7);
+    }
+    A(h6, R * n6); A(h7, R * d.n7);
+#undef A
+    // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
+    HIPCHK(c, hipMemcpy(c->W6, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->b6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
+    // int7_1 and int7_2 both read int6: one GEMM with the two weight blocks stacked along N.
+    HIPCHK(c, hipMemcpy(c->W7, W71, (size_t)n71 * n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->W7 + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->b7, b71, (size_t)n71 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->b7 + n71, b72, (size_t)n72 * 4, hipMemcpyHostToDevice));
+    // epilogue weights: rows 0..10 adj_score, 11..54 adj_bbox, 55 zoom_score, row stride ldt
+    HIPCHK(c, hipMemset(c->Wt, 0, (size_t)56 * ldt * 4));
+    HIPCHK(c, hipMemcpy2D(c->Wt, (size_t)ldt * 4, Was, (size_t)n71 * 4, (size_t)n71 * 4, 11, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy2D(c->Wt + (size_t)11 * ldt, (size_t)ldt * 4, Wab, (size_t)n71 * 4, (size_t)n71 * 4, 44,
+                          hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->Wt + (size_t)55 * ldt, Wz, (size_t)n72 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bt, bas, 11 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bt + 11, bab, 44 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->bt + 55, bz, 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->head_loaded = true;
+    return AZ_OK;
+}
+
+int az_set_feature_map_dev(az_ctx *c, const float *dev_ptr, int C, int H, int W)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!dev_ptr || C != c->d.C || H <= 0 || W <= 0)
+        return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
+    c->feat = dev_ptr;
+    c->d.H = H; c->d.W = W;
+    return AZ_OK;
+}
+
+int az_set_feature_map_host(az_ctx *c, const float *host_ptr, int C, int H, int W)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!host_ptr || C != c->d.C || H <= 0 || W <= 0)
+        return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)C * H * W;
+    if (n > c->feat_owned_elems) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->feat_owned) hipFree(c->feat_owned);
+        c->feat_owned = nullptr; c->feat_owned_elems = 0;
+        HIPCHK(c, hipMalloc((void **)&c->feat_owned, n * 4));
+        c->feat_owned_elems = n;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->feat_owned, host_ptr, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->feat = c->feat_owned;
+    c->d.H = H; c->d.W = W;
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int az_propose_launch(az_ctx *c, const az_params *p)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!p || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) || p->batch_size <= 0 || !(p->min_side > 0))
+        return fail(c, AZ_ERR_INVALID, "az_propose: bad parameters");
+    const int K = num_levels(p->im_h, p->im_w, p->min_side);
+    const int nlev = K - 1;
+    if (nlev < 1)
+        return fail(c, AZ_ERR_INVALID,
+                    "az_propose: image too small for one search level (the reference's loop at "
+                    "lib/detect/test.py:373 would not execute)");
+    if (nlev > AZ_MAX_LEVELS) return fail(c, AZ_ERR_CAPACITY, "az_propose: too many levels");
+    int k = p->num_proposals;
+    if (p->fixed_num) {
+        if (k <= 0) return fail(c, AZ_ERR_INVALID, "az_propose: num_proposals must be positive");
+        if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    clear_events(c);
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);
+    for (int l = 0; l < nlev; ++l) {
+        const int cur = l & 1;
+        const int *Pptr = &c->cnt->P[l];
+        int *Uptr = &c->cnt->U[l];
+        { Timed t(c, "rois_keys", l);
+          azk_rois_keys(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
+                        c->grp); }
+        { Timed t(c, "dedup_rois", l);
+          azk_dedup_rois(s, c->key, c->grp, Pptr, c->maxR, c->first, c->rois, c->B[cur], c->index, c->inv,
+                         c->urois, c->ubox, Uptr); }
+        launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps);
+        { Timed t(c, "flags_compact", l);
+          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, c->pred_u, c->score_u,
+                            c->zoom_u, p->Tz, p->min_side, l == 0, c->cflag, c->zflag, c->bc_c, c->bc_z,
+                            c->Yall, c->Sall, c->Z); }
+        if (l + 1 < nlev) {      // the reference also divides after the last level but never uses it
+            { Timed t(c, "divide", l);
+              azk_divide(s, c->cnt, l, c->maxR, c->maxCh, c->Z, p->min_side, c->choff, c->child, c->ckey); }
+            { Timed t(c, "sift_dup", l);
+              azk_dedup_regions(s, c->ckey, &c->cnt->CH[l], c->maxCh, c->maxR, c->first, c->child,
+                                c->B[cur ^ 1], &c->cnt->P[l + 1], &c->cnt->err); }
+        }
+    }
+    { Timed t(c, "select", nlev);
+      if (p->fixed_num)
+          azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
+                        c->Sall, c->Yout, c->Sout);
+      else
+          azk_thresh_select_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, p->Tc, c->maxCand, c->sel_idx,
+                                 &c->cnt->nsel, c->Yall, c->Sall, c->Yout, c->Sout); }
+    HIPCHK(c, hipGetLastError());
+    c->last = *p;
+    c->last_nlev = nlev;
+    c->launched = true;
+    return AZ_OK;
+}
+
+int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
+{
+    if (!c || !c->launched) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");
+    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_propose_fetch: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int nlev = c->last_nlev;
+    // With a fixed proposal count the output size is bounded up front: one batched D2H, one sync.
+    const int want = c->last.fixed_num ? c->last.num_proposals : -1;
+    int rc;
+    if (want > 0) {
+        if ((rc = ensure_host(c, want)) != AZ_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_Y, c->Yout, (size_t)want * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_S, c->Sout, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        int n = c->h_cnt->nsel;
+        if (n > c->maxCand) n = c->maxCand;
+        if ((rc = ensure_host(c, n > 0 ? n : 1)) != AZ_OK) return rc;
+        if (n > 0) {
+            HIPCHK(c, hipMemcpyAsync(c->h_Y, c->Yout, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(c->h_S, c->Sout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+        }
+    }
+    c->launched = false;
+    const AzCounts &h = *c->h_cnt;
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        st->n_levels = nlev;
+        st->n_candidates = h.ytot[nlev];
+        for (int l = 0; l < nlev; ++l) {
+            st->level_regions[l] = h.P[l];
+            st->level_unique[l] = h.U[l];
+            st->level_zoomed[l] = h.PZ[l];
+            st->num_eval += h.P[l];
+            if (h.P[l] > 0) st->depth = l + 1;
+        }
+    }
+    if (h.err)
+        return fail(c, AZ_ERR_CAPACITY,
+                    std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
+                        "): raise az_set_limits");
+    const int n = h.nsel;
+    if (st) st->n_proposals = n;
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_propose: output capacity too small");
+    std::memcpy(boxes_out, c->h_Y, (size_t)n * 4 * sizeof(double));
+    if (scores_out) std::memcpy(scores_out, c->h_S, (size_t)n * sizeof(float));
+    return AZ_OK;
+}
+
+int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_out, int cap, int *n_out,
+               az_stats *st)
+{
+    int rc = az_propose_launch(c, p);
+    if (rc) return rc;
+    return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+}
+
+int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!n_out) return AZ_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = c->h_cnt->ytot[c->last_nlev];
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_last_candidates: cap too small");
+    if (boxes_out) HIPCHK(c, hipMemcpy(boxes_out, c->Yall, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (scores_out) HIPCHK(c, hipMemcpy(scores_out, c->Sall, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Unit entry points: host in, host out, same kernels.
+static int sift_common(az_ctx *c, int C, double min_side, double *out, int cap, int *n_out)
+{
+    hipStream_t s = c->stream;
+    int *Nptr = &c->cnt->scratch[0], *Pn = &c->cnt->scratch[1], *err = &c->cnt->scratch[2];
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    int rc = set_count(c, Nptr, C);
+    if (rc) return rc;
+    azk_region_keys(s, c->child, Nptr, c->maxCh, min_side, c->ckey);
+    azk_dedup_regions(s, c->ckey, Nptr, c->maxCh, c->maxR, c->first, c->child, c->B[1], Pn, err);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->h_cnt->scratch[2]) return fail(c, AZ_ERR_CAPACITY, "sift_dup: region capacity exceeded");
+    const int n = c->h_cnt->scratch[1];
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "sift_dup: output cap too small");
+    if (n) HIPCHK(c, hipMemcpy(out, c->B[1], (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_sift_dup(az_ctx *c, const double *regions, int C, double min_side, double *out, int cap, int *n_out)
+{
+    int rc = check_geom(c);
+    if (rc) return rc;
+    if (C < 0 || (C && !regions) || !n_out || !(min_side > 0)) return fail(c, AZ_ERR_INVALID, "az_sift_dup: bad arguments");
+    if (C > c->maxCh) return fail(c, AZ_ERR_CAPACITY, "az_sift_dup: too many regions");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (C) HIPCHK(c, hipMemcpyAsync(c->child, regions, (size_t)C * 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    return sift_common(c, C, min_side, out, cap, n_out);
+}
+
+int az_divide_region(az_ctx *c, const double *regions, int P, double min_side, double *out, int cap, int *n_out)
+{
+    int rc = check_geom(c);
+    if (rc) return rc;
+    if (P < 0 || (P && !regions) || !n_out || !(min_side > 0)) return fail(c, AZ_ERR_INVALID, "az_divide_region: bad arguments");
+    if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: too many regions");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    if (P) HIPCHK(c, hipMemcpyAsync(c->Z, regions, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = set_count(c, &c->cnt->PZ[0], P)) != AZ_OK) return rc;
+    azk_divide(s, c->cnt, 0, c->maxR, c->maxCh, c->Z, min_side, c->choff, c->child, c->ckey);
+    azk_dedup_regions(s, c->ckey, &c->cnt->CH[0], c->maxCh, c->maxR, c->first, c->child, c->B[1], &c->cnt->P[1],
+                      &c->cnt->err);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->h_cnt->err) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: ctx capacity exceeded");
+    const int n = c->h_cnt->P[1];
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: output cap too small");
+    if (n) HIPCHK(c, hipMemcpy(out, c->B[1], (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_roi_dedup(az_ctx *c, const double *boxes, int P, double scale, double dedup, int batch_size,
+                 float *rois_out, int32_t *index_out, int32_t *inv_index_out, int *n_unique)
+{
+    int rc = check_geom(c);
+    if (rc) return rc;
+    if (P < 0 || (P && !boxes) || !n_unique || batch_size <= 0) return fail(c, AZ_ERR_INVALID, "az_roi_dedup: bad arguments");
+    if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_roi_dedup: too many regions");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    if (P) HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
+    azk_rois_keys(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp);
+    azk_dedup_rois(s, c->key, c->grp, &c->cnt->P[0], c->maxR, c->first, c->rois, c->B[0], c->index, c->inv,
+                   c->urois, c->ubox, &c->cnt->U[0]);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int U = c->h_cnt->U[0];
+    *n_unique = U;
+    if (P && rois_out) HIPCHK(c, hipMemcpy(rois_out, c->rois, (size_t)P * 5 * 4, hipMemcpyDeviceToHost));
+    if (U && index_out) HIPCHK(c, hipMemcpy(index_out, c->index, (size_t)U * 4, hipMemcpyDeviceToHost));
+    if (P && inv_index_out) HIPCHK(c, hipMemcpy(inv_index_out, c->inv, (size_t)P * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+static int stage_rois(az_ctx *c, const float *rois, int R)
+{
+    if (R < 0 || (R && !rois)) return fail(c, AZ_ERR_INVALID, "bad rois");
+    if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "too many rois");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), c->stream));
+    if (R) HIPCHK(c, hipMemcpyAsync(c->urois, rois, (size_t)R * 5 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ubox, 0, (size_t)(R > 0 ? R : 1) * 4 * sizeof(double), c->stream));
+    return set_count(c, &c->cnt->U[0], R);
+}
+
+int az_roi_pool(az_ctx *c, const float *rois, int R, float *out)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
+    if (!out) return fail(c, AZ_ERR_INVALID, "az_roi_pool: null output");
+    azk_roi_pool(c->stream, c->feat, c->d, c->spatial_scale, c->urois, &c->cnt->U[0], c->maxR, c->pool5);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (R) HIPCHK(c, hipMemcpy(out, c->pool5, (size_t)R * c->d.K6 * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_head_forward(az_ctx *c, const float *rois, int R, float *zoom_prob, float *adj_prob, float *adj_bbox)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
+    clear_events(c);
+    launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (R && zoom_prob) HIPCHK(c, hipMemcpy(zoom_prob, c->zoom_u, (size_t)R * 4, hipMemcpyDeviceToHost));
+    if (R && adj_prob) HIPCHK(c, hipMemcpy(adj_prob, c->score_u, (size_t)R * AZ_NSUB * 4, hipMemcpyDeviceToHost));
+    if (R && adj_bbox) HIPCHK(c, hipMemcpy(adj_bbox, c->delta_u, (size_t)R * 4 * AZ_NSUB * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_decode_filter(az_ctx *c, const double *anchors, const float *deltas, const float *scores, int R,
+                     int im_h, int im_w, double eps, double min_side, double *boxes_out, float *scores_out,
+                     int cap, int *n_out)
+{
+    int rc = check_geom(c);
+    if (rc) return rc;
+    if (R < 0 || (R && (!anchors || !deltas || !scores)) || !n_out) return fail(c, AZ_ERR_INVALID, "az_decode_filter: bad arguments");
+    if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_decode_filter: too many regions");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    // stage: anchors -> ubox, deltas -> delta_u, scores -> Sout (scratch); inv = identity
+    std::vector<int> ident(R);
+    for (int i = 0; i < R; ++i) ident[i] = i;
+    if (R) {
+        HIPCHK(c, hipMemcpyAsync(c->ubox, anchors, (size_t)R * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->delta_u, deltas, (size_t)R * 4 * AZ_NSUB * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->Sout, scores, (size_t)R * AZ_NSUB * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->inv, ident.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = set_count(c, &c->cnt->P[0], R)) != AZ_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->zoom_u, 0, (size_t)(R > 0 ? R : 1) * 4, s));
+    azk_decode_unit(s, c->ubox, c->delta_u, c->Sout, R, im_h, im_w, eps, c->pred_u, c->score_u);
+    azk_flags_compact(s, c->cnt, 0, c->maxR, c->maxCand, c->ubox, c->inv, c->pred_u, c->score_u, c->zoom_u, 2.0,
+                      min_side, 0, c->cflag, c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int n = c->h_cnt->NC[0];
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_decode_filter: output cap too small");
+    if (n && boxes_out) HIPCHK(c, hipMemcpy(boxes_out, c->Yall, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (n && scores_out) HIPCHK(c, hipMemcpy(scores_out, c->Sall, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_topk(az_ctx *c, const float *scores, int n, int k, int32_t *idx_out, int *n_out)
+{
+    int rc = check_geom(c);
+    if (rc) return rc;
+    if (n < 0 || (n && !scores) || k <= 0 || !idx_out || !n_out) return fail(c, AZ_ERR_INVALID, "az_topk: bad arguments");
+    if (n > c->maxCand || k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_topk: n or k too large");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->Sall, scores, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if ((rc = set_count(c, &c->cnt->scratch[0], n)) != AZ_OK) return rc;
+    azk_topk(s, c->Sall, &c->cnt->scratch[0], c->maxCand, k, c->sel_idx, &c->cnt->nsel);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int m = c->h_cnt->nsel;
+    *n_out = m;
+    if (m) HIPCHK(c, hipMemcpy(idx_out, c->sel_idx, (size_t)m * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, int *n_keep)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (n < 0 || (n && (!dets || !keep)) || !n_keep) return fail(c, AZ_ERR_INVALID, "az_nms: bad arguments");
+    *n_keep = 0;
+    if (n == 0) return AZ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (n > c->nms_cap) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
+        c->nms_dets = nullptr; c->nms_cap = 0;
+        int cap = 1024;
+        while (cap < n) cap *= 2;
+        const size_t W = (size_t)(cap + 63) / 64;
+        if (W * sizeof(unsigned long long) > 60000) return fail(c, AZ_ERR_CAPACITY, "az_nms: n too large");
+        HIPCHK(c, hipMalloc((void **)&c->nms_dets, (size_t)cap * 5 * 4));
+        HIPCHK(c, hipMalloc((void **)&c->nms_sdets, (size_t)cap * 5 * 4));
+        HIPCHK(c, hipMalloc((void **)&c->nms_order, (size_t)cap * 4 + 16));
+        HIPCHK(c, hipMalloc((void **)&c->nms_mask, (size_t)cap * W * 8));
+        HIPCHK(c, hipMalloc((void **)&c->nms_keep, (size_t)cap * 8 + 16));
+        c->nms_cap = cap;
+    }
+    int *nk = c->nms_order + c->nms_cap;      // spare int after the order array
+    HIPCHK(c, hipMemcpyAsync(c->nms_dets, dets, (size_t)n * 5 * 4, hipMemcpyHostToDevice, s));
+    azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, c->nms_keep, nk);
+    int h_nk = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_nk, nk, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    *n_keep = h_nk;
+    if (h_nk) HIPCHK(c, hipMemcpy(keep, c->nms_keep, (size_t)h_nk * 8, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------------------------
+int az_set_profiling(az_ctx *c, int on)
+{
+    if (!c) return AZ_ERR_INVALID;
+    c->profiling = on != 0;
+    return AZ_OK;
+}
+
+int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *level_out, int cap, int *n_out)
+{
+    if (!c || !n_out) return AZ_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = (int)c->events.size();
+    *n_out = n;
+    for (int i = 0; i < n && i < cap; ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b);
+        if (ms_out) ms_out[i] = ms;
+        if (level_out) level_out[i] = c->events[i].level;
+        if (names_out) {
+            std::memset(names_out + 32 * i, 0, 32);
+            std::strncpy(names_out + 32 * i, c->events[i].name.c_str(), 31);
+        }
+    }
+    return AZ_OK;
+}
+
+}  // extern "C"

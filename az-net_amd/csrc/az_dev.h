@@ -1,0 +1,107 @@
+// az_dev.h -- shared declarations for the gfx950 kernels behind libaznet_hip.so.
+// Wave = 64 lanes everywhere in this tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/aznet_hip.h"
+
+#define AZ_WAVE 64
+#define AZ_NSUB AZ_NUM_SUBREG
+
+// Device-resident bookkeeping of one search; every kernel of the level loop reads its
+// sizes from here, so the host never synchronises inside the loop.
+struct AzCounts {
+    int P[AZ_MAX_LEVELS + 1];   // regions per level (B.shape[0]); P[0] = 1
+    int U[AZ_MAX_LEVELS];       // unique rois forwarded at that level
+    int NC[AZ_MAX_LEVELS];      // candidates kept at that level (after the MIN_SIDE filter)
+    int PZ[AZ_MAX_LEVELS];      // regions selected for zoom (len(indZ))
+    int CH[AZ_MAX_LEVELS];      // children before _sift_dup
+    int ytot[AZ_MAX_LEVELS + 1];// running number of candidates before each level
+    int nsel;                   // proposals selected at the end
+    int err;                    // bit 0: region capacity, bit 1: candidate capacity, bit 2: children
+    int scratch[6];
+};
+
+// Geometry of one launch of the head on `U` rois (all device pointers).
+struct AzHeadDims {
+    int C, H, W;        // feature map
+    int pooled;         // 7
+    int K6;             // C * pooled * pooled
+    int n6, n71, n72;   // fc sizes
+    int n7;             // n71 + n72
+};
+
+// ----------------------------------------------------------------------------------------
+// Box decode shared by the head epilogue and the unit entry point:
+// _bbox_pred + _clip_boxes (lib/detect/test.py:106-151).  f64, one rounding per operation;
+// exp is evaluated in f32 (np.exp of the f32 deltas) and widened.
+static __device__ __forceinline__ void az_decode_box(const double *anchor, const float *d4, int im_h, int im_w, double eps,
+                              double *out4)
+{
+    const double w = anchor[2] - anchor[0] + eps;
+    const double h = anchor[3] - anchor[1] + eps;
+    const double cx = anchor[0] + 0.5 * w;
+    const double cy = anchor[1] + 0.5 * h;
+    const double pcx = (double)d4[0] * w + cx;
+    const double pcy = (double)d4[1] * h + cy;
+    const double pw = (double)expf(d4[2]) * w;
+    const double ph = (double)expf(d4[3]) * h;
+    double x1 = pcx - 0.5 * pw, y1 = pcy - 0.5 * ph;
+    double x2 = pcx + 0.5 * pw, y2 = pcy + 0.5 * ph;
+    x1 = x1 > 0.0 ? x1 : 0.0;                       // np.maximum(x1, 0)
+    y1 = y1 > 0.0 ? y1 : 0.0;
+    const double xm = (double)(im_w - 1), ym = (double)(im_h - 1);
+    x2 = x2 < xm ? x2 : xm;                         // np.minimum(x2, W - 1)
+    y2 = y2 < ym ? y2 : ym;
+    out4[0] = x1; out4[1] = y1; out4[2] = x2; out4[3] = y2;
+}
+
+
+// ---- launchers (az_geom.hip) -----------------------------------------------------------
+void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w);
+void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
+                   int batch, float *rois, long long *key, int *grp);
+void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const int *Nptr, int cap,
+                    unsigned char *first, const float *rois, const double *B, int *index, int *inv,
+                    float *urois, double *ubox, int *Uptr);
+void azk_flags_compact(hipStream_t s, AzCounts *cnt, int level, int capR, int capCand,
+                       const double *B, const int *inv, const double *pred_u, const float *score_u,
+                       const float *zoom_u, double Tz, double min_side, int force_root,
+                       unsigned char *cflag, unsigned char *zflag, int *bc_c, int *bc_z,
+                       double *Yall, float *Sall, double *Z);
+void azk_divide(hipStream_t s, AzCounts *cnt, int level, int capR, int capCh, const double *Z,
+                double min_side, int *choff, double *child, long long *ckey);
+void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,
+                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err);
+// decode + flags for the unit entry point az_decode_filter
+void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int cap, double min_side,
+                     long long *ckey);
+void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, const float *scores,
+                     int R, int im_h, int im_w, double eps, double *pred_u, float *score_u);
+
+// ---- launchers (az_head.hip) -----------------------------------------------------------
+void azk_roi_pool(hipStream_t s, const float *feat, AzHeadDims d, float spatial_scale,
+                  const float *urois, const int *Uptr, int capU, float *pool5);
+// y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip).
+void azk_fc(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const float *bias,
+            const int *Mptr, int capM, int N, int K, int S, float *part, float *y, int ldy, int relu);
+void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
+                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps,
+                   float *zoom_u, float *score_u, float *delta_u, double *pred_u);
+int azk_fc_split(int K);
+
+// ---- launchers (az_select.hip) ---------------------------------------------------------
+// Top-k by score (descending, ties: lower index first).  With Yall/Sall/Yout/Sout non-NULL the
+// selected boxes/scores are gathered in the same launch.
+void azk_topk_full(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
+                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout);
+void azk_topk(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
+              int *nsel);
+void azk_thresh_select_full(hipStream_t s, const float *scores, const int *Nptr, int capN, double Tc,
+                            int cap_out, int *sel_idx, int *nsel, const double *Yall, const float *Sall,
+                            double *Yout, float *Sout);
+void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap, const double *Yall,
+                    const float *Sall, double *Yout, float *Sout);
+void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
+             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep);
+#define AZ_TOPK_MAX 4096

@@ -1,0 +1,459 @@
+// az_geom.hip -- region geometry of the AZ search on gfx950: roi projection + 1/16 dedup,
+// candidate filter + ordered stream compaction, zoom selection, divide_region and the
+// 10-px-grid _sift_dup.  All of it is HBM/latency-bound integer and f64 work (no MFMA);
+// built with -ffp-contract=off so every f64/f32 expression rounds once per operation,
+// in the reference's operation order.
+#include "az_dev.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Exclusive prefix sum of one int per thread across the block (blockDim.x <= 1024).
+__device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints of LDS */)
+{
+    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();                       // wsum may still be read from a previous call
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { int t = wsum[w]; wsum[w] = run; run += t; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    *total = wsum[16];
+    return wsum[wid] + inc - v;
+}
+
+// ----------------------------------------------------------------------------------------
+__global__ void k_init_root(AzCounts *cnt, double *B0, int im_h, int im_w)
+{
+    // lib/detect/test.py:355: B = [[0, 0, W - 1.0, H - 1.0]]
+    cnt->P[0] = 1;
+    B0[0] = 0.0; B0[1] = 0.0; B0[2] = im_w - 1.0; B0[3] = im_h - 1.0;
+}
+
+// lib/detect/test.py:61-97 (_get_rois_blob: f64 box * scale -> f32) and :212-214 (hash of
+// np.round(rois * DEDUP_BOXES) . [1,1e3,1e6,1e9,1e12]; exact integers, so int64 here).
+__global__ void k_rois_keys(const double *__restrict__ B, const int *Pptr, double scale, float dedup,
+                            int batch, float *rois, long long *key, int *grp)
+{
+    const int P = *Pptr;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P; r += gridDim.x * blockDim.x) {
+        long long h = 0, mult = 1000;
+        rois[5 * r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x = (float)(B[4 * r + c] * scale);
+            rois[5 * r + 1 + c] = x;
+            float t = rintf(x * dedup);            // np.round: half to even, in f32
+            h += (long long)t * mult;
+            mult *= 1000;
+        }
+        key[r] = h;
+        grp[r] = r / batch;                        // dedup is per BATCH_SIZE chunk (test.py:195-218)
+    }
+}
+
+// first[i] = no j < i carries the same (grp, key): np.unique(return_index=True) keeps the
+// first occurrence.  O(N^2) over LDS tiles; N is a few thousand at most.
+__global__ void k_first(const long long *__restrict__ key, const int *__restrict__ grp, const int *Nptr,
+                        unsigned char *first)
+{
+    __shared__ long long sk[TB];
+    __shared__ int sg[TB];
+    const int N = *Nptr;
+    const int nblk = (N + TB - 1) / TB;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int i = b * TB + threadIdx.x;
+        const long long ki = i < N ? key[i] : 0;
+        const int gi = (i < N && grp) ? grp[i] : 0;
+        bool dup = false;
+        for (int t = 0; t <= b; ++t) {
+            const int j = t * TB + threadIdx.x;
+            __syncthreads();
+            sk[threadIdx.x] = j < N ? key[j] : 0;
+            sg[threadIdx.x] = (j < N && grp) ? grp[j] : 0;
+            __syncthreads();
+            int lim = i - t * TB;                  // only j < i
+            if (lim > TB) lim = TB;
+            for (int jj = 0; jj < lim; ++jj) dup |= (sk[jj] == ki) & (sg[jj] == gi);
+        }
+        if (i < N) first[i] = dup ? 0 : 1;
+    }
+}
+
+// slot[i] = number of distinct (grp, key) pairs ordered before i's pair = position of i's
+// pair in np.unique's ascending output.
+__device__ __forceinline__ int dedup_slot(const long long *key, const int *grp, const unsigned char *first,
+                                          int N, int i, long long *sk, int *sg, unsigned char *sf)
+{
+    const long long ki = i < N ? key[i] : 0;
+    const int gi = (i < N && grp) ? grp[i] : 0;
+    int slot = 0;
+    for (int t = 0; t * TB < N; ++t) {
+        const int j = t * TB + threadIdx.x;
+        __syncthreads();
+        sk[threadIdx.x] = j < N ? key[j] : 0;
+        sg[threadIdx.x] = (j < N && grp) ? grp[j] : 0;
+        sf[threadIdx.x] = j < N ? first[j] : 0;
+        __syncthreads();
+        int lim = N - t * TB;
+        if (lim > TB) lim = TB;
+        for (int jj = 0; jj < lim; ++jj) {
+            const bool less = (sg[jj] < gi) | ((sg[jj] == gi) & (sk[jj] < ki));
+            slot += (sf[jj] != 0) & less;
+        }
+    }
+    return slot;
+}
+
+// Feature-space dedup outputs (lib/detect/test.py:215-218): index, inv_index and the
+// gathered unique rois / anchor boxes (`boxes = boxes[index, :]`).
+__global__ void k_dedup_rois(const long long *__restrict__ key, const int *__restrict__ grp, const int *Nptr,
+                             const unsigned char *__restrict__ first, const float *__restrict__ rois,
+                             const double *__restrict__ B, int *index, int *inv, float *urois, double *ubox,
+                             int *Uptr)
+{
+    __shared__ long long sk[TB];
+    __shared__ int sg[TB];
+    __shared__ unsigned char sf[TB];
+    const int N = *Nptr;
+    const int nblk = (N + TB - 1) / TB;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int i = b * TB + threadIdx.x;
+        const int slot = dedup_slot(key, grp, first, N, i, sk, sg, sf);
+        const bool f = i < N && first[i];
+        if (i < N) inv[i] = slot;
+        if (f) {
+            index[slot] = i;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) urois[5 * slot + c] = rois[5 * i + c];
+            if (B) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ubox[4 * slot + c] = B[4 * i + c];
+            }
+        }
+        const int nf = __syncthreads_count(f);
+        if (threadIdx.x == 0 && nf) atomicAdd(Uptr, nf);
+    }
+}
+
+// _sift_dup output (lib/utils/div.pyx:85-89): regions[index] in ascending hash order.
+__global__ void k_dedup_regions(const long long *__restrict__ key, const int *Nptr, int capOut,
+                                const unsigned char *__restrict__ first, const double *__restrict__ child,
+                                double *Bnext, int *Pnext, int *err)
+{
+    __shared__ long long sk[TB];
+    __shared__ int sg[TB];
+    __shared__ unsigned char sf[TB];
+    const int N = *Nptr;
+    const int nblk = (N + TB - 1) / TB;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int i = b * TB + threadIdx.x;
+        const int slot = dedup_slot(key, nullptr, first, N, i, sk, sg, sf);
+        bool f = i < N && first[i];
+        if (f && slot >= capOut) { atomicOr(err, 1); f = false; }
+        if (f) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Bnext[4 * slot + c] = child[4 * i + c];
+        }
+        const int nf = __syncthreads_count(f);
+        if (threadIdx.x == 0 && nf) atomicAdd(Pnext, nf);
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// Candidate filter (test.py:171-187: keep min(w, h) + 1 >= MIN_SIDE, order r*11+s) and zoom
+// selection (test.py:383-387: zoom[0] = 1 at level 1; indZ = where(zoom >= Tz), f32 zoom
+// widened to double).  Pass 1: flags + per-block counts.
+__global__ void k_flags(const AzCounts *cnt, int level, const int *__restrict__ inv,
+                        const double *__restrict__ pred_u, const float *__restrict__ zoom_u, double Tz,
+                        double min_side, int force_root, unsigned char *cflag, unsigned char *zflag,
+                        int *bc_c, int *bc_z)
+{
+    const int P = cnt->P[level];
+    const int NCAND = P * AZ_NSUB;
+    const int nblk = (NCAND + TB - 1) / TB;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int c = b * TB + threadIdx.x;
+        int fl = 0;
+        if (c < NCAND) {
+            const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
+            const double *bx = pred_u + ((size_t)inv[r] * AZ_NSUB + s) * 4;
+            const double h = bx[3] - bx[1] + 1;
+            const double w = bx[2] - bx[0] + 1;
+            const double side = (h < w) ? h : w;          // np.minimum(heights, widths)
+            fl = side >= min_side;
+            cflag[c] = (unsigned char)fl;
+        }
+        int zf = 0;
+        if (c < P) {
+            float z = zoom_u[inv[c]];
+            if (force_root && c == 0) z = 1.0f;
+            zf = ((double)z >= Tz);
+            zflag[c] = (unsigned char)zf;
+        }
+        const int n1 = __syncthreads_count(fl);
+        const int n2 = __syncthreads_count(zf);
+        if (threadIdx.x == 0) { bc_c[b] = n1; bc_z[b] = n2; }
+    }
+}
+
+__device__ __forceinline__ int block_sum_upto(const int *v, int n, int *red)
+{
+    int s = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) s += v[t];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    __syncthreads();
+    if (lane_id() == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    int tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+    return tot;
+}
+
+// Pass 2: ordered compaction.  Candidates are appended to Y / aScores (test.py:380-381) and
+// the zoom set Z = B[indZ] is gathered (test.py:387).
+__global__ void k_compact(AzCounts *cnt, int level, int capCand, const double *__restrict__ B,
+                          const int *__restrict__ inv, const double *__restrict__ pred_u,
+                          const float *__restrict__ score_u, const unsigned char *__restrict__ cflag,
+                          const unsigned char *__restrict__ zflag, const int *__restrict__ bc_c,
+                          const int *__restrict__ bc_z, double *Yall, float *Sall, double *Z)
+{
+    __shared__ int red[TB / 64];
+    __shared__ int wsum[17];
+    const int P = cnt->P[level];
+    const int NCAND = P * AZ_NSUB;
+    const int nblk = (NCAND + TB - 1) / TB;
+    const int ybase = cnt->ytot[level];
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int base_c = block_sum_upto(bc_c, b, red);
+        const int base_z = block_sum_upto(bc_z, b, red);
+        const int c = b * TB + threadIdx.x;
+        const int fl = (c < NCAND) ? cflag[c] : 0;
+        int tot;
+        const int off = block_excl_scan(fl, &tot, wsum);
+        if (fl) {
+            const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
+            const size_t src = (size_t)inv[r] * AZ_NSUB + s;
+            const int dst = ybase + base_c + off;
+            if (dst < capCand) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Yall[(size_t)dst * 4 + k] = pred_u[src * 4 + k];
+                Sall[dst] = score_u[src];
+            }
+        }
+        const int zf = (c < P) ? zflag[c] : 0;
+        const int zoff = block_excl_scan(zf, &tot, wsum);
+        if (zf) {
+            const int dst = base_z + zoff;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Z[(size_t)dst * 4 + k] = B[(size_t)c * 4 + k];
+        }
+    }
+    if (blockIdx.x == 0) {
+        const int tc = block_sum_upto(bc_c, nblk, red);
+        const int tz = block_sum_upto(bc_z, nblk, red);
+        if (threadIdx.x == 0) {
+            int nc = tc;
+            if (ybase + nc > capCand) { nc = capCand - ybase; atomicOr(&cnt->err, 2); }
+            cnt->NC[level] = nc;
+            cnt->ytot[level + 1] = ybase + nc;
+            cnt->PZ[level] = tz;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// divide_region, lib/utils/div.pyx:15-76.
+struct DivPlan { int min_ind; unsigned num_long; double l_short, l_long; };
+
+__device__ __forceinline__ DivPlan div_plan(const double *r)
+{
+    DivPlan p;
+    const double L0 = r[2] - r[0] + 1.0, L1 = r[3] - r[1] + 1.0;   // div.pyx:32-33
+    p.min_ind = (L1 < L0) ? 1 : 0;                                 // np.argmin: tie -> width
+    const double Lmin = p.min_ind ? L1 : L0, Lmax = p.min_ind ? L0 : L1;
+    p.l_short = Lmin / 2;                                          // div.pyx:40
+    const double q = Lmax / p.l_short;
+    p.num_long = (p.l_short > 0.0 && q < 1.0e6) ? (unsigned)q : 0u;   // int(): truncation, div.pyx:42
+    p.l_long = p.num_long ? Lmax / p.num_long : 0.0;               // div.pyx:43
+    return p;
+}
+
+// Single workgroup: children per parent + exclusive scan -> child offsets, total in CH[level].
+__global__ void __launch_bounds__(1024) k_divide_scan(AzCounts *cnt, int level, int capCh,
+                                                      const double *__restrict__ Z, int *choff)
+{
+    __shared__ int wsum[17];
+    const int PZ = cnt->PZ[level];
+    int running = 0;
+    for (int base = 0; base < PZ; base += blockDim.x) {
+        const int z = base + threadIdx.x;
+        int n = 0;
+        if (z < PZ) {
+            const DivPlan p = div_plan(Z + 4 * (size_t)z);
+            n = p.num_long ? (int)(3 * p.num_long - 1) : 0;        // div.pyx:45
+        }
+        int tot;
+        const int ex = block_excl_scan(n, &tot, wsum);
+        if (z < PZ) choff[z] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        if (running > capCh) { atomicOr(&cnt->err, 4); running = 0; }
+        cnt->CH[level] = running;
+    }
+}
+
+__global__ void k_divide_emit(const AzCounts *cnt, int level, const double *__restrict__ Z,
+                              const int *__restrict__ choff, double min_side, double *child,
+                              long long *ckey)
+{
+    const int PZ = cnt->PZ[level];
+    if (cnt->CH[level] == 0) return;
+    for (int z = blockIdx.x * blockDim.x + threadIdx.x; z < PZ; z += gridDim.x * blockDim.x) {
+        const double *r = Z + 4 * (size_t)z;
+        const DivPlan p = div_plan(r);
+        if (!p.num_long) continue;
+        const double x0 = r[0], y0 = r[1];
+        const double h_short = p.l_short / 2, h_long = p.l_long / 2;   // div.pyx:58-59
+        const int nb = (int)(3 * p.num_long - 1);
+        const size_t o = (size_t)choff[z];
+        for (int bi = 0; bi < nb; ++bi) {
+            double s_lo, s_hi, l_lo, l_hi;      // short-axis / long-axis cell bounds
+            if (bi < (int)(2 * p.num_long)) {   // grid cells, index k*num_long + j (div.pyx:47-56)
+                const unsigned k = (unsigned)bi / p.num_long, j = (unsigned)bi - k * p.num_long;
+                s_lo = k * p.l_short; s_hi = (k + 1) * p.l_short;
+                l_lo = j * p.l_long;  l_hi = (j + 1) * p.l_long;
+            } else {                            // half-offset cells, k = 0 (div.pyx:60-69)
+                const unsigned j = (unsigned)bi - 2 * p.num_long;
+                s_lo = 0 * p.l_short + h_short; s_hi = (0 + 1) * p.l_short + h_short;
+                l_lo = j * p.l_long + h_long;   l_hi = (j + 1) * p.l_long + h_long;
+            }
+            double c[4];
+            if (p.min_ind == 0) { c[0] = s_lo; c[1] = l_lo; c[2] = s_hi; c[3] = l_hi; }
+            else                { c[0] = l_lo; c[1] = s_lo; c[2] = l_hi; c[3] = s_hi; }
+            c[0] += x0; c[2] += x0; c[1] += y0; c[3] += y0;            // div.pyx:71-72
+            long long h = 0, mult = 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                child[(o + bi) * 4 + q] = c[q];
+                h += (long long)rint(c[q] / min_side) * mult;          // div.pyx:86
+                mult *= 1000;
+            }
+            ckey[o + bi] = h;
+        }
+    }
+}
+
+// Keys only (unit entry point az_sift_dup).
+__global__ void k_region_keys(const double *__restrict__ regions, const int *Nptr, double min_side,
+                              long long *ckey)
+{
+    const int N = *Nptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        long long h = 0, mult = 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h += (long long)rint(regions[4 * (size_t)i + q] / min_side) * mult;
+            mult *= 1000;
+        }
+        ckey[i] = h;
+    }
+}
+
+}  // namespace
+
+namespace {
+__global__ void k_decode_unit(const double *__restrict__ anchors, const float *__restrict__ deltas,
+                              const float *__restrict__ scores, int R, int im_h, int im_w, double eps,
+                              double *pred_u, float *score_u)
+{
+    const int n = R * AZ_NSUB;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
+        az_decode_box(anchors + 4 * (size_t)r, deltas + (size_t)r * 4 * AZ_NSUB + 4 * s, im_h, im_w, eps,
+                      pred_u + 4 * (size_t)c);
+        score_u[c] = scores[c];
+    }
+}
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+static inline int grid_for(int cap, int per) { int g = (cap + per - 1) / per; return g < 1 ? 1 : (g > 2048 ? 2048 : g); }
+
+void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w)
+{
+    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, s, cnt, B0, im_h, im_w);
+}
+
+void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
+                   int batch, float *rois, long long *key, int *grp)
+{
+    hipLaunchKernelGGL(k_rois_keys, dim3(grid_for(cap, TB)), dim3(TB), 0, s, B, Pptr, scale, dedup, batch,
+                       rois, key, grp);
+}
+
+void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const int *Nptr, int cap,
+                    unsigned char *first, const float *rois, const double *B, int *index, int *inv,
+                    float *urois, double *ubox, int *Uptr)
+{
+    const int g = grid_for(cap, TB);
+    hipLaunchKernelGGL(k_first, dim3(g), dim3(TB), 0, s, key, grp, Nptr, first);
+    hipLaunchKernelGGL(k_dedup_rois, dim3(g), dim3(TB), 0, s, key, grp, Nptr, first, rois, B, index, inv,
+                       urois, ubox, Uptr);
+}
+
+void azk_flags_compact(hipStream_t s, AzCounts *cnt, int level, int capR, int capCand, const double *B,
+                       const int *inv, const double *pred_u, const float *score_u, const float *zoom_u,
+                       double Tz, double min_side, int force_root, unsigned char *cflag,
+                       unsigned char *zflag, int *bc_c, int *bc_z, double *Yall, float *Sall, double *Z)
+{
+    const int g = grid_for(capR * AZ_NSUB, TB);
+    hipLaunchKernelGGL(k_flags, dim3(g), dim3(TB), 0, s, cnt, level, inv, pred_u, zoom_u, Tz, min_side,
+                       force_root, cflag, zflag, bc_c, bc_z);
+    hipLaunchKernelGGL(k_compact, dim3(g), dim3(TB), 0, s, cnt, level, capCand, B, inv, pred_u, score_u,
+                       cflag, zflag, bc_c, bc_z, Yall, Sall, Z);
+}
+
+void azk_divide(hipStream_t s, AzCounts *cnt, int level, int capR, int capCh, const double *Z,
+                double min_side, int *choff, double *child, long long *ckey)
+{
+    hipLaunchKernelGGL(k_divide_scan, dim3(1), dim3(1024), 0, s, cnt, level, capCh, Z, choff);
+    hipLaunchKernelGGL(k_divide_emit, dim3(grid_for(capR, TB)), dim3(TB), 0, s, cnt, level, Z, choff,
+                       min_side, child, ckey);
+}
+
+void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,
+                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err)
+{
+    const int g = grid_for(cap, TB);
+    hipLaunchKernelGGL(k_first, dim3(g), dim3(TB), 0, s, key, (const int *)nullptr, Nptr, first);
+    hipLaunchKernelGGL(k_dedup_regions, dim3(g), dim3(TB), 0, s, key, Nptr, capOut, first, child, Bnext,
+                       Pnext, err);
+}
+
+void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int cap, double min_side,
+                     long long *ckey)
+{
+    hipLaunchKernelGGL(k_region_keys, dim3(grid_for(cap, TB)), dim3(TB), 0, s, regions, Nptr, min_side, ckey);
+}
+
+void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, const float *scores, int R,
+                     int im_h, int im_w, double eps, double *pred_u, float *score_u)
+{
+    hipLaunchKernelGGL(k_decode_unit, dim3(grid_for(R * AZ_NSUB, TB)), dim3(TB), 0, s, anchors, deltas,
+                       scores, R, im_h, im_w, eps, pred_u, score_u);
+}

@@ -1,0 +1,328 @@
+// az_head.hip -- the Caffe-resident part of the AZ head on gfx950
+// (models/Pascal/VGG16/az-net/test_fc.prototxt:14-232): RoIPool 7x7 over the cached conv5_3
+// map, the InnerProduct layers as an fp32-MFMA GEMM with a fixed split of K, and the fused
+// epilogue (11+44+1 outputs, sigmoid, box decode, clip).
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is bitwise a k-ordered fmaf chain, so every output row is
+// a fixed function of its input row: the K range is always cut into the same S chunks and the
+// S partial sums are always added in chunk order, whatever the number of rows in flight.  That
+// is what makes az_head_forward (unit call) and az_propose (fused loop) agree bit for bit and
+// makes the result independent of cfg.SEAR.BATCH_SIZE chunking.
+#include "az_dev.h"
+#include <float.h>
+
+namespace {
+
+// ======================================================================================
+// RoIPool (ROIPooling layer, test_fc.prototxt:14-25; semantics of Fast R-CNN's
+// ROIPoolingLayer: C round() of coord*scale, size >= 1, f32 bin size, floor/ceil edges,
+// clamp, empty bin -> 0).  One thread per output element; consecutive threads walk
+// (c, ph, pw) of one roi, so stores are fully coalesced and the window reads of neighbouring
+// bins hit the same cache lines of the 4.9 MB map (L2-resident).
+// ======================================================================================
+__global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat, AzHeadDims d,
+                                                  float spatial_scale, const float *__restrict__ urois,
+                                                  const int *Uptr, float *__restrict__ pool5)
+{
+    const int U = *Uptr;
+    const int PP = d.pooled * d.pooled;
+    const long long total = (long long)U * d.K6;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int u = (int)(idx / d.K6);
+        const int rem = (int)(idx - (long long)u * d.K6);
+        const int c = rem / PP;
+        const int p = rem - c * PP;
+        const int ph = p / d.pooled, pw = p - ph * d.pooled;
+        const float *roi = urois + 5 * (size_t)u;
+        const int rsw = (int)roundf(roi[1] * spatial_scale);
+        const int rsh = (int)roundf(roi[2] * spatial_scale);
+        const int rew = (int)roundf(roi[3] * spatial_scale);
+        const int reh = (int)roundf(roi[4] * spatial_scale);
+        int rh = reh - rsh + 1; rh = rh < 1 ? 1 : rh;
+        int rw = rew - rsw + 1; rw = rw < 1 ? 1 : rw;
+        const float bh = (float)rh / (float)d.pooled;
+        const float bw = (float)rw / (float)d.pooled;
+        int hs = (int)floorf((float)ph * bh) + rsh;
+        int he = (int)ceilf((float)(ph + 1) * bh) + rsh;
+        int ws = (int)floorf((float)pw * bw) + rsw;
+        int we = (int)ceilf((float)(pw + 1) * bw) + rsw;
+        hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
+        ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
+        const bool empty = (he <= hs) || (we <= ws);
+        float m = empty ? 0.0f : -FLT_MAX;
+        const float *plane = feat + (size_t)c * d.H * d.W;
+        for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w) {
+                const float v = plane[h * d.W + w];
+                m = v > m ? v : m;
+            }
+        pool5[idx] = m;
+    }
+}
+
+// ======================================================================================
+// InnerProduct as split-K GEMM on the fp32 matrix cores.
+//   part[s][m][n] = sum_{k in chunk s} x[m][k] * W[n][k]        (k order fixed, see below)
+//   y[m][n]       = act(((part[0] + part[1]) + ...) + b[n])
+// Workgroup = 256 threads = 4 waves; tile 128 (M) x 128 (N) x 32 (K-step).  Wave w owns the
+// 32-column strip w of the tile and all four 32-row strips: 4 accumulators of
+// v_mfma_f32_32x32x2_f32 (64 VGPRs).  Row strips beyond M are skipped wave-uniformly, so a
+// ragged last M-tile costs only its live strips.
+// Operands are staged global -> VGPR (dwordx4) -> LDS (padded rows, ds_write_b128) with the
+// next K-step's loads in flight during the current step's MFMAs; fragments come back with
+// ds_read_b128: lane l reads 4 consecutive k of row (l & 31) at k-offset 4*(l >> 5), which
+// feeds 4 MFMAs (k-pairs {j, 4+j}).  Within each 8-wide k group the accumulation order is
+// therefore k = 0,4,1,5,2,6,3,7 -- fixed, and part of the definition above.
+// The fp32 MFMA takes 64 cycles per SIMD, so LDS and issue bandwidth are far from binding;
+// what matters is keeping HBM loads in flight (2 workgroups/CU, register-prefetched tiles)
+// and keeping the weight panel of one (n, s) group on one XCD's L2 (item -> XCD mapping).
+// ======================================================================================
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BK + 4;          // padded LDS row (floats): 144 B, conflict-free b128 reads
+constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld_guard(const float *base, int row, int nrows, size_t ld, int k, int kend)
+{
+    // rows >= nrows and k >= kend read as zero (k, kend multiples of 4).
+    if (row < nrows && k < kend) return *reinterpret_cast<const float4 *>(base + (size_t)row * ld + k);
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ void __launch_bounds__(256, 2)
+k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
+            const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
+
+    const int M = *Mptr;
+    if (M <= 0) return;
+    const int mt = (M + BM - 1) / BM;
+    const int nt = (N + BN - 1) / BN;
+    const int G = nt * S;                       // (n-tile, k-chunk) groups
+    const int G8 = (G + 7) / 8;
+    const int nitems = G8 * 8 * mt;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = (lane >> 5) * 4;
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        // Items congruent mod 8 run on one XCD (dispatch is round-robin over XCDs); give them
+        // the m-tiles of the same (n, s) groups so the weight panel is fetched once per XCD.
+        const int xcd = item & 7, q = item >> 3;
+        const int g = (q / mt) * 8 + xcd;
+        const int mtile = q % mt;
+        if (g >= G) continue;
+        const int ntile = g / S, s = g - ntile * S;
+        const int m0 = mtile * BM, n0 = ntile * BN;
+        const int k0 = s * Kc;
+        const int kend = min(K, k0 + Kc);
+        const int nk = (kend - k0 + BK - 1) / BK;
+        const int rows_here = min(BM, M - m0);
+        const int n_rt = (rows_here + 31) >> 5;          // live 32-row strips (wave-uniform)
+
+        floatx16 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+        // global -> register staging: thread t owns float4 f = t + 256*i, row f/8, column (f%8)*4
+        float4 ra[4], rb[4];
+        auto gload = [&](int kt) {
+            const int kb = k0 + kt * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + 256 * i;
+                const int row = f >> 3, c4 = (f & 7) * 4;
+                ra[i] = (row < n_rt * 32) ? ld_guard(X, m0 + row, M, (size_t)ldx, kb + c4, kend)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = ld_guard(Wt, n0 + row, N, (size_t)ldw, kb + c4, kend);
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + 256 * i;
+                const int row = f >> 3, c4 = (f & 7) * 4;
+                *reinterpret_cast<float4 *>(&sA[buf][row * LDT + c4]) = ra[i];
+                *reinterpret_cast<float4 *>(&sB[buf][row * LDT + c4]) = rb[i];
+            }
+        };
+
+        gload(0);
+        __syncthreads();                 // previous item's readers are done with both buffers
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) gload(kt + 1);
+            const float *a_base = &sA[cur][lrow * LDT + lk];
+            const float *b_base = &sB[cur][(wave * 32 + lrow) * LDT + lk];
+#pragma unroll
+            for (int g8 = 0; g8 < BK / 8; ++g8) {
+                const float4 bf = *reinterpret_cast<const float4 *>(b_base + g8 * 8);
+                float4 af[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < n_rt) af[r] = *reinterpret_cast<const float4 *>(a_base + r * 32 * LDT + g8 * 8);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < n_rt) {
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].x, bf.x, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].y, bf.y, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].z, bf.z, acc[r], 0, 0, 0);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].w, bf.w, acc[r], 0, 0, 0);
+                    }
+            }
+            if (kt + 1 < nk) lstore(cur ^ 1);
+            __syncthreads();
+        }
+
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+        float *slab = part + (size_t)s * capM * N;
+        const int col = n0 + wave * 32 + (lane & 31);
+        if (col < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < n_rt) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = m0 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        if (row < M) slab[(size_t)row * N + col] = acc[r][e];
+                    }
+                }
+        }
+    }
+}
+
+// y = act(sum_s part[s] + b): partial sums added in chunk order (fixed), then the bias.
+__global__ void __launch_bounds__(256)
+k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, const int *Mptr, int capM,
+            int N, int S, float *__restrict__ y, int ldy, int relu)
+{
+    const int M = *Mptr;
+    const int N4 = N >> 2;                       // N % 4 == 0 (checked by the host)
+    const long long total = (long long)M * N4;
+    const size_t slab = (size_t)capM * N;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / N4);
+        const int n = (int)(idx - (long long)m * N4) * 4;
+        const float *p = part + (size_t)m * N + n;
+        float4 a = *reinterpret_cast<const float4 *>(p);
+        for (int s = 1; s < S; ++s) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + s * slab);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        const float4 b = *reinterpret_cast<const float4 *>(bias + n);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        if (relu) {
+            a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f;
+            a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(y + (size_t)m * ldy + n) = a;
+    }
+}
+
+// ======================================================================================
+// Head epilogue: adj_score (11) + adj_bbox (44) off int7_1, zoom_score (1) off int7_2
+// (test_fc.prototxt:146-220), Sigmoid on the 12 scores (:221-232), then _bbox_pred +
+// _clip_boxes (lib/detect/test.py:106-151) against the roi's own anchor box.
+// One workgroup per roi; each of the 56 outputs is a lane-strided fmaf chain
+// (k = lane, lane+64, ...) followed by an xor-butterfly sum -- again a fixed order per row.
+// Wt rows: 0..10 adj_score, 11..54 adj_bbox, 55 zoom_score; row stride ldt.
+// ======================================================================================
+constexpr int NOUT = AZ_NSUB * 5 + 1;   // 56
+
+__global__ void __launch_bounds__(256)
+k_head_tail(const float *__restrict__ h7, AzHeadDims d, const float *__restrict__ Wt, int ldt,
+            const float *__restrict__ bt, const double *__restrict__ ubox, const int *Uptr, int im_h,
+            int im_w, double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+{
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // n7 floats + NOUT
+    float *hrow = sh;
+    float *outv = sh + d.n7;
+    const int U = *Uptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = blockIdx.x; u < U; u += gridDim.x) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < d.n7; k += blockDim.x) hrow[k] = h7[(size_t)u * d.n7 + k];
+        __syncthreads();
+        for (int o = wave; o < NOUT; o += 4) {
+            const bool zoom = (o == NOUT - 1);
+            const int K = zoom ? d.n72 : d.n71;
+            const float *x = zoom ? hrow + d.n71 : hrow;
+            const float *w = Wt + (size_t)o * ldt;
+            float acc = 0.f;
+            for (int k = lane; k < K; k += 64) acc = fmaf(x[k], w[k], acc);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            if (lane == 0) outv[o] = acc + bt[o];
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < AZ_NSUB) {
+            // Caffe Sigmoid: 1. / (1. + exp(-x)) -- f32 exp, double divide, f32 store.
+            const float e = expf(-outv[t]);
+            const float sc = (float)(1.0 / (1.0 + (double)e));
+            score_u[(size_t)u * AZ_NSUB + t] = sc;
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d4[q] = outv[AZ_NSUB + 4 * t + q];
+                delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
+            }
+            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps,
+                          pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+        } else if (t == 64) {
+            const float e = expf(-outv[NOUT - 1]);
+            zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
+        }
+    }
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------
+void azk_roi_pool(hipStream_t s, const float *feat, AzHeadDims d, float spatial_scale, const float *urois,
+                  const int *Uptr, int capU, float *pool5)
+{
+    (void)capU;
+    hipLaunchKernelGGL(k_roi_pool, dim3(2048), dim3(256), 0, s, feat, d, spatial_scale, urois, Uptr, pool5);
+}
+
+// Fixed number of K chunks per layer (independent of M; see the header comment).
+int azk_fc_split(int K)
+{
+    if (K >= 16384) return 16;
+    if (K >= 2048) return 8;
+    if (K >= 512) return 2;
+    return 1;
+}
+
+void azk_fc(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const float *bias,
+            const int *Mptr, int capM, int N, int K, int S, float *part, float *y, int ldy, int relu)
+{
+    // chunk length: a multiple of the K-step so that chunk boundaries never depend on M
+    int Kc = (K + S - 1) / S;
+    Kc = (Kc + BK - 1) / BK * BK;
+    hipLaunchKernelGGL(k_fc_splitk, dim3(GEMM_GRID), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
+                       Kc, part);
+    hipLaunchKernelGGL(k_fc_reduce, dim3(1024), dim3(256), 0, s, part, bias, Mptr, capM, N, S, y, ldy, relu);
+}
+
+void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
+                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps,
+                   float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+{
+    (void)capU;
+    const int ldt = d.n71 > d.n72 ? d.n71 : d.n72;
+    const size_t shm = (size_t)(d.n7 + NOUT) * sizeof(float);
+    hipLaunchKernelGGL(k_head_tail, dim3(1024), dim3(256), shm, s, h7, d, Wt, ldt, bt, ubox, Uptr, im_h,
+                       im_w, eps, zoom_u, score_u, delta_u, pred_u);
+}

@@ -1,0 +1,368 @@
+// az_select.hip -- final proposal selection (lib/detect/test.py:393-401) and greedy NMS
+// (lib/utils/nms.pyx:17-68) on gfx950.  Integer / comparison work: a radix select over the
+// score bits instead of a full sort, wave ballots for the NMS suppression bitmask, and a
+// 64-box-at-a-time scan over that mask.  Built with -ffp-contract=off (IoU in f32 with
+// one rounding per operation and IEEE division, as the Cython code computes it).
+#include "az_dev.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned score_key(float f)
+{
+    // order-preserving map float -> uint (ascending)
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ int block_excl_scan1024(int v, int *total, int *wsum)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { int t = wsum[w]; wsum[w] = run; run += t; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    *total = wsum[16];
+    return wsum[wid] + inc - v;
+}
+
+constexpr int TOPK_MAX = 4096;
+
+// Top-k of N scores, descending, ties broken by the lower candidate index (a stable
+// descending sort; NumPy's argsort(-aScores) is unstable, tied candidates are duplicates of
+// one roi and carry identical boxes).  Single workgroup: 3 radix-select passes over the
+// order-preserving key (11 + 11 + 10 bits) find the k-th largest key T; everything above T
+// plus the first (k - count_above) items equal to T is gathered in index order, then ranked.
+__global__ void __launch_bounds__(1024)
+k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *sel_idx, int *nsel,
+       const double *__restrict__ Yall, const float *__restrict__ Sall, double *Yout, float *Sout)
+{
+    __shared__ int hist[2048];
+    __shared__ int wsum[17];
+    __shared__ unsigned s_prefix, s_mask;
+    __shared__ int s_need;
+    __shared__ unsigned skey[TOPK_MAX];
+    __shared__ int sidx[TOPK_MAX];
+    __shared__ int s_ngt, s_neq;
+
+    int N = *Nptr;
+    if (N > capN) N = capN;
+    if (k > TOPK_MAX) k = TOPK_MAX;
+    const int ksel = k < N ? k : N;
+    const int tid = threadIdx.x;
+    unsigned T = 0;
+    int need_eq = 0;
+    if (ksel < N) {
+        if (tid == 0) { s_prefix = 0; s_mask = 0; s_need = ksel; }
+        __syncthreads();
+        const int shifts[3] = {21, 10, 0};
+        const int widths[3] = {11, 11, 10};
+        for (int p = 0; p < 3; ++p) {
+            const int sh = shifts[p], nb = 1 << widths[p];
+            for (int b = tid; b < 2048; b += blockDim.x) hist[b] = 0;
+            __syncthreads();
+            const unsigned prefix = s_prefix, mask = s_mask;
+            for (int i = tid; i < N; i += blockDim.x) {
+                const unsigned key = score_key(scores[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // lane L owns bins [nb - (L+1)*per, nb - L*per): descending chunks
+                const int per = nb / 64;
+                const int hi = nb - tid * per;
+                int csum = 0;
+                for (int b = hi - 1; b >= hi - per; --b) csum += hist[b];
+                int inc = csum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    int t = __shfl_up(inc, d, 64);
+                    if (tid >= d) inc += t;
+                }
+                const int need = s_need;
+                const int before = inc - csum;           // items in chunks above this lane's
+                const bool mine = (before < need) && (inc >= need);
+                if (mine) {
+                    int run = before, b = hi - 1;
+                    for (; b >= hi - per; --b) {
+                        if (run + hist[b] >= need) break;
+                        run += hist[b];
+                    }
+                    s_prefix = prefix | ((unsigned)b << sh);
+                    s_mask = mask | ((unsigned)(nb - 1) << sh);
+                    s_need = need - run;                 // still needed inside bin b
+                }
+            }
+            __syncthreads();
+        }
+        T = s_prefix;
+        need_eq = s_need;
+    }
+    if (tid == 0) { s_ngt = 0; s_neq = 0; }
+    __syncthreads();
+    // ordered gather (index order) of keys > T, and of the first need_eq keys == T
+    for (int base = 0; base < N; base += blockDim.x) {
+        const int i = base + tid;
+        unsigned key = 0;
+        int gt = 0, eq = 0;
+        if (i < N) {
+            key = score_key(scores[i]);
+            if (ksel == N) gt = 1;
+            else { gt = key > T; eq = key == T; }
+        }
+        int tot_gt, tot_eq;
+        const int ogt = block_excl_scan1024(gt, &tot_gt, wsum);
+        const int oeq = block_excl_scan1024(eq, &tot_eq, wsum);
+        const int ngt = s_ngt, neq = s_neq;
+        if (gt && ngt + ogt < TOPK_MAX) { skey[ngt + ogt] = key; sidx[ngt + ogt] = i; }
+        __syncthreads();
+        if (tid == 0) { s_ngt = ngt + tot_gt; s_neq = neq + tot_eq; }
+        __syncthreads();
+        // equal keys go after all greater keys: store them at the tail slots [ksel - need_eq, ksel)
+        if (eq && neq + oeq < need_eq) {
+            const int slot = ksel - need_eq + neq + oeq;
+            skey[slot] = key; sidx[slot] = i;
+        }
+    }
+    __syncthreads();
+    // rank the ksel gathered items: descending key, then ascending index
+    for (int a = tid; a < ksel; a += blockDim.x) {
+        const unsigned ka = skey[a];
+        const int ia = sidx[a];
+        int rank = 0;
+        for (int b = 0; b < ksel; ++b) {
+            const unsigned kb = skey[b];
+            rank += (kb > ka) | ((kb == ka) & (sidx[b] < ia));
+        }
+        sel_idx[rank] = ia;
+        if (Yout) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Yout[(size_t)rank * 4 + q] = Yall[(size_t)ia * 4 + q];
+            Sout[rank] = Sall[ia];
+        }
+    }
+    if (tid == 0) *nsel = ksel;
+}
+
+// aScores >= Tc selection (lib/detect/test.py:393-395), original order, double compare.
+__global__ void __launch_bounds__(1024)
+k_thresh_select(const float *__restrict__ scores, const int *Nptr, int capN, double Tc, int cap_out,
+                int *sel_idx, int *nsel, const double *__restrict__ Yall, const float *__restrict__ Sall,
+                double *Yout, float *Sout)
+{
+    __shared__ int wsum[17];
+    int N = *Nptr;
+    if (N > capN) N = capN;
+    int run = 0;
+    for (int base = 0; base < N; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int fl = (i < N) && ((double)scores[i] >= Tc);
+        int tot;
+        const int off = block_excl_scan1024(fl, &tot, wsum);
+        const int dst = run + off;
+        if (fl && dst < cap_out) {
+            sel_idx[dst] = i;
+            if (Yout) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Yout[(size_t)dst * 4 + q] = Yall[(size_t)i * 4 + q];
+                Sout[dst] = Sall[i];
+            }
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) *nsel = run;      // may exceed cap_out: the host reports AZ_ERR_CAPACITY
+}
+
+// ======================================================================================
+// NMS, lib/utils/nms.pyx:17-68.
+// 1. order = argsort(scores)[::-1] as a rank sort (descending score; equal scores: higher
+//    original index first, which is what a stable ascending sort reversed yields).
+// 2. suppression bitmask: mask[i][w] bit b = (j = 64w + b > i) && IoU(i, j) >= thresh, built
+//    with one wave ballot per (row, 64-column word).
+// 3. greedy scan 64 sorted boxes at a time: the 64x64 diagonal word block resolves the
+//    dependencies inside the chunk, then the kept rows are OR-ed into the removed bitmap.
+// ======================================================================================
+__global__ void k_nms_rank(const float *__restrict__ dets, int n, int *order, float *sdets)
+{
+    __shared__ float ss[256];
+    const int nblk = (n + 255) / 256;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int i = b * 256 + threadIdx.x;
+        const float si = i < n ? dets[5 * (size_t)i + 4] : 0.f;
+        int rank = 0;
+        for (int t = 0; t < nblk; ++t) {
+            const int j = t * 256 + threadIdx.x;
+            __syncthreads();
+            ss[threadIdx.x] = j < n ? dets[5 * (size_t)j + 4] : 0.f;
+            __syncthreads();
+            const int lim = min(256, n - t * 256);
+            for (int jj = 0; jj < lim; ++jj) {
+                const float sj = ss[jj];
+                const int jidx = t * 256 + jj;
+                rank += (sj > si) | ((sj == si) & (jidx > i));
+            }
+        }
+        if (i < n) {
+            order[rank] = i;
+            const float x1 = dets[5 * (size_t)i], y1 = dets[5 * (size_t)i + 1];
+            const float x2 = dets[5 * (size_t)i + 2], y2 = dets[5 * (size_t)i + 3];
+            float w = x2 - x1; w = w + 1.0f;
+            float h = y2 - y1; h = h + 1.0f;
+            float *o = sdets + 5 * (size_t)rank;
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = w * h;      // areas, nms.pyx:24
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long long *mask)
+{
+    const int W = (n + 63) / 64;
+    const int cb = blockIdx.x, rb = blockIdx.y;
+    if (cb < rb) return;                       // every j in this word <= every i: nothing to suppress
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = cb * 64 + lane;
+    float jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0, jarea = 0;
+    if (j < n) {
+        const float *d = sdets + 5 * (size_t)j;
+        jx1 = d[0]; jy1 = d[1]; jx2 = d[2]; jy2 = d[3]; jarea = d[4];
+    }
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int i = rb * 64 + rr;
+        if (i >= n) break;
+        const float *d = sdets + 5 * (size_t)i;
+        const float ix1 = d[0], iy1 = d[1], ix2 = d[2], iy2 = d[3], iarea = d[4];
+        const float xx1 = ix1 >= jx1 ? ix1 : jx1;          // nms.pyx:11-15 max/min
+        const float yy1 = iy1 >= jy1 ? iy1 : jy1;
+        const float xx2 = ix2 <= jx2 ? ix2 : jx2;
+        const float yy2 = iy2 <= jy2 ? iy2 : jy2;
+        float tw = xx2 - xx1; tw = tw + 1.0f;
+        float th = yy2 - yy1; th = th + 1.0f;
+        const float w = 0.0f >= tw ? 0.0f : tw;
+        const float h = 0.0f >= th ? 0.0f : th;
+        const float inter = w * h;
+        float den = iarea + jarea; den = den - inter;
+        const float ovr = inter / den;
+        const bool sup = (j < n) && (j > i) && ((double)ovr >= thresh);
+        const unsigned long long word = __ballot(sup);
+        if (lane == 0) mask[(size_t)i * W + cb] = word;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ order, int n,
+           unsigned long long *removed_g, long long *keep, int *nkeep)
+{
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_nk;
+    extern __shared__ unsigned long long removed[];   // W words
+    const int W = (n + 63) / 64;
+    (void)removed_g;
+    for (int w = threadIdx.x; w < W; w += blockDim.x) removed[w] = 0ull;
+    if (threadIdx.x == 0) s_nk = 0;
+    __syncthreads();
+    for (int c = 0; c < W; ++c) {
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const int row = c * 64 + lane;
+            const unsigned long long diag = row < n ? mask[(size_t)row * W + c] : 0ull;
+            const int nvalid = min(64, n - c * 64);
+            unsigned long long alive = ~removed[c];
+            if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
+            unsigned long long kept = 0ull;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            for (int b = 0; b < nvalid; ++b) {
+                const unsigned long long drow =
+                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                    (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+                if ((alive >> b) & 1ull) { kept |= (1ull << b); alive &= ~drow; }
+            }
+            // append kept boxes (sorted positions -> original indices, visiting order)
+            const int nk = s_nk;
+            if ((kept >> lane) & 1ull) {
+                const int pos = __popcll(kept & ((1ull << lane) - 1ull));
+                keep[nk + pos] = order[row];
+            }
+            if (lane == 0) { s_kept = kept; s_nk = nk + __popcll(kept); }
+        }
+        __syncthreads();
+        unsigned long long kept = s_kept;
+        for (int w = c + 1 + threadIdx.x; w < W; w += blockDim.x) {
+            unsigned long long acc = removed[w];
+            unsigned long long kk = kept;
+            while (kk) {
+                const int b = __ffsll((long long)kk) - 1;
+                kk &= kk - 1;
+                acc |= mask[(size_t)(c * 64 + b) * W + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nkeep = s_nk;
+}
+
+__global__ void k_gather_sel(const int *__restrict__ sel_idx, const int *nsel, int cap,
+                             const double *__restrict__ Yall, const float *__restrict__ Sall, double *Yout,
+                             float *Sout)
+{
+    int n = *nsel;
+    if (n > cap) n = cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int src = sel_idx[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Yout[(size_t)i * 4 + q] = Yall[(size_t)src * 4 + q];
+        Sout[i] = Sall[src];
+    }
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------
+void azk_topk_full(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
+                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout)
+{
+    hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, s, scores, Nptr, capN, k, sel_idx, nsel, Yall, Sall,
+                       Yout, Sout);
+}
+
+void azk_topk(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx, int *nsel)
+{
+    azk_topk_full(s, scores, Nptr, capN, k, sel_idx, nsel, nullptr, nullptr, nullptr, nullptr);
+}
+
+void azk_thresh_select_full(hipStream_t s, const float *scores, const int *Nptr, int capN, double Tc,
+                            int cap_out, int *sel_idx, int *nsel, const double *Yall, const float *Sall,
+                            double *Yout, float *Sout)
+{
+    hipLaunchKernelGGL(k_thresh_select, dim3(1), dim3(1024), 0, s, scores, Nptr, capN, Tc, cap_out, sel_idx,
+                       nsel, Yall, Sall, Yout, Sout);
+}
+
+void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap, const double *Yall,
+                    const float *Sall, double *Yout, float *Sout)
+{
+    hipLaunchKernelGGL(k_gather_sel, dim3(64), dim3(256), 0, s, sel_idx, nsel, cap, Yall, Sall, Yout, Sout);
+}
+
+void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
+             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep)
+{
+    if (n <= 0) { hipMemsetAsync(nkeep, 0, sizeof(int), s); return; }
+    const int W = (n + 63) / 64;
+    const int g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_nms_rank, dim3(g > 1024 ? 1024 : g), dim3(256), 0, s, dets, n, order, sdets);
+    hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask);
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)W * sizeof(unsigned long long), s, mask, order,
+                       n, removed, keep, nkeep);
+}

@@ -1,0 +1,56 @@
+"""VGG16 conv1_1 .. conv5_3 forward in PyTorch-ROCm (fp32).
+
+This is the one place torch computes anything: north_star keeps the backbone on
+PyTorch-ROCm and the hand-written HIP path starts at its output.  Architecture per
+models/Pascal/VGG16/az-net/test.prototxt:16-384: thirteen 3x3 pad-1 convs + ReLU, four
+2x2/2 max-pools in Caffe's ceil mode (600x1000 -> 38x63), no pool5.  torchvision is not
+available offline, so the stack is spelled out here; weights are seeded He-normal unless
+a dict of Caffe-layout arrays is supplied.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# (name, out_channels) with 'P' = max-pool
+VGG16_CONV = [("conv1_1", 64), ("conv1_2", 64), "P", ("conv2_1", 128), ("conv2_2", 128), "P",
+              ("conv3_1", 256), ("conv3_2", 256), ("conv3_3", 256), "P",
+              ("conv4_1", 512), ("conv4_2", 512), ("conv4_3", 512), "P",
+              ("conv5_1", 512), ("conv5_2", 512), ("conv5_3", 512)]
+
+
+class VGG16Conv5(object):
+    def __init__(self, device="cuda:0", seed=4321, weights=None, width_div=1):
+        """width_div > 1 shrinks every layer's channel count (fast tests); 1 = real VGG16."""
+        self.device = torch.device(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.layers = []
+        cin = 3
+        for item in VGG16_CONV:
+            if item == "P":
+                self.layers.append(None)
+                continue
+            name, cout = item
+            cout = max(4, cout // width_div)
+            if weights is not None and name in weights:
+                w = torch.from_numpy(np.ascontiguousarray(weights[name][0], dtype=np.float32))
+                b = torch.from_numpy(np.ascontiguousarray(weights[name][1], dtype=np.float32))
+            else:
+                w = torch.randn(cout, cin, 3, 3, generator=g) * float(np.sqrt(2.0 / (cin * 9)))
+                b = torch.zeros(cout)
+            self.layers.append((name, w.to(self.device), b.to(self.device)))
+            cin = cout
+        self.out_channels = cin
+
+    @torch.no_grad()
+    def forward(self, blob):
+        """blob: [1,3,H,W] float32 (BGR, mean-subtracted), NumPy or torch -> conv5_3 [1,C,h,w]
+        contiguous fp32 tensor on the device."""
+        x = torch.as_tensor(blob, dtype=torch.float32, device=self.device)
+        for layer in self.layers:
+            if layer is None:
+                x = F.max_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
+            else:
+                x = F.relu_(F.conv2d(x, layer[1], layer[2], padding=1))
+        return x.contiguous()
+
+    __call__ = forward

@@ -1,0 +1,362 @@
+"""ctypes binding of libaznet_hip.so (include/aznet_hip.h).
+
+This is the only way the Python host code reaches the GPU path, and there is no
+fallback: if the shared library is missing or no gfx950 device is visible, the
+constructors raise.  NumPy owns every host buffer; torch (when used) owns the
+feature map and hands over a raw device pointer.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaznet_hip.so")
+
+AZ_MAX_LEVELS = 16
+AZ_NUM_SUBREG = 11
+AZ_OK = 0
+AZ_ERR_INVALID, AZ_ERR_HIP, AZ_ERR_CAPACITY, AZ_ERR_STATE, AZ_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+_ERR_NAMES = {-1: "AZ_ERR_INVALID", -2: "AZ_ERR_HIP", -3: "AZ_ERR_CAPACITY", -4: "AZ_ERR_STATE",
+              -5: "AZ_ERR_NO_DEVICE"}
+
+# every symbol include/aznet_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "az_version", "az_create", "az_destroy", "az_last_error", "az_set_limits", "az_load_head",
+    "az_set_feature_map_dev", "az_set_feature_map_host", "az_propose", "az_propose_launch",
+    "az_propose_fetch", "az_last_candidates", "az_divide_region", "az_sift_dup", "az_roi_dedup",
+    "az_roi_pool", "az_head_forward", "az_decode_filter", "az_topk", "az_nms", "az_set_profiling",
+    "az_last_kernel_times", "az_stream",
+]
+
+
+class AzParams(ctypes.Structure):
+    _fields_ = [("im_h", ctypes.c_int32), ("im_w", ctypes.c_int32), ("scale", ctypes.c_double),
+                ("Tz", ctypes.c_double), ("Tc", ctypes.c_double), ("dedup", ctypes.c_double),
+                ("eps", ctypes.c_double), ("min_side", ctypes.c_double),
+                ("batch_size", ctypes.c_int32), ("num_proposals", ctypes.c_int32),
+                ("fixed_num", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class AzStats(ctypes.Structure):
+    _fields_ = [("n_proposals", ctypes.c_int32), ("num_eval", ctypes.c_int32),
+                ("depth", ctypes.c_int32), ("n_levels", ctypes.c_int32),
+                ("n_candidates", ctypes.c_int32),
+                ("level_regions", ctypes.c_int32 * AZ_MAX_LEVELS),
+                ("level_unique", ctypes.c_int32 * AZ_MAX_LEVELS),
+                ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS)]
+
+
+class AzError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "%s (%d): %s" % (_ERR_NAMES.get(code, "AZ_ERR"), code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libaznet_hip.so and declare prototypes.  Fails loudly when it is absent:
+    build it with `python -c 'import __graft_entry__ as g; g.build()'` or
+    `make -C az-net_amd/csrc`."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("libaznet_hip.so not found at %s -- the HIP extension is required "
+                          "(no CPU fallback); run make -C az-net_amd/csrc" % p)
+    L = ctypes.CDLL(p)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    fp, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
+    ip, i64p = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)
+    cip = ctypes.POINTER(ctypes.c_int)
+    L.az_version.restype = ctypes.c_char_p
+    L.az_version.argtypes = []
+    L.az_create.argtypes = [ci, ctypes.POINTER(vp)]
+    L.az_destroy.argtypes = [vp]
+    L.az_last_error.restype = ctypes.c_char_p
+    L.az_last_error.argtypes = [vp]
+    L.az_set_limits.argtypes = [vp, ci, ci]
+    L.az_load_head.argtypes = [vp, ci, ci, ci, ci] + [fp] * 12
+    L.az_set_feature_map_dev.argtypes = [vp, vp, ci, ci, ci]
+    L.az_set_feature_map_host.argtypes = [vp, fp, ci, ci, ci]
+    L.az_propose.argtypes = [vp, ctypes.POINTER(AzParams), dp, fp, ci, cip, ctypes.POINTER(AzStats)]
+    L.az_propose_launch.argtypes = [vp, ctypes.POINTER(AzParams)]
+    L.az_propose_fetch.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
+    L.az_last_candidates.argtypes = [vp, dp, fp, ci, cip]
+    L.az_divide_region.argtypes = [vp, dp, ci, cd, dp, ci, cip]
+    L.az_sift_dup.argtypes = [vp, dp, ci, cd, dp, ci, cip]
+    L.az_roi_dedup.argtypes = [vp, dp, ci, cd, cd, ci, fp, ip, ip, cip]
+    L.az_roi_pool.argtypes = [vp, fp, ci, fp]
+    L.az_head_forward.argtypes = [vp, fp, ci, fp, fp, fp]
+    L.az_decode_filter.argtypes = [vp, dp, fp, fp, ci, ci, ci, cd, cd, dp, fp, ci, cip]
+    L.az_topk.argtypes = [vp, fp, ci, ci, ip, cip]
+    L.az_nms.argtypes = [vp, fp, ci, cd, i64p, cip]
+    L.az_set_profiling.argtypes = [vp, ci]
+    L.az_last_kernel_times.argtypes = [vp, ctypes.c_char_p, fp, ip, ci, cip]
+    L.az_stream.restype = vp
+    L.az_stream.argtypes = [vp]
+    for name in SYMBOLS:
+        if name not in ("az_version", "az_last_error", "az_stream"):
+            getattr(L, name).restype = ci
+    if path is None:
+        _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+class AzContext(object):
+    """One GPU's search context (az_ctx).  Not thread-safe; one per process/GPU."""
+
+    def __init__(self, device=0, max_regions=None, max_candidates=None):
+        self.L = load_library()
+        h = ctypes.c_void_p()
+        rc = self.L.az_create(int(device), ctypes.byref(h))
+        if rc != AZ_OK:
+            raise AzError(rc, "az_create(device=%d) failed: a gfx950 GPU is required, there is no "
+                              "CPU fallback" % device)
+        self.h = h
+        self.device = int(device)
+        self.dims = None
+        self.feat_shape = None
+        self._feat_keepalive = None
+        if max_regions is not None:
+            self._chk(self.L.az_set_limits(self.h, int(max_regions),
+                                           int(max_candidates or max_regions * AZ_NUM_SUBREG)))
+        self.max_regions = max_regions or 16384
+        self.max_candidates = max_candidates or self.max_regions * AZ_NUM_SUBREG
+
+    def _chk(self, rc):
+        if rc != AZ_OK:
+            raise AzError(rc, self.L.az_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.az_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup --------------------------------------------------------------------
+    def load_head(self, head):
+        """head: dict of Caffe-layout fp32 arrays W6,b6,W71,b71,W72,b72,Was,bas,Wab,bab,Wz,bz."""
+        W6 = _f32(head["W6"])
+        n6, K6 = W6.shape
+        assert K6 % 49 == 0
+        C = K6 // 49
+        n71, n72 = head["W71"].shape[0], head["W72"].shape[0]
+        assert head["W71"].shape == (n71, n6) and head["W72"].shape == (n72, n6)
+        assert head["Was"].shape == (11, n71) and head["Wab"].shape == (44, n71)
+        assert head["Wz"].shape == (1, n72)
+        arrs = [W6] + [_f32(head[k]) for k in ("b6", "W71", "b71", "W72", "b72", "Was", "bas", "Wab",
+                                                 "bab", "Wz", "bz")]
+        self._chk(self.L.az_load_head(self.h, C, n6, n71, n72, *[_p(a, ctypes.c_float) for a in arrs]))
+        self.dims = dict(C=C, n6=n6, n71=n71, n72=n72, K6=K6)
+
+    def set_feature_map(self, fmap):
+        """fmap: [1,C,H,W] or [C,H,W]; a NumPy array (copied to HBM) or a CUDA torch tensor
+        (borrowed: its data_ptr is handed to the library, the tensor is kept alive here)."""
+        if isinstance(fmap, np.ndarray):
+            a = _f32(fmap)
+            if a.ndim == 4:
+                assert a.shape[0] == 1
+                a = a[0]
+            C, H, W = a.shape
+            self._chk(self.L.az_set_feature_map_host(self.h, _p(a, ctypes.c_float), C, H, W))
+            self._feat_keepalive = None
+        else:   # torch tensor on this device
+            t = fmap
+            if t.dim() == 4:
+                assert t.shape[0] == 1
+                t = t[0]
+            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32"
+            C, H, W = (int(x) for x in t.shape)
+            self._chk(self.L.az_set_feature_map_dev(self.h, ctypes.c_void_p(t.data_ptr()), C, H, W))
+            self._feat_keepalive = fmap
+        self.feat_shape = (C, H, W)
+
+    # ---- hot path -----------------------------------------------------------------
+    @staticmethod
+    def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
+                    dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000):
+        return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
+                        float(eps), float(min_side), int(batch_size), int(num_proposals),
+                        1 if fixed_num else 0, 0)
+
+    def propose(self, params, want_scores=False, want_stats=False):
+        cap = params.num_proposals if params.fixed_num else self.max_candidates
+        boxes = np.empty((cap, 4), dtype=np.float64)
+        scores = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        st = AzStats()
+        self._chk(self.L.az_propose(self.h, ctypes.byref(params), _p(boxes, ctypes.c_double),
+                                    _p(scores, ctypes.c_float), cap, ctypes.byref(n), ctypes.byref(st)))
+        out = [boxes[:n.value].copy() if n.value < cap else boxes]
+        if want_scores:
+            out.append(scores[:n.value].copy())
+        if want_stats:
+            out.append(st)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def propose_launch(self, params):
+        self._last_params = params
+        self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
+
+    def propose_fetch(self, want_scores=False, want_stats=False):
+        params = self._last_params
+        cap = params.num_proposals if params.fixed_num else self.max_candidates
+        boxes = np.empty((cap, 4), dtype=np.float64)
+        scores = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        st = AzStats()
+        self._chk(self.L.az_propose_fetch(self.h, _p(boxes, ctypes.c_double), _p(scores, ctypes.c_float),
+                                          cap, ctypes.byref(n), ctypes.byref(st)))
+        out = [boxes[:n.value].copy()]
+        if want_scores:
+            out.append(scores[:n.value].copy())
+        if want_stats:
+            out.append(st)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def last_candidates(self):
+        cap = self.max_candidates
+        boxes = np.empty((cap, 4), dtype=np.float64)
+        scores = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_last_candidates(self.h, _p(boxes, ctypes.c_double), _p(scores, ctypes.c_float),
+                                            cap, ctypes.byref(n)))
+        return boxes[:n.value].copy(), scores[:n.value].copy()
+
+    # ---- unit entry points ----------------------------------------------------------
+    def divide_region(self, regions, min_side=10.0):
+        regions = _f64(regions).reshape(-1, 4)
+        cap = max(16, 12 * regions.shape[0] + 64)
+        out = np.empty((cap, 4), dtype=np.float64)
+        n = ctypes.c_int(0)
+        rc = self.L.az_divide_region(self.h, _p(regions, ctypes.c_double), regions.shape[0], float(min_side),
+                                     _p(out, ctypes.c_double), cap, ctypes.byref(n))
+        if rc == AZ_ERR_CAPACITY and n.value > cap:
+            cap = n.value
+            out = np.empty((cap, 4), dtype=np.float64)
+            rc = self.L.az_divide_region(self.h, _p(regions, ctypes.c_double), regions.shape[0],
+                                         float(min_side), _p(out, ctypes.c_double), cap, ctypes.byref(n))
+        self._chk(rc)
+        return out[:n.value].copy()
+
+    def sift_dup(self, regions, min_side=10.0):
+        regions = _f64(regions).reshape(-1, 4)
+        cap = max(1, regions.shape[0])
+        out = np.empty((cap, 4), dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_sift_dup(self.h, _p(regions, ctypes.c_double), regions.shape[0], float(min_side),
+                                     _p(out, ctypes.c_double), cap, ctypes.byref(n)))
+        return out[:n.value].copy()
+
+    def roi_dedup(self, boxes, scale, dedup=1. / 16., batch_size=10000):
+        boxes = _f64(boxes).reshape(-1, 4)
+        P = boxes.shape[0]
+        rois = np.empty((max(P, 1), 5), dtype=np.float32)
+        index = np.empty((max(P, 1),), dtype=np.int32)
+        inv = np.empty((max(P, 1),), dtype=np.int32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_roi_dedup(self.h, _p(boxes, ctypes.c_double), P, float(scale), float(dedup),
+                                      int(batch_size), _p(rois, ctypes.c_float), _p(index, ctypes.c_int32),
+                                      _p(inv, ctypes.c_int32), ctypes.byref(n)))
+        return rois[:P].copy(), index[:n.value].copy(), inv[:P].copy()
+
+    def roi_pool(self, rois):
+        rois = _f32(rois).reshape(-1, 5)
+        R = rois.shape[0]
+        out = np.empty((max(R, 1), self.dims["K6"]), dtype=np.float32)
+        self._chk(self.L.az_roi_pool(self.h, _p(rois, ctypes.c_float), R, _p(out, ctypes.c_float)))
+        return out[:R]
+
+    def head_forward(self, rois):
+        rois = _f32(rois).reshape(-1, 5)
+        R = rois.shape[0]
+        z = np.empty((max(R, 1), 1), dtype=np.float32)
+        p = np.empty((max(R, 1), AZ_NUM_SUBREG), dtype=np.float32)
+        d = np.empty((max(R, 1), 4 * AZ_NUM_SUBREG), dtype=np.float32)
+        self._chk(self.L.az_head_forward(self.h, _p(rois, ctypes.c_float), R, _p(z, ctypes.c_float),
+                                         _p(p, ctypes.c_float), _p(d, ctypes.c_float)))
+        return z[:R], p[:R], d[:R]
+
+    def decode_filter(self, anchors, deltas, scores, im_h, im_w, eps=1e-14, min_side=10.0):
+        anchors = _f64(anchors).reshape(-1, 4)
+        R = anchors.shape[0]
+        deltas = _f32(deltas).reshape(R, 4 * AZ_NUM_SUBREG)
+        scores = _f32(scores).reshape(R, AZ_NUM_SUBREG)
+        cap = max(1, R * AZ_NUM_SUBREG)
+        ob = np.empty((cap, 4), dtype=np.float64)
+        os_ = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_decode_filter(self.h, _p(anchors, ctypes.c_double), _p(deltas, ctypes.c_float),
+                                          _p(scores, ctypes.c_float), R, int(im_h), int(im_w), float(eps),
+                                          float(min_side), _p(ob, ctypes.c_double), _p(os_, ctypes.c_float),
+                                          cap, ctypes.byref(n)))
+        return ob[:n.value].copy(), os_[:n.value].copy()
+
+    def topk(self, scores, k):
+        scores = _f32(scores).ravel()
+        idx = np.empty((max(1, min(k, scores.shape[0])),), dtype=np.int32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_topk(self.h, _p(scores, ctypes.c_float), scores.shape[0], int(k),
+                                 _p(idx, ctypes.c_int32), ctypes.byref(n)))
+        return idx[:n.value].copy()
+
+    def nms(self, dets, thresh):
+        dets = _f32(dets).reshape(-1, 5)
+        N = dets.shape[0]
+        keep = np.empty((max(N, 1),), dtype=np.int64)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_nms(self.h, _p(dets, ctypes.c_float), N, float(thresh), _p(keep, ctypes.c_int64),
+                                ctypes.byref(n)))
+        return keep[:n.value].copy()
+
+    # ---- measurement -----------------------------------------------------------------
+    def set_profiling(self, on):
+        self._chk(self.L.az_set_profiling(self.h, 1 if on else 0))
+
+    def last_kernel_times(self, cap=512):
+        names = ctypes.create_string_buffer(32 * cap)
+        ms = np.zeros(cap, dtype=np.float32)
+        lv = np.zeros(cap, dtype=np.int32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_last_kernel_times(self.h, names, _p(ms, ctypes.c_float), _p(lv, ctypes.c_int32),
+                                              cap, ctypes.byref(n)))
+        out = []
+        for i in range(min(n.value, cap)):
+            nm = names.raw[32 * i:32 * i + 32].split(b"\0", 1)[0].decode()
+            out.append((nm, int(lv[i]), float(ms[i])))
+        return out
+
+    def stream_handle(self):
+        return self.L.az_stream(self.h)
+
+
+_default_ctx = None
+
+
+def default_context(device=0):
+    """Process-wide context used by the drop-in modules (utils.cython_div / cython_nms)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = AzContext(device)
+    return _default_ctx

@@ -1,0 +1,83 @@
+"""HipAZNet: the object that stands where the reference's pair of caffe.Net objects stood
+(tools/prop_az.py:92-98 builds `nets = {'full': net, 'fc': net_fc}`).
+
+Two ways to use it, both without any CPU compute path:
+  * whole search on the GPU -- `detect.test.im_propose(HipAZNet, im)` calls `propose()`,
+    i.e. az_propose (the level loop never returns to the host);
+  * as a pycaffe-shaped net -- `.blobs[name].reshape(...)` and
+    `.forward(blobs=[...], data=... | conv5_3=..., rois=...)` return `zoom_prob`,
+    `adj_prob`, `adj_bbox` (and `conv5_3` when asked), which is exactly the surface
+    lib/detect/test.py:221-242 drives.  The reference's own Python loop (or the oracle's)
+    can therefore run on top of the HIP head unchanged; tests use that to check the fused
+    loop against the per-level path.
+"""
+import numpy as np
+
+from aznet_hip import ffi
+
+
+class _Blob(object):
+    def __init__(self):
+        self.shape = None
+
+    def reshape(self, *shape):
+        self.shape = tuple(shape)
+
+
+class HipAZNet(object):
+    def __init__(self, head, backbone=None, device=0, name="vgg16_az_net_hip", ctx=None,
+                 max_regions=None):
+        self.ctx = ctx or ffi.AzContext(device, max_regions=max_regions)
+        self.ctx.load_head(head)
+        self.backbone = backbone
+        self.name = name
+        self.blobs = {k: _Blob() for k in ("data", "rois", "conv5_3")}
+        self._conv = None          # what the last forward/set_image left in HBM
+
+    # dict-of-two compatibility: net['full'] / net['fc'] / 'fc' in net.keys()
+    def __getitem__(self, k):
+        if k in ("full", "fc"):
+            return self
+        raise KeyError(k)
+
+    def keys(self):
+        return ["full", "fc"]
+
+    def __contains__(self, k):
+        return k in ("full", "fc")
+
+    # ---- feature map -----------------------------------------------------------------
+    def set_conv(self, conv):
+        """conv: NumPy [1,C,H,W] (copied to HBM) or a CUDA torch tensor (borrowed)."""
+        self.ctx.set_feature_map(conv)
+        self._conv = conv
+
+    def compute_conv(self, data_blob):
+        """Run the torch backbone on a [1,3,H,W] blob and hand conv5_3 to the HIP context."""
+        if self.backbone is None:
+            raise RuntimeError("HipAZNet has no backbone: supply conv5_3 with set_conv()")
+        import torch
+        conv = self.backbone(data_blob)
+        torch.cuda.current_stream(conv.device).synchronize()   # the ctx stream reads it next
+        self.set_conv(conv)
+        return conv
+
+    # ---- whole search ------------------------------------------------------------------
+    def propose(self, params, want_scores=False, want_stats=False):
+        return self.ctx.propose(params, want_scores=want_scores, want_stats=want_stats)
+
+    # ---- pycaffe-shaped surface ----------------------------------------------------------
+    def forward(self, blobs=None, **kw):
+        rois = np.ascontiguousarray(kw["rois"], dtype=np.float32)
+        if "conv5_3" in kw:
+            conv = kw["conv5_3"]
+            if conv is not self._conv:
+                self.set_conv(conv)
+        elif "data" in kw:
+            self.compute_conv(kw["data"])
+        z, p, d = self.ctx.head_forward(rois)
+        out = {"zoom_prob": z, "adj_prob": p, "adj_bbox": d}
+        if blobs:
+            for b in blobs:
+                out[b] = self._conv
+        return out

@@ -1,0 +1,169 @@
+"""Proposal API of the reference's `detect.test` (lib/detect/test.py), on the MI355X path.
+
+Same names, arguments and return types as the reference for the proposal path:
+    im_propose(net, im, return_conv=False, num_proposals=None)      test.py:346-414
+    test_proposals(net, imdb)                                       test.py:486-539
+    apply_nms(all_boxes, thresh)                                    test.py:467-484
+    divide_region(regions)                                          test.py:153-161
+`net` is a `HipAZNet` (it also answers net['full'] / net['fc'], so the reference's dict of
+two nets keeps working).  The level loop itself -- roi projection and dedup, RoIPool, fc
+head, decode, filter, zoom selection, divide_region, top-K -- runs inside one az_propose
+call on the GPU; this module only prepares the image blob, reads `cfg`, and formats the
+result.  There is no CPU implementation here to fall back to.
+"""
+import os
+import pickle
+
+import numpy as np
+
+from detect.config import cfg, get_output_dir
+from utils.timer import Timer
+from utils.blob import im_list_to_blob
+from utils.cython_nms import nms
+import utils.cython_div as div
+from aznet_hip import ffi
+
+
+def _im_scale(im_shape):
+    """Scale of the single test scale, capped by MAX_SIZE (test.py:40-50)."""
+    im_size_min = np.min(im_shape[0:2])
+    im_size_max = np.max(im_shape[0:2])
+    scales = []
+    for target_size in cfg.TEST.SCALES:
+        im_scale = float(target_size) / float(im_size_min)
+        if np.round(im_scale * im_size_max) > cfg.TEST.MAX_SIZE:
+            im_scale = float(cfg.TEST.MAX_SIZE) / float(im_size_max)
+        scales.append(im_scale)
+    return scales
+
+
+def _resize_bilinear(im, scale):
+    """cv2.resize(..., fx=scale, fy=scale, INTER_LINEAR) stand-in (cv2 is not available
+    offline): half-pixel-centre bilinear, output size round(dim * scale)."""
+    if scale == 1.0:
+        return im
+    import torch
+    import torch.nn.functional as F
+    h = int(round(im.shape[0] * scale))
+    w = int(round(im.shape[1] * scale))
+    t = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1)))[None]
+    t = F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
+    return t[0].numpy().transpose(1, 2, 0)
+
+
+def _get_image_blob(im):
+    """BGR uint8 image -> ([1,3,H,W] float32 mean-subtracted blob, scale factors)
+    (test.py:27-59).  Computed once per image; the reference recomputes it at every level."""
+    im_orig = im.astype(np.float32, copy=True)
+    im_orig -= cfg.PIXEL_MEANS.astype(np.float32)
+    scales = _im_scale(im_orig.shape)
+    ims = [_resize_bilinear(im_orig, s) for s in scales]
+    return im_list_to_blob(ims), np.array(scales)
+
+
+def divide_region(regions):
+    """test.py:153-161."""
+    regions = np.ascontiguousarray(regions, dtype=np.float64)
+    return div.divide_region(regions, float(cfg.SEAR.MIN_SIDE))
+
+
+def _params(im_shape, scale, num_proposals):
+    fixed = not ((cfg.SEAR.FIXED_PROPOSAL_NUM is False) and (num_proposals is None))
+    if num_proposals is None:
+        num_proposals = cfg.SEAR.NUM_PROPOSALS
+    return ffi.AzContext.make_params(
+        im_shape[0], im_shape[1], scale, cfg.SEAR.Tz, num_proposals=num_proposals, fixed_num=fixed,
+        Tc=cfg.SEAR.Tc, dedup=cfg.DEDUP_BOXES, eps=cfg.EPS, min_side=cfg.SEAR.MIN_SIDE,
+        batch_size=cfg.SEAR.BATCH_SIZE)
+
+
+def _append_boxes(boxes):
+    """test.py:320-344 (off by default, cfg.SEAR.APPEND_BOXES)."""
+    num_boxes = boxes.shape[0]
+    num_subregs = cfg.SEAR.APPEND_TEMP.shape[2]
+    widths = boxes[:, [2]] - boxes[:, [0]]
+    heights = boxes[:, [3]] - boxes[:, [1]]
+    L = np.hstack((widths, heights, widths, heights))[:, :, np.newaxis]
+    delta = np.hstack((boxes[:, [0]], boxes[:, [1]], boxes[:, [0]], boxes[:, [1]]))[:, :, np.newaxis]
+    subs = np.transpose((L * cfg.SEAR.APPEND_TEMP) + delta, [2, 0, 1])
+    subs = np.ascontiguousarray(subs.reshape((num_boxes * num_subregs, 4)), dtype=np.float64)
+    return div._sift_dup(subs, 1 / cfg.DEDUP_BOXES)
+
+
+def im_propose(net, im, return_conv=False, num_proposals=None, conv=None):
+    """Generate object proposals with AZ-Net (test.py:346-414).
+
+    net: HipAZNet (or the reference-style dict {'full': HipAZNet, 'fc': HipAZNet})
+    im:  HxWx3 uint8/float image, BGR
+    conv (extension): a precomputed conv5_3 {name: array/tensor} to skip the backbone.
+    Returns Y [n,4] float64 (x1,y1,x2,y2 in original pixels), and the conv dict when
+    return_conv is set."""
+    hnet = net["full"] if isinstance(net, dict) else net
+    scales = _im_scale(im.shape)
+    if conv is None:
+        blob, _ = _get_image_blob(im)
+        conv_t = hnet.compute_conv(blob)
+        conv = {name: conv_t for name in cfg.SEAR.FRCNN_CONV}
+    else:
+        hnet.set_conv(conv[cfg.SEAR.AZ_CONV[0]])
+    params = _params(im.shape, scales[0], num_proposals)
+    Y, st = hnet.propose(params, want_stats=True)
+    if cfg.SEAR.APPEND_BOXES:
+        Y = _append_boxes(Y)
+        Y[:, 0::4] = np.maximum(Y[:, 0::4], 0)
+        Y[:, 1::4] = np.maximum(Y[:, 1::4], 0)
+        Y[:, 2::4] = np.minimum(Y[:, 2::4], im.shape[1] - 1)
+        Y[:, 3::4] = np.minimum(Y[:, 3::4], im.shape[0] - 1)
+    print('{0} proposals, evaluate {1} regions, reaches depth {2}.'
+          .format(Y.shape[0], st.num_eval, st.depth))
+    if return_conv:
+        return Y, conv
+    return Y
+
+
+def apply_nms(all_boxes, thresh):
+    """Per-class, per-image NMS over detections (test.py:467-484)."""
+    num_classes = len(all_boxes)
+    num_images = len(all_boxes[0])
+    nms_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    for cls_ind in range(num_classes):
+        for im_ind in range(num_images):
+            dets = all_boxes[cls_ind][im_ind]
+            if isinstance(dets, list) and dets == []:
+                continue
+            keep = nms(np.ascontiguousarray(dets, dtype=np.float32), thresh)
+            if len(keep) == 0:
+                continue
+            nms_boxes[cls_ind][im_ind] = dets[keep, :].copy()
+    return nms_boxes
+
+
+def test_proposals(net, imdb):
+    """Proposals for every image of an imdb, written as proposals.pkl with the
+    reference's layout {'boxes': [n_i x 4 float64], 'time': avg seconds, 'recall': 0}
+    (test.py:486-539).  imdb needs .image_index, .name and .image_at(i) or
+    .image_path_at(i) (a .npy path; cv2.imread is not available offline)."""
+    num_images = len(imdb.image_index)
+    prop_boxes = [[] for _ in range(num_images)]
+    hnet = net["full"] if isinstance(net, dict) else net
+    output_dir = get_output_dir(imdb, hnet)
+    if not os.path.exists(output_dir):
+        os.makedirs(output_dir)
+    _t = {'im_prop': Timer()}
+    num_boxes = 0.0
+    for i in range(num_images):
+        im = imdb.image_at(i) if hasattr(imdb, "image_at") else np.load(imdb.image_path_at(i))
+        _t['im_prop'].tic()
+        prop_boxes[i] = im_propose(net, im)
+        _t['im_prop'].toc()
+        num_boxes += prop_boxes[i].shape[0]
+        print('im_prop: {:d}/{:d} {:.3f}s'.format(i + 1, num_images, _t['im_prop'].average_time))
+    recall = 0            # the reference's recall bookkeeping is commented out (test.py:515-531)
+    prop = {'boxes': prop_boxes, 'time': _t['im_prop'].average_time, 'recall': recall}
+    prop_file = os.path.join(output_dir, 'proposals.pkl')
+    with open(prop_file, 'wb') as f:
+        pickle.dump(prop, f, pickle.HIGHEST_PROTOCOL)
+    print('The recall is {:.3f}'.format(recall))
+    print('On average, {0} boxes per image are generated'.format(num_boxes / num_images))
+    print('The average proposal generation time is {:.3f}s'.format(_t['im_prop'].average_time))
+    return prop_file

@@ -1,0 +1,333 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI
+(aznet_hip.ffi -> libaznet_hip.so), against the oracle and the golden vectors.
+
+Tolerances: integer / index / f64-geometry work is compared bit-exactly.  The fp32 head
+is compared at 1e-4 (north_star); the box decode at rtol 1e-6 because its only inexact
+operation is the f32 exp (NumPy's SIMD expf vs the device's, ulp-level).
+"""
+import numpy as np
+import pytest
+
+from helpers import load, unpack_list, TRACES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    from oracle import az_oracle as orc
+    return ffi, synth, HipAZNet, orc
+
+
+@pytest.fixture(scope="module")
+def small(mods):
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="small")
+    return net, head
+
+
+@pytest.fixture(scope="module")
+def full(mods):
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+    net = HipAZNet(head, name="full", max_regions=4096)
+    return net, head
+
+
+# ---------------------------------------------------------------- geometry, bit-exact
+def test_divide_region_golden(small):
+    ctx = small[0].ctx
+    g = load("g1_divide_region.npz")
+    for i in range(len(g["sizes"])):
+        for a, b in zip(unpack_list(g, "root%d_in" % i), unpack_list(g, "root%d_out" % i)):
+            got = ctx.divide_region(a, 10.0)
+            assert got.shape == b.shape and np.array_equal(got, b)
+    assert np.array_equal(ctx.divide_region(g["rand_in"], 10.0), g["rand_out"])
+    for i, s in enumerate(unpack_list(g, "single_out")):
+        assert np.array_equal(ctx.divide_region(g["rand_in"][i:i + 1], 10.0), s)
+    assert ctx.divide_region(np.zeros((0, 4)), 10.0).shape == (0, 4)
+
+
+def test_sift_dup_golden(small):
+    ctx = small[0].ctx
+    g = load("g2_sift_dup.npz")
+    assert np.array_equal(ctx.sift_dup(g["in"], 10.0), g["out10"])
+    assert np.array_equal(ctx.sift_dup(g["in"], 16.0), g["out16"])
+
+
+def test_cython_dropins(small, mods):
+    import utils.cython_div as cdiv
+    import utils.cython_nms as cnms
+    g = load("g1_divide_region.npz")
+    assert np.array_equal(cdiv.divide_region(g["rand_in"], 10.0), g["rand_out"])
+    with pytest.raises(ValueError):
+        cdiv.divide_region(g["rand_in"].astype(np.float32), 10.0)
+    with pytest.raises(ValueError):
+        cnms.nms(np.zeros((3, 5)), 0.5)
+    assert cnms.nms(np.zeros((0, 5), dtype=np.float32), 0.5) == []
+
+
+@pytest.mark.parametrize("scale,batch", [(1.0, 10000), (1.6, 10000), (0.9375, 100), (1.0, 7)])
+def test_roi_dedup_vs_oracle(small, mods, scale, batch):
+    ffi, synth, HipAZNet, orc = mods
+    ctx = small[0].ctx
+    B = np.array([[0, 0, 999.0, 599.0]])
+    for _ in range(5):
+        rois, index, inv = ctx.roi_dedup(B, scale, 1. / 16., batch)
+        ref_rois = orc.get_rois_blob(B, scale)
+        assert np.array_equal(rois, ref_rois)
+        # oracle dedup is per BATCH_SIZE chunk (test.py:195-218)
+        ref_index, ref_inv, off = [], [], 0
+        for s in range(0, B.shape[0], batch):
+            idx, iv = orc.roi_dedup(ref_rois[s:s + batch])
+            ref_index.append(idx + s)
+            ref_inv.append(iv + off)
+            off += len(idx)
+        assert np.array_equal(index, np.concatenate(ref_index))
+        assert np.array_equal(inv, np.concatenate(ref_inv))
+        B = orc.divide_region(B, 10)
+
+
+def test_decode_filter_golden(small):
+    ctx = small[0].ctx
+    g = load("g4_decode.npz")
+    b, s = ctx.decode_filter(g["boxes"], g["deltas"], g["scores"], 600, 1000)
+    assert b.shape == g["unwrap_boxes"].shape            # same candidates survive the filter
+    np.testing.assert_allclose(b, g["unwrap_boxes"], rtol=1e-6, atol=1e-9)
+    assert np.array_equal(s, g["unwrap_scores"])
+
+
+def test_nms_golden(small):
+    ctx = small[0].ctx
+    g = load("g5_nms.npz")
+    for i in range(int(g["ncases"])):
+        keep = ctx.nms(g["dets%d" % i], float(g["thresh%d" % i]))
+        assert list(keep) == list(g["keep%d" % i]), "nms case %d" % i
+
+
+def test_topk_vs_numpy(small):
+    ctx = small[0].ctx
+    rng = np.random.RandomState(5)
+    for n, k in [(1, 300), (299, 300), (300, 300), (301, 300), (8129, 300), (30019, 300), (5000, 2000)]:
+        s = rng.uniform(0, 1, n).astype(np.float32)
+        if n > 1000:
+            s[rng.randint(0, n, n // 4)] = s[rng.randint(0, n, n // 4)]      # ties
+        idx = ctx.topk(s, k)
+        ref = np.argsort(-s.astype(np.float64), kind="stable")[:k]
+        assert np.array_equal(idx, ref), (n, k)
+
+
+# ---------------------------------------------------------------- head
+def _rand_rois(rng, n, W, H):
+    x1 = rng.uniform(0, W - 20, n)
+    y1 = rng.uniform(0, H - 20, n)
+    w = rng.uniform(8, W / 2, n)
+    h = rng.uniform(8, H / 2, n)
+    r = np.stack([np.zeros(n), x1, y1, np.minimum(x1 + w, W - 1), np.minimum(y1 + h, H - 1)], 1)
+    r[0] = [0, 0, 0, W - 1, H - 1]
+    if n > 3:
+        r[1] = [0, 8, 8, 8, 8]                       # .5 rounding, one cell
+        r[2] = [0, W - 5, H - 5, W + 200, H + 300]   # hangs off the map -> empty bins
+    return r.astype(np.float32)
+
+
+def test_roi_pool_bit_exact(small, mods):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    fmap = synth.make_feature_map(3, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(1), 300, 1000, 600)
+    got = net.ctx.roi_pool(rois)
+    ref = orc.roi_pool(fmap[0], rois)
+    assert np.array_equal(got, ref)
+
+
+def test_roi_pool_full_width_bit_exact(full, mods):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = full
+    fmap = synth.make_feature_map(4, 512, 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(2), 40, 1000, 600)
+    assert np.array_equal(net.ctx.roi_pool(rois), orc.roi_pool(fmap[0], rois))
+
+
+@pytest.mark.parametrize("R", [1, 8, 41, 130, 300])
+def test_head_forward_small(small, mods, R):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    fmap = synth.make_feature_map(3, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(R), R, 1000, 600)
+    z, p, d = net.ctx.head_forward(rois)
+    zr, pr, dr = orc.head_forward(head, fmap[0], rois)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(p, pr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(d, dr, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("R", [1, 33, 130])
+def test_head_forward_full(full, mods, R):
+    """Full-size head (25088 -> 4096 -> {1024 -> 11+44, 256 -> 1}) vs the BLAS oracle."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = full
+    fmap = synth.make_feature_map(4, 512, 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(R), R, 1000, 600)
+    z, p, d = net.ctx.head_forward(rois)
+    zr, pr, dr = orc.head_forward(head, fmap[0], rois)
+    np.testing.assert_allclose(z, zr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(p, pr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(d, dr, rtol=1e-4, atol=1e-4)
+
+
+def test_head_rows_independent_of_batch(small, mods):
+    """Each roi's outputs are a fixed function of that roi: same bits whatever else is in
+    the batch (needed for chunk-independence and for unit-vs-fused agreement)."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    fmap = synth.make_feature_map(3, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(9), 200, 1000, 600)
+    z, p, d = net.ctx.head_forward(rois)
+    z1, p1, d1 = net.ctx.head_forward(rois[37:38])
+    z2, p2, d2 = net.ctx.head_forward(rois[100:170])
+    assert np.array_equal(z[37:38], z1) and np.array_equal(p[37:38], p1) and np.array_equal(d[37:38], d1)
+    assert np.array_equal(z[100:170], z2) and np.array_equal(p[100:170], p2) and np.array_equal(d[100:170], d2)
+
+
+# ---------------------------------------------------------------- whole loop
+def _oracle_loop_on_gpu_head(orc, net, fmap, H, W, scale, cfg):
+    """The oracle's level loop with the HIP head injected as the pycaffe-shaped net --
+    the same seam the reference's Python uses (test.py:221-236)."""
+    return orc.im_propose({"full": net, "fc": net}, (H, W), scale, cfg, data_blob=None,
+                          return_trace=True)
+
+
+@pytest.mark.parametrize("H,W,tzq,batch", [(600, 1000, 0.0, 10000), (375, 500, 0.55, 10000),
+                                           (480, 640, 0.4, 10000), (640, 853, 0.5, 100),
+                                           (600, 1000, 1.5, 10000)])
+def test_fused_loop_equals_per_level_loop(small, mods, H, W, tzq, batch):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    scale = 600.0 / min(H, W)
+    if np.round(scale * max(H, W)) > 1000:
+        scale = 1000.0 / max(H, W)
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    fmap = synth.make_feature_map(5, synth.SMALL_DIMS["C"], fh, fw)
+    net.set_conv(fmap)
+    # choose Tz from the zoom scores of a full-tree run
+    if tzq in (0.0, 1.5):
+        Tz = tzq
+    else:
+        p0 = ffi.AzContext.make_params(H, W, scale, 0.0, batch_size=batch)
+        net.propose(p0)
+        zs = []
+        B = np.array([[0, 0, W - 1.0, H - 1.0]])
+        for _ in range(orc.num_levels(H, W) - 1):
+            zs.append(net.ctx.head_forward(orc.get_rois_blob(B, scale))[0].ravel())
+            B = orc.divide_region(B, 10)
+        Tz = float(np.quantile(np.concatenate(zs).astype(np.float64), tzq))
+    params = ffi.AzContext.make_params(H, W, scale, Tz, batch_size=batch)
+    Y, S, st = net.propose(params, want_scores=True, want_stats=True)
+    cfg = orc.OracleCfg(Tz=Tz, BATCH_SIZE=batch)
+
+    class Injected(object):      # pycaffe-shaped view of the HIP head
+        name = "inj"
+        blobs = net.blobs
+
+        def forward(self, blobs=None, **kw):
+            kw.pop("data", None)
+            kw["conv5_3"] = fmap
+            return net.forward(blobs=blobs, **kw)
+
+    inj = Injected()
+    Yref, tr = orc.im_propose({"full": inj, "fc": inj}, (H, W), scale, cfg, return_trace=True)
+    # structure: same regions per level, same unique counts, same depth / eval count
+    assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
+    for l, lev in enumerate(tr["levels"]):
+        assert st.level_regions[l] == lev["B"].shape[0]
+        assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"])
+        assert st.level_zoomed[l] == len(lev["indZ"])
+    Yall, Sall = net.ctx.last_candidates()
+    assert Yall.shape == tr["Y_all"].shape
+    assert np.array_equal(Sall.astype(np.float64), tr["aScores"])          # scores: same bits
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-6, atol=1e-9)    # decode: exp ulps
+    # selection: identical candidate indices in identical order (stable ties)
+    ref_idx = np.argsort(-tr["aScores"], kind="stable")[:300]
+    assert Y.shape == (min(300, Yall.shape[0]), 4)
+    assert np.array_equal(Y, Yall[ref_idx])
+    assert np.array_equal(S, Sall[ref_idx])
+    # NumPy's own (unstable) argsort picks the same boxes up to permutation of exact ties
+    np.testing.assert_allclose(np.sort(Yref, axis=0), np.sort(tr["Y_all"][ref_idx], axis=0), rtol=0, atol=0)
+
+
+def test_fused_loop_vs_cpu_oracle_head(small, mods):
+    """End-to-end against the pure-CPU oracle (BLAS head): scores/boxes within 1e-4."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    H, W = 600, 1000
+    fmap = synth.make_feature_map(5, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    params = ffi.AzContext.make_params(H, W, 1.0, 0.0)
+    Y, S = net.propose(params, want_scores=True)
+    onet = orc.OracleNet(head, feat_fn=lambda d: fmap)
+    Yref, tr = orc.im_propose({"full": onet, "fc": onet}, (H, W), 1.0, orc.OracleCfg(Tz=0.0), return_trace=True)
+    Yall, Sall = net.ctx.last_candidates()
+    assert Yall.shape == tr["Y_all"].shape
+    np.testing.assert_allclose(Sall, tr["aScores"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=1e-3)
+    # top-300 sets agree except where scores tie within the tolerance
+    kth = np.sort(tr["aScores"])[::-1][299]
+    sure = tr["aScores"] > kth + 2e-4
+    sel = set(map(tuple, np.round(Y, 2)))
+    for b in np.round(tr["Y_all"][sure], 2):
+        assert tuple(b) in sel
+
+
+def test_threshold_mode(small, mods):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    fmap = synth.make_feature_map(5, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    params = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, fixed_num=False, Tc=0.6)
+    Y, S = net.propose(params, want_scores=True)
+    Yall, Sall = net.ctx.last_candidates()
+    keep = np.where(Sall.astype(np.float64) >= 0.6)[0]
+    assert np.array_equal(Y, Yall[keep]) and np.array_equal(S, Sall[keep])
+
+
+def test_error_behaviour(small, mods):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    with pytest.raises(ffi.AzError):
+        net.propose(ffi.AzContext.make_params(15, 15, 1.0, 0.0))       # no level fits
+    with pytest.raises(ffi.AzError):
+        net.ctx.set_feature_map(np.zeros((1, 3, 4, 4), dtype=np.float32))   # wrong channels
+
+
+def test_full_size_fused_loop(full, mods):
+    """BASELINE config: 600x1000, full head, Tz = 0: tree [1,8,32,134,564], 8129 candidates."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = full
+    fmap = synth.make_feature_map(4, 512, 38, 63)
+    net.set_conv(fmap)
+    Y, S, st = net.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0), want_scores=True, want_stats=True)
+    assert list(st.level_regions[:5]) == [1, 8, 32, 134, 564]
+    assert list(st.level_unique[:5]) == [1, 8, 32, 130, 517]
+    assert st.num_eval == 739 and st.depth == 5 and Y.shape == (300, 4)
+    assert np.all(np.diff(S) <= 0)                      # sorted by score
+    assert np.all(Y[:, 0] >= 0) and np.all(Y[:, 2] <= 999) and np.all(Y[:, 3] <= 599)
+    assert np.all(np.minimum(Y[:, 2] - Y[:, 0], Y[:, 3] - Y[:, 1]) + 1 >= 10)
+    # per-level head vs the fused loop on the level-4 regions: same bits
+    B = np.array([[0, 0, 999.0, 599.0]])
+    for _ in range(3):
+        B = orc.divide_region(B, 10)
+    rois = orc.get_rois_blob(B, 1.0)
+    idx, inv = orc.roi_dedup(rois)
+    z, p, d = net.ctx.head_forward(rois[idx])
+    zr, pr, dr = orc.head_forward(head, fmap[0], rois[idx][:16])
+    np.testing.assert_allclose(z[:16], zr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(p[:16], pr, rtol=0, atol=1e-4)
