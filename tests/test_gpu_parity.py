@@ -2,8 +2,9 @@
 (aznet_hip.ffi -> libaznet_hip.so), against the oracle and the golden vectors.
 
 Tolerances: integer / index / f64-geometry work is compared bit-exactly.  The fp32 head
-is compared at 1e-4 (north_star); the box decode at rtol 1e-6 because its only inexact
-operation is the f32 exp (NumPy's SIMD expf vs the device's, ulp-level).
+is compared at 1e-4 (north_star); decoded boxes at 1e-4 px absolute, because the only inexact
+operation of the decode is the f32 exp (NumPy's SIMD expf vs the device's differ by an ulp,
+which a 1000-px box width turns into <= 4e-5 px).
 """
 import numpy as np
 import pytest
@@ -96,7 +97,7 @@ def test_decode_filter_golden(small):
     g = load("g4_decode.npz")
     b, s = ctx.decode_filter(g["boxes"], g["deltas"], g["scores"], 600, 1000)
     assert b.shape == g["unwrap_boxes"].shape            # same candidates survive the filter
-    np.testing.assert_allclose(b, g["unwrap_boxes"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(b, g["unwrap_boxes"], rtol=0, atol=1e-4)      # px; f32-exp ulps x box size
     assert np.array_equal(s, g["unwrap_scores"])
 
 
@@ -254,7 +255,7 @@ def test_fused_loop_equals_per_level_loop(small, mods, H, W, tzq, batch):
     Yall, Sall = net.ctx.last_candidates()
     assert Yall.shape == tr["Y_all"].shape
     assert np.array_equal(Sall.astype(np.float64), tr["aScores"])          # scores: same bits
-    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-6, atol=1e-9)    # decode: exp ulps
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=0, atol=1e-4)       # decode: f32-exp ulps, px
     # selection: identical candidate indices in identical order (stable ties)
     ref_idx = np.argsort(-tr["aScores"], kind="stable")[:300]
     assert Y.shape == (min(300, Yall.shape[0]), 4)
@@ -282,9 +283,8 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
     # top-300 sets agree except where scores tie within the tolerance
     kth = np.sort(tr["aScores"])[::-1][299]
     sure = tr["aScores"] > kth + 2e-4
-    sel = set(map(tuple, np.round(Y, 2)))
-    for b in np.round(tr["Y_all"][sure], 2):
-        assert tuple(b) in sel
+    for b in tr["Y_all"][sure]:
+        assert np.abs(Y - b).max(axis=1).min() < 1e-3
 
 
 def test_threshold_mode(small, mods):
