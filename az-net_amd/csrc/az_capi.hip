@@ -55,7 +55,7 @@ struct az_ctx {
     az_params last{};
     int last_nlev = 0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;
     std::vector<AzEventRec> events;
     std::vector<void *> allocs;        // head-sized buffers (az_load_head)
     std::vector<void *> allocs_geom;   // geometry buffers (first use)
@@ -119,10 +119,13 @@ int ensure_geom(az_ctx *c)
     return AZ_OK;
 }
 
+// Profiling modes (az_set_profiling): bit 0 = time the GEMM launches only, bit 1 = time every
+// launch group, bit 2 = keep events across az_propose calls (read them once at the end).
 struct Timed {
     az_ctx *c; bool on; hipEvent_t a{}, b{}; const char *name; int level;
-    Timed(az_ctx *c_, const char *n, int l) : c(c_), on(c_->profiling), name(n), level(l)
+    Timed(az_ctx *c_, const char *n, int l, int cls = 2) : c(c_), name(n), level(l)
     {
+        on = (c_->profiling & 2) || ((c_->profiling & 1) && cls == 1);
         if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
     }
     ~Timed()
@@ -171,15 +174,17 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5); }
-    { Timed t(c, "fc6", level);
-      azk_fc(c->stream, c->pool5, d.K6, c->W6, d.K6, c->b6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part, c->h6,
-             d.n6, 1); }
-    { Timed t(c, "fc7", level);
-      azk_fc(c->stream, c->h6, d.n6, c->W7, d.n6, c->b7, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part, c->h7,
-             d.n7, 1); }
+    { Timed t(c, "fc6_gemm", level, 1);
+      azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part); }
+    { Timed t(c, "fc6_reduce", level);
+      azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
+    { Timed t(c, "fc7_gemm", level, 1);
+      azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
+    { Timed t(c, "fc7_reduce", level);
+      azk_fc_reduce(c->stream, c->part, c->b7, Uptr, c->maxR, d.n7, c->S7, c->h7, d.n7, 1); }
     { Timed t(c, "head_tail", level);
-      azk_head_tail(c->stream, c->h7, d, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, c->zoom_u,
-                    c->score_u, c->delta_u, c->pred_u); }
+      azk_head_tail(c->stream, c->h7, d, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, c->part,
+                    c->zoom_u, c->score_u, c->delta_u, c->pred_u); }
 }
 
 int check_geom(az_ctx *c)
@@ -275,16 +280,16 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     d.H = d.W = 0;
     c->S6 = azk_fc_split(d.K6);
     c->S7 = azk_fc_split(d.n6);
-    const int ldt = n71 > n72 ? n71 : n72;
     const size_t R = (size_t)c->maxR;
     int rc;
 #define A(p, n) if ((rc = dalloc(c, &c->p, (n))) != AZ_OK) return rc
     A(W6, (size_t)n6 * d.K6); A(b6, n6); A(W7, (size_t)d.n7 * n6); A(b7, d.n7);
-    A(Wt, (size_t)56 * ldt); A(bt, 56);
+    A(Wt, (size_t)56 * d.n7); A(bt, 56);
     A(pool5, R * d.K6);
     {
-        const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7;
-        A(part, p6 > p7 ? p6 : p7);
+        const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7, pt = (size_t)AZK_TAIL_SPLIT * R * 56;
+        const size_t pm = p6 > p7 ? p6 : p7;
+        A(part, pm > pt ? pm : pt);
     }
     A(h6, R * n6); A(h7, R * d.n7);
 #undef A
@@ -296,12 +301,13 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipMemcpy(c->W7 + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7, b71, (size_t)n71 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7 + n71, b72, (size_t)n72 * 4, hipMemcpyHostToDevice));
-    // epilogue weights: rows 0..10 adj_score, 11..54 adj_bbox, 55 zoom_score, row stride ldt
-    HIPCHK(c, hipMemset(c->Wt, 0, (size_t)56 * ldt * 4));
-    HIPCHK(c, hipMemcpy2D(c->Wt, (size_t)ldt * 4, Was, (size_t)n71 * 4, (size_t)n71 * 4, 11, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy2D(c->Wt + (size_t)11 * ldt, (size_t)ldt * 4, Wab, (size_t)n71 * 4, (size_t)n71 * 4, 44,
+    // epilogue weights: rows 0..10 adj_score, 11..54 adj_bbox (columns 0..n71), row 55
+    // zoom_score (columns n71..n7); everything else zero
+    HIPCHK(c, hipMemset(c->Wt, 0, (size_t)56 * d.n7 * 4));
+    HIPCHK(c, hipMemcpy2D(c->Wt, (size_t)d.n7 * 4, Was, (size_t)n71 * 4, (size_t)n71 * 4, 11, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy2D(c->Wt + (size_t)11 * d.n7, (size_t)d.n7 * 4, Wab, (size_t)n71 * 4, (size_t)n71 * 4, 44,
                           hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->Wt + (size_t)55 * ldt, Wz, (size_t)n72 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->Wt + (size_t)55 * d.n7 + n71, Wz, (size_t)n72 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt, bas, 11 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt + 11, bab, 44 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt + 55, bz, 4, hipMemcpyHostToDevice));
@@ -363,7 +369,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
     }
     HIPCHK(c, hipSetDevice(c->device));
-    clear_events(c);
+    if (!(c->profiling & 4)) clear_events(c);
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);
@@ -591,7 +597,7 @@ int az_head_forward(az_ctx *c, const float *rois, int R, float *zoom_prob, float
     int rc = check_ready(c, true);
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
-    clear_events(c);
+    if (!(c->profiling & 4)) clear_events(c);
     launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
@@ -695,7 +701,8 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
 int az_set_profiling(az_ctx *c, int on)
 {
     if (!c) return AZ_ERR_INVALID;
-    c->profiling = on != 0;
+    c->profiling = on;
+    if (!on) clear_events(c);
     return AZ_OK;
 }
 

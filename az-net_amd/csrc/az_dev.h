@@ -82,11 +82,17 @@ void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, 
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5);
-// y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip).
-void azk_fc(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const float *bias,
-            const int *Mptr, int capM, int N, int K, int S, float *part, float *y, int ldy, int relu);
+// y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip):
+// _gemm writes the S partial slabs part[s][m][n], _reduce adds them in order + bias (+ReLU).
+void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
+                 int N, int K, int S, float *part);
+void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
+                   int S, float *y, int ldy, int relu);
+// adj_score + adj_bbox + zoom_score as one more GEMM over Wt [56, n71+n72] (zero-padded rows),
+// then slab sum + bias + sigmoid + box decode/clip.  `part` is GEMM scratch.
+#define AZK_TAIL_SPLIT 8
 void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
-                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps,
+                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *part,
                    float *zoom_u, float *score_u, float *delta_u, double *pred_u);
 int azk_fc_split(int K);
 

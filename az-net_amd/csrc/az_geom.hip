@@ -65,54 +65,46 @@ __global__ void k_rois_keys(const double *__restrict__ B, const int *Pptr, doubl
 }
 
 // first[i] = no j < i carries the same (grp, key): np.unique(return_index=True) keeps the
-// first occurrence.  O(N^2) over LDS tiles; N is a few thousand at most.
+// first occurrence.  One wave per element, lanes stride over j (coalesced key reads served
+// by L2), wave vote at the end: O(N^2 / 64) wave-steps, N is a few thousand at most.
 __global__ void k_first(const long long *__restrict__ key, const int *__restrict__ grp, const int *Nptr,
                         unsigned char *first)
 {
-    __shared__ long long sk[TB];
-    __shared__ int sg[TB];
     const int N = *Nptr;
-    const int nblk = (N + TB - 1) / TB;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
-        const int i = b * TB + threadIdx.x;
-        const long long ki = i < N ? key[i] : 0;
-        const int gi = (i < N && grp) ? grp[i] : 0;
+    const int lane = lane_id();
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        const long long ki = key[i];
+        const int gi = grp ? grp[i] : 0;
         bool dup = false;
-        for (int t = 0; t <= b; ++t) {
-            const int j = t * TB + threadIdx.x;
-            __syncthreads();
-            sk[threadIdx.x] = j < N ? key[j] : 0;
-            sg[threadIdx.x] = (j < N && grp) ? grp[j] : 0;
-            __syncthreads();
-            int lim = i - t * TB;                  // only j < i
-            if (lim > TB) lim = TB;
-            for (int jj = 0; jj < lim; ++jj) dup |= (sk[jj] == ki) & (sg[jj] == gi);
+        for (int j0 = 0; j0 < i; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < i) dup |= (key[j] == ki) & ((grp ? grp[j] : 0) == gi);
+            if (__any(dup)) break;
         }
-        if (i < N) first[i] = dup ? 0 : 1;
+        const bool any_dup = __any(dup);            // vote with all lanes active
+        if (lane == 0) first[i] = any_dup ? 0 : 1;
     }
 }
 
 // slot[i] = number of distinct (grp, key) pairs ordered before i's pair = position of i's
-// pair in np.unique's ascending output.
-__device__ __forceinline__ int dedup_slot(const long long *key, const int *grp, const unsigned char *first,
-                                          int N, int i, long long *sk, int *sg, unsigned char *sf)
+// pair in np.unique's ascending output.  Same wave-per-element scheme, ballot + popcount.
+__device__ __forceinline__ int dedup_slot(const long long *__restrict__ key, const int *__restrict__ grp,
+                                          const unsigned char *__restrict__ first, int N, int i)
 {
-    const long long ki = i < N ? key[i] : 0;
-    const int gi = (i < N && grp) ? grp[i] : 0;
+    const int lane = lane_id();
+    const long long ki = key[i];
+    const int gi = grp ? grp[i] : 0;
     int slot = 0;
-    for (int t = 0; t * TB < N; ++t) {
-        const int j = t * TB + threadIdx.x;
-        __syncthreads();
-        sk[threadIdx.x] = j < N ? key[j] : 0;
-        sg[threadIdx.x] = (j < N && grp) ? grp[j] : 0;
-        sf[threadIdx.x] = j < N ? first[j] : 0;
-        __syncthreads();
-        int lim = N - t * TB;
-        if (lim > TB) lim = TB;
-        for (int jj = 0; jj < lim; ++jj) {
-            const bool less = (sg[jj] < gi) | ((sg[jj] == gi) & (sk[jj] < ki));
-            slot += (sf[jj] != 0) & less;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        bool c = false;
+        if (j < N) {
+            const int gj = grp ? grp[j] : 0;
+            const long long kj = key[j];
+            c = (first[j] != 0) & ((gj < gi) | ((gj == gi) & (kj < ki)));
         }
+        slot += __popcll(__ballot(c));
     }
     return slot;
 }
@@ -124,28 +116,21 @@ __global__ void k_dedup_rois(const long long *__restrict__ key, const int *__res
                              const double *__restrict__ B, int *index, int *inv, float *urois, double *ubox,
                              int *Uptr)
 {
-    __shared__ long long sk[TB];
-    __shared__ int sg[TB];
-    __shared__ unsigned char sf[TB];
     const int N = *Nptr;
-    const int nblk = (N + TB - 1) / TB;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
-        const int i = b * TB + threadIdx.x;
-        const int slot = dedup_slot(key, grp, first, N, i, sk, sg, sf);
-        const bool f = i < N && first[i];
-        if (i < N) inv[i] = slot;
+    const int lane = lane_id();
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    int nfirst = 0;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        const int slot = dedup_slot(key, grp, first, N, i);
+        const bool f = first[i] != 0;
+        if (lane == 0) inv[i] = slot;
         if (f) {
-            index[slot] = i;
-#pragma unroll
-            for (int c = 0; c < 5; ++c) urois[5 * slot + c] = rois[5 * i + c];
-            if (B) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) ubox[4 * slot + c] = B[4 * i + c];
-            }
+            if (lane == 0) { index[slot] = i; ++nfirst; }
+            if (lane < 5) urois[5 * slot + lane] = rois[5 * i + lane];
+            if (B && lane >= 8 && lane < 12) ubox[4 * slot + (lane - 8)] = B[4 * i + (lane - 8)];
         }
-        const int nf = __syncthreads_count(f);
-        if (threadIdx.x == 0 && nf) atomicAdd(Uptr, nf);
     }
+    if (lane == 0 && nfirst) atomicAdd(Uptr, nfirst);
 }
 
 // _sift_dup output (lib/utils/div.pyx:85-89): regions[index] in ascending hash order.
@@ -153,23 +138,18 @@ __global__ void k_dedup_regions(const long long *__restrict__ key, const int *Np
                                 const unsigned char *__restrict__ first, const double *__restrict__ child,
                                 double *Bnext, int *Pnext, int *err)
 {
-    __shared__ long long sk[TB];
-    __shared__ int sg[TB];
-    __shared__ unsigned char sf[TB];
     const int N = *Nptr;
-    const int nblk = (N + TB - 1) / TB;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
-        const int i = b * TB + threadIdx.x;
-        const int slot = dedup_slot(key, nullptr, first, N, i, sk, sg, sf);
-        bool f = i < N && first[i];
-        if (f && slot >= capOut) { atomicOr(err, 1); f = false; }
-        if (f) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) Bnext[4 * slot + c] = child[4 * i + c];
-        }
-        const int nf = __syncthreads_count(f);
-        if (threadIdx.x == 0 && nf) atomicAdd(Pnext, nf);
+    const int lane = lane_id();
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    int nfirst = 0;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        if (!first[i]) continue;                     // wave-uniform
+        const int slot = dedup_slot(key, nullptr, first, N, i);
+        if (slot >= capOut) { if (lane == 0) atomicOr(err, 1); continue; }
+        if (lane < 4) Bnext[4 * slot + lane] = child[4 * i + lane];
+        if (lane == 0) ++nfirst;
     }
+    if (lane == 0 && nfirst) atomicAdd(Pnext, nfirst);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -410,7 +390,7 @@ void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const i
                     unsigned char *first, const float *rois, const double *B, int *index, int *inv,
                     float *urois, double *ubox, int *Uptr)
 {
-    const int g = grid_for(cap, TB);
+    const int g = grid_for(cap, TB / 64);      // one wave per element
     hipLaunchKernelGGL(k_first, dim3(g), dim3(TB), 0, s, key, grp, Nptr, first);
     hipLaunchKernelGGL(k_dedup_rois, dim3(g), dim3(TB), 0, s, key, grp, Nptr, first, rois, B, index, inv,
                        urois, ubox, Uptr);
@@ -439,7 +419,7 @@ void azk_divide(hipStream_t s, AzCounts *cnt, int level, int capR, int capCh, co
 void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,
                        unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err)
 {
-    const int g = grid_for(cap, TB);
+    const int g = grid_for(cap, TB / 64);      // one wave per element
     hipLaunchKernelGGL(k_first, dim3(g), dim3(TB), 0, s, key, (const int *)nullptr, Nptr, first);
     hipLaunchKernelGGL(k_dedup_regions, dim3(g), dim3(TB), 0, s, key, Nptr, capOut, first, child, Bnext,
                        Pnext, err);

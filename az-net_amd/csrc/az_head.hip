@@ -230,57 +230,45 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
 }
 
 // ======================================================================================
-// Head epilogue: adj_score (11) + adj_bbox (44) off int7_1, zoom_score (1) off int7_2
-// (test_fc.prototxt:146-220), Sigmoid on the 12 scores (:221-232), then _bbox_pred +
+// Head epilogue.  adj_score (11) + adj_bbox (44) read int7_1, zoom_score (1) reads int7_2
+// (test_fc.prototxt:146-220): the 56 output rows are stacked into one [56, n71+n72] weight
+// block (zero where a row does not read a column; fmaf(x, 0, acc) == acc exactly), so the
+// three layers are one more call of the split-K GEMM above.  This kernel finishes them:
+// slab sum + bias, Sigmoid on the 12 scores (test_fc.prototxt:221-232), then _bbox_pred +
 // _clip_boxes (lib/detect/test.py:106-151) against the roi's own anchor box.
-// One workgroup per roi; each of the 56 outputs is a lane-strided fmaf chain
-// (k = lane, lane+64, ...) followed by an xor-butterfly sum -- again a fixed order per row.
-// Wt rows: 0..10 adj_score, 11..54 adj_bbox, 55 zoom_score; row stride ldt.
+// One thread per (roi, sub-region) and one per (roi, zoom).
 // ======================================================================================
 constexpr int NOUT = AZ_NSUB * 5 + 1;   // 56
 
 __global__ void __launch_bounds__(256)
-k_head_tail(const float *__restrict__ h7, AzHeadDims d, const float *__restrict__ Wt, int ldt,
-            const float *__restrict__ bt, const double *__restrict__ ubox, const int *Uptr, int im_h,
-            int im_w, double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+k_tail_epilogue(const float *__restrict__ part, int capM, int S, const float *__restrict__ bt,
+                const double *__restrict__ ubox, const int *Uptr, int im_h, int im_w, double eps,
+                float *zoom_u, float *score_u, float *delta_u, double *pred_u)
 {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // n7 floats + NOUT
-    float *hrow = sh;
-    float *outv = sh + d.n7;
     const int U = *Uptr;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int u = blockIdx.x; u < U; u += gridDim.x) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < d.n7; k += blockDim.x) hrow[k] = h7[(size_t)u * d.n7 + k];
-        __syncthreads();
-        for (int o = wave; o < NOUT; o += 4) {
-            const bool zoom = (o == NOUT - 1);
-            const int K = zoom ? d.n72 : d.n71;
-            const float *x = zoom ? hrow + d.n71 : hrow;
-            const float *w = Wt + (size_t)o * ldt;
-            float acc = 0.f;
-            for (int k = lane; k < K; k += 64) acc = fmaf(x[k], w[k], acc);
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-            if (lane == 0) outv[o] = acc + bt[o];
-        }
-        __syncthreads();
-        const int t = threadIdx.x;
+    const int total = U * (AZ_NSUB + 1);
+    const size_t slab = (size_t)capM * NOUT;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int u = idx / (AZ_NSUB + 1), t = idx - u * (AZ_NSUB + 1);
+        const float *row = part + (size_t)u * NOUT;
+        auto out = [&](int o) {
+            float a = row[o];
+            for (int s = 1; s < S; ++s) a += row[o + s * slab];
+            return a + bt[o];
+        };
         if (t < AZ_NSUB) {
             // Caffe Sigmoid: 1. / (1. + exp(-x)) -- f32 exp, double divide, f32 store.
-            const float e = expf(-outv[t]);
-            const float sc = (float)(1.0 / (1.0 + (double)e));
-            score_u[(size_t)u * AZ_NSUB + t] = sc;
+            const float e = expf(-out(t));
+            score_u[(size_t)u * AZ_NSUB + t] = (float)(1.0 / (1.0 + (double)e));
             float d4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                d4[q] = outv[AZ_NSUB + 4 * t + q];
+                d4[q] = out(AZ_NSUB + 4 * t + q);
                 delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
             }
-            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps,
-                          pred_u + ((size_t)u * AZ_NSUB + t) * 4);
-        } else if (t == 64) {
-            const float e = expf(-outv[NOUT - 1]);
+            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+        } else {
+            const float e = expf(-out(NOUT - 1));
             zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
         }
     }
@@ -305,24 +293,32 @@ int azk_fc_split(int K)
     return 1;
 }
 
-void azk_fc(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const float *bias,
-            const int *Mptr, int capM, int N, int K, int S, float *part, float *y, int ldy, int relu)
+static int fc_chunk(int K, int S)
 {
     // chunk length: a multiple of the K-step so that chunk boundaries never depend on M
     int Kc = (K + S - 1) / S;
-    Kc = (Kc + BK - 1) / BK * BK;
+    return (Kc + BK - 1) / BK * BK;
+}
+
+void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
+                 int N, int K, int S, float *part)
+{
     hipLaunchKernelGGL(k_fc_splitk, dim3(GEMM_GRID), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
-                       Kc, part);
+                       fc_chunk(K, S), part);
+}
+
+void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
+                   int S, float *y, int ldy, int relu)
+{
     hipLaunchKernelGGL(k_fc_reduce, dim3(1024), dim3(256), 0, s, part, bias, Mptr, capM, N, S, y, ldy, relu);
 }
 
 void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
-                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps,
+                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *part,
                    float *zoom_u, float *score_u, float *delta_u, double *pred_u)
 {
-    (void)capU;
-    const int ldt = d.n71 > d.n72 ? d.n71 : d.n72;
-    const size_t shm = (size_t)(d.n7 + NOUT) * sizeof(float);
-    hipLaunchKernelGGL(k_head_tail, dim3(1024), dim3(256), shm, s, h7, d, Wt, ldt, bt, ubox, Uptr, im_h,
-                       im_w, eps, zoom_u, score_u, delta_u, pred_u);
+    const int S = AZK_TAIL_SPLIT;
+    azk_fc_gemm(s, h7, d.n7, Wt, d.n7, Uptr, capU, NOUT, d.n7, S, part);
+    hipLaunchKernelGGL(k_tail_epilogue, dim3(256), dim3(256), 0, s, part, capU, S, bt, ubox, Uptr, im_h, im_w,
+                       eps, zoom_u, score_u, delta_u, pred_u);
 }

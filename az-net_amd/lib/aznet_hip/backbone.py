@@ -54,3 +54,13 @@ class VGG16Conv5(object):
         return x.contiguous()
 
     __call__ = forward
+
+    @torch.no_grad()
+    def normalize_output(self, blob):
+        """Synthetic (random-init) weights only: rescale conv5_3's filters so the map has
+        unit RMS on `blob` -- stands in for what training would have done, and keeps the
+        synthetic head's scores and box deltas in a sane range."""
+        rms = float(self.forward(blob).pow(2).mean().sqrt())
+        name, w, b = self.layers[-1]
+        self.layers[-1] = (name, w / rms, b / rms)
+        return rms

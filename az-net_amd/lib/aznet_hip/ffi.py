@@ -331,10 +331,12 @@ class AzContext(object):
         return keep[:n.value].copy()
 
     # ---- measurement -----------------------------------------------------------------
-    def set_profiling(self, on):
-        self._chk(self.L.az_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, mode):
+        """mode bits: 1 = fc GEMM launches only, 2 = every launch group, 4 = accumulate across
+        calls until read; 0 = off."""
+        self._chk(self.L.az_set_profiling(self.h, int(mode)))
 
-    def last_kernel_times(self, cap=512):
+    def last_kernel_times(self, cap=65536):
         names = ctypes.create_string_buffer(32 * cap)
         ms = np.zeros(cap, dtype=np.float32)
         lv = np.zeros(cap, dtype=np.int32)

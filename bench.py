@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: AZ proposals/sec on synthetic 600x1000 images (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one image: az_propose on the cached VGG16 conv5_3
+map (roi projection + dedup, RoIPool, fc head, decode, filter, zoom select, divide_region,
+top-300), 300 proposals copied back to the host.  The conv5_3 map is resident in HBM when
+the timed region starts (it is the hot path's input); the PyTorch backbone is timed
+separately and reported as `end_to_end`.  Images shard one-per-GPU (rank r owns image seed r,
+weak scaling); proposals are exchanged with one RCCL all-gather per batch of images.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
+dominant kernel (the fp32-MFMA fc GEMM, timed with HIP events on the ctx stream during the
+timed steps) and `cpu_baseline` (the oracle's NumPy/C/BLAS restatement on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "az-net_amd", "lib"))
+sys.path.insert(0, REPO)
+
+H_IM, W_IM = 600, 1000
+NUM_PROPOSALS = 300
+# per RoI 216 119 808 FLOP for the whole head; the fc GEMM kernel covers
+# int6 + int7_1 + int7_2 = 2*(25088*4096 + 4096*1280) FLOP per RoI.
+GEMM_FLOP_PER_ROI = 2 * (25088 * 4096 + 4096 * 1280)
+HEAD_FLOP_PER_ROI = 216119808
+PEAK_F32_MFMA_TFLOPS = 157.3
+HBM_PEAK = 8.0e12
+
+
+def t_min_us(unique_per_level, fmap_elems):
+    """Hot-path floor of BASELINE.md section 3: per level max(bytes / 8 TB/s, flops / 157.3 TF)."""
+    tot = 0.0
+    for U in unique_per_level:
+        if U <= 0:
+            continue
+        b = 432239616 + 21728 + 4 * fmap_elems + U * 244
+        f = U * HEAD_FLOP_PER_ROI
+        tot += max(b / HBM_PEAK, f / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    return tot * 1e6
+
+
+def cpu_baseline(head, fmap, Tz, budget_s=20.0):
+    """The oracle (kind "port") on the host: NumPy geometry exactly as lib/detect/test.py,
+    C divide_region/RoIPool, BLAS sgemm for the fc head."""
+    from oracle import az_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    net = orc.OracleNet(head, feat_fn=lambda d: fmap)
+    cfg = orc.OracleCfg(Tz=Tz)
+    nets = {"full": net, "fc": net}
+    orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)          # warm-up
+    times = []
+    t0 = time.time()
+    while len(times) < 3 or (time.time() - t0 < budget_s and len(times) < 30):
+        t = time.time()
+        orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)
+        times.append(time.time() - t)
+    med = float(np.median(times))
+    return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(cores), "kind": "port",
+            "sample": "%d images of the same 600x1000 full-tree workload (median %.3f s/image), "
+                      "hot path only (conv5_3 given)" % (len(times), med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tz", type=float, default=0.0, help="zoom threshold; 0 = full tree (deterministic work)")
+    ap.add_argument("--gather-every", type=int, default=8, help="images per rank per RCCL gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    from aznet_hip.backbone import VGG16Conv5
+    from aznet_hip import dist as azdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+    backbone = VGG16Conv5(device=dev, seed=4321)
+    net = HipAZNet(head, backbone=backbone, device=local_rank, name="vgg16_az_net_hip", max_regions=4096)
+    from detect.test import _get_image_blob
+    im = synth.make_image(rank, H_IM, W_IM)                  # one image per GPU, seed = rank
+    blob, scales = _get_image_blob(im)
+    backbone.normalize_output(blob)                          # random-init weights: unit-RMS conv5_3
+    conv = net.compute_conv(blob)                            # resident in HBM from here on
+    params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pending = []
+
+    def step(i):
+        Y, S = net.propose(params, want_scores=True)
+        if world > 1:
+            pending.append((Y, S))
+            if len(pending) == args.gather_every or i == args.steps - 1:
+                azdist.gather_proposals(pending, NUM_PROPOSALS, device=dev)
+                del pending[:]
+        return Y
+
+    for i in range(args.warmup):
+        step(-1)
+    del pending[:]
+    net.ctx.set_profiling(0)
+    net.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ktimes = net.ctx.last_kernel_times()
+    net.ctx.set_profiling(0)
+    Y, S, st = net.propose(params, want_scores=True, want_stats=True)
+    uniq = [int(st.level_unique[l]) for l in range(st.n_levels)]
+    regions = [int(st.level_regions[l]) for l in range(st.n_levels)]
+
+    out = None
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * NUM_PROPOSALS * args.steps / dt
+        gemm = [(n, l, ms) for (n, l, ms) in ktimes if n.endswith("_gemm")]
+        gemm_ms_total = sum(ms for _, _, ms in gemm)
+        n_launch = max(len(gemm), 1)
+        flops_per_image = sum(uniq) * GEMM_FLOP_PER_ROI
+        achieved = flops_per_image * args.steps / (gemm_ms_total * 1e-3) / 1e12 if gemm_ms_total > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "roofline_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        per_level = {}
+        for n, l, ms in ktimes:
+            per_level.setdefault("%s@L%d" % (n, l + 1), []).append(ms)
+        floor_us = t_min_us(uniq, int(conv.numel()))
+        out = {
+            "metric": "AZ proposals/sec (600x1000 img)", "value": value, "unit": "proposals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "VGG16 AZ proposal hot path, 600x1000 image (scale 1.0), batch=1 per GPU, "
+                                   "Tz=%g, regions/level %s, unique RoIs/level %s, top-%d of %d candidates; "
+                                   "conv5_3 [1,512,38,63] resident in HBM" %
+                                   (args.tz, regions, uniq, NUM_PROPOSALS, st.n_candidates),
+                       "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
+                       "parallelism": "image-shard x%d" % world,
+                       "gather": ("RCCL all_gather every %d images/rank" % args.gather_every) if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "k_fc_splitk (fc6+fc7 GEMM, v_mfma_f32_32x32x2_f32)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "flops_per_launch": flops_per_image / (n_launch / max(args.steps, 1)),
+                         "avg_launch_ms": gemm_ms_total / n_launch,
+                         "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic},
+            "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
+                           "frac": floor_us / (ms_step * 1e3)},
+            "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in sorted(per_level.items())},
+        }
+    # ---- backbone + hot path, for context (not `value`) -----------------------------------
+    if not args.no_e2e:
+        for _ in range(3):
+            net.compute_conv(blob)
+        barrier()
+        n_e2e = max(5, min(50, args.steps // 4))
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            net.compute_conv(blob)
+            net.propose(params)
+        barrier()
+        de = time.perf_counter() - t0
+        if rank == 0:
+            out["end_to_end"] = {"value": world * NUM_PROPOSALS * n_e2e / de, "unit": "proposals/s",
+                                 "ms_per_image": de / n_e2e * 1e3,
+                                 "note": "adds the fp32 PyTorch-ROCm VGG16 conv1_1..conv5_3 forward (367.7 GFLOP)"}
+    if rank == 0 and not args.no_cpu_baseline:
+        fm = conv.detach().cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(head, fm, args.tz)
+        out["gpu_over_cpu"] = out["value"] / world / out["cpu_baseline"]["value"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

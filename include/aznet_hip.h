@@ -150,9 +150,11 @@ int az_topk(az_ctx *ctx, const float *scores, int n, int k, int32_t *idx_out, in
 int az_nms(az_ctx *ctx, const float *dets, int n, double thresh, int64_t *keep, int *n_keep);
 
 /* ---- measurement ------------------------------------------------------------------ */
-/* Per-kernel HIP-event timing of the launches made by the last az_propose when profiling
- * is on (events on the ctx stream).  names_out: `cap` slots of 32 chars. */
-int az_set_profiling(az_ctx *ctx, int on);
+/* HIP-event timing (events on the ctx stream) of the launches made by az_propose /
+ * az_head_forward.  mode bits: 1 = time only the fc GEMM launches, 2 = time every launch
+ * group, 4 = keep accumulating across calls until read (otherwise each call starts afresh);
+ * 0 = off.  names_out: `cap` slots of 32 chars. */
+int az_set_profiling(az_ctx *ctx, int mode);
 int az_last_kernel_times(az_ctx *ctx, char *names_out, float *ms_out, int32_t *level_out,
                          int cap, int *n_out);
 /* The HIP stream the ctx launches on (a hipStream_t). */
