@@ -84,11 +84,164 @@ constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float4 ld_guard(const float *base, int row, int nrows, size_t ld, int k, int kend)
+// Operand tiles are fetched with buffer loads: one descriptor per operand tile (wave-uniform,
+// SGPRs), a per-thread byte offset per row that never changes during the K loop (rows past the
+// operand's end are clamped to its last row -- their products land in output rows that are
+// never stored), and the K position as the scalar offset.  No VALU address arithmetic in the
+// loop, and reads past the end of the allocation return 0 instead of faulting.  Values with k
+// past the chunk end (only when K is not a multiple of the chunk) are zeroed later, when the
+// registers are written to LDS (zero_tail), NOT here: touching a loaded value right after the
+// load would make the compiler wait for it and serialise the prefetch.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, size_t elems_left)
 {
-    // rows >= nrows and k >= kend read as zero (k, kend multiples of 4).
-    if (row < nrows && k < kend) return *reinterpret_cast<const float4 *>(base + (size_t)row * ld + k);
-    return make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t bytes = elems_left * sizeof(float);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)bytes,
+                                             0x00020000);
+}
+
+__device__ __forceinline__ float4 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__device__ __forceinline__ float4 zero_tail(float4 v, bool ok)
+{
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    return v;
+}
+
+// Rows of one launch are cut into ceil(strips / 4) m-tiles whose sizes differ by at most one
+// 32-row strip (e.g. 17 strips -> 4,4,3,3,3), so work items have near-equal cost.
+__device__ __forceinline__ void mtile_rows(int strips, int mt, int t, int &strip0, int &nstrips)
+{
+    const int base = strips / mt, rem = strips - base * mt;
+    strip0 = t * base + (t < rem ? t : rem);
+    nstrips = base + (t < rem ? 1 : 0);
+}
+
+// One (m-tile, n-tile, k-chunk) work item with NRT live 32-row strips.
+// Software pipeline (per wave, so that ONE wave keeps its SIMD's matrix pipe busy; the second
+// resident workgroup is cover, not a requirement):
+//   * global loads run two K-steps ahead of their use: tile kt+2 is requested at the start of
+//     step kt into the register set that step kt-1 emptied, and is written to LDS during step
+//     kt+1, while step kt+1's MFMAs run;
+//   * the ds_read_b128 fragment loads of the next 8-wide k group are issued before the current
+//     group's MFMAs (sched_barrier fences keep the compiler from clustering all reads first);
+//   * one barrier per K-step.
+template <int NRT>
+__device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
+                                        int ldw, int M, int N, int m0, int n0, int k0, int kend,
+                                        float *__restrict__ slab, float (*sA)[BM * LDT], float (*sB)[BN * LDT])
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = (lane >> 5) * 4;
+    const int nk = (kend - k0 + BK - 1) / BK;
+
+    floatx16 acc[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    // global -> register staging: thread t owns float4 f = t + 256*i, row f/8, column (f%8)*4 of
+    // the (NRT*32) x 32 activation tile and of the 128 x 32 weight tile.
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    // descriptors start at the tile's first row; per-thread row offsets are loop-invariant
+    const __amdgpu_buffer_rsrc_t rsA = tile_rsrc(X + (size_t)m0 * ldx, (size_t)(M - m0) * ldx);
+    const __amdgpu_buffer_rsrc_t rsB = tile_rsrc(Wt + (size_t)n0 * ldw, (size_t)(N - n0) * ldw);
+    unsigned voA[NRT], voB[4];
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) voA[i] = (unsigned)((min(srow + 32 * i, M - 1 - m0) * ldx + sc4) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) voB[i] = (unsigned)((min(srow + 32 * i, N - 1 - n0) * ldw + sc4) * 4);
+    auto gload = [&](int kt, float4 (&ra)[NRT], float4 (&rb)[4]) {
+        const unsigned so = (unsigned)(k0 + kt * BK) * 4u;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) ra[i] = buf_ld(rsA, voA[i], so);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = buf_ld(rsB, voB[i], so);
+    };
+    auto lstore = [&](int kt, int buf, const float4 (&ra)[NRT], const float4 (&rb)[4]) {
+        const bool ok = (k0 + kt * BK + sc4) < kend;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+            *reinterpret_cast<float4 *>(&sA[buf][(srow + 32 * i) * LDT + sc4]) = zero_tail(ra[i], ok);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(&sB[buf][(srow + 32 * i) * LDT + sc4]) = zero_tail(rb[i], ok);
+    };
+    const float *a_base = &sA[0][lrow * LDT + lk];
+    const float *b_base = &sB[0][(wave * 32 + lrow) * LDT + lk];
+    auto frag = [&](int buf, int g8, float4 (&af)[NRT], float4 &bf) {
+        bf = *reinterpret_cast<const float4 *>(b_base + buf * (BN * LDT) + g8 * 8);
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+            af[r] = *reinterpret_cast<const float4 *>(a_base + buf * (BM * LDT) + r * 32 * LDT + g8 * 8);
+    };
+    // 4*NRT MFMAs on one 8-wide k group; k-pairs {j, 4 + j}: accumulation order 0,4,1,5,2,6,3,7
+    auto mfma8 = [&](const float4 (&af)[NRT], const float4 &bf) {
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].x, bf.x, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].y, bf.y, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].z, bf.z, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].w, bf.w, acc[r], 0, 0, 0);
+    };
+    static_assert(BK == 32, "the step body below is written for four 8-wide k groups");
+    // One K-step: MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 into (rl_a, rl_b) and
+    // write tile kt+1 from (rw_a, rw_b) into LDS[buf^1].
+    auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
+                    const float4 (&rw_b)[4]) {
+        float4 a0[NRT], a1[NRT], b0, b1;
+        frag(buf, 0, a0, b0);
+        gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: keeps the vmcnt bookkeeping exact
+        __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 2, a0, b0);
+        lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: writes a tile nobody reads)
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        frag(buf, 3, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma8(a1, b1);
+        __syncthreads();
+    };
+
+    float4 ra0[NRT], rb0[4], ra1[NRT], rb1[4];
+    gload(0, ra0, rb0);
+    gload(nk > 1 ? 1 : 0, ra1, rb1);
+    __syncthreads();                 // the previous work item's readers are done with both buffers
+    lstore(0, 0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, 0, ra0, rb0, ra1, rb1);
+        if (kt + 1 < nk) step(kt + 1, 1, ra1, rb1, ra0, rb0);
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
+    const int col = n0 + wave * 32 + (lane & 31);
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row < M) slab[(size_t)row * N + col] = acc[r][e];
+            }
+    }
 }
 
 __global__ void __launch_bounds__(256, 2)
@@ -100,102 +253,36 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
 
     const int M = *Mptr;
     if (M <= 0) return;
-    const int mt = (M + BM - 1) / BM;
+    const int strips = (M + 31) >> 5;
+    const int mt = (strips + 3) >> 2;
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
-    const int G8 = (G + 7) / 8;
-    const int nitems = G8 * 8 * mt;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 31, lk = (lane >> 5) * 4;
+    // With at least one group per workgroup, a workgroup owns whole groups and walks their
+    // m-tiles itself: every workgroup then does the same number of strip-steps whatever M is
+    // (no tail imbalance; the weight panel is re-read mt times, from Infinity Cache / HBM,
+    // which the 64-cycle fp32 MFMA hides).  With fewer groups than workgroups (the narrow
+    // layers) the (group, m-tile) pairs are spread over workgroups instead.
+    const bool mloop = (G >= (int)gridDim.x);
+    const int nitems = mloop ? G : G * mt;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        // Items congruent mod 8 run on one XCD (dispatch is round-robin over XCDs); give them
-        // the m-tiles of the same (n, s) groups so the weight panel is fetched once per XCD.
-        const int xcd = item & 7, q = item >> 3;
-        const int g = (q / mt) * 8 + xcd;
-        const int mtile = q % mt;
-        if (g >= G) continue;
+        const int g = mloop ? item : item / mt;
         const int ntile = g / S, s = g - ntile * S;
-        const int m0 = mtile * BM, n0 = ntile * BN;
+        const int n0 = ntile * BN;
         const int k0 = s * Kc;
         const int kend = min(K, k0 + Kc);
-        const int nk = (kend - k0 + BK - 1) / BK;
-        const int rows_here = min(BM, M - m0);
-        const int n_rt = (rows_here + 31) >> 5;          // live 32-row strips (wave-uniform)
-
-        floatx16 acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
-
-        // global -> register staging: thread t owns float4 f = t + 256*i, row f/8, column (f%8)*4
-        float4 ra[4], rb[4];
-        auto gload = [&](int kt) {
-            const int kb = k0 + kt * BK;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = tid + 256 * i;
-                const int row = f >> 3, c4 = (f & 7) * 4;
-                ra[i] = (row < n_rt * 32) ? ld_guard(X, m0 + row, M, (size_t)ldx, kb + c4, kend)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = ld_guard(Wt, n0 + row, N, (size_t)ldw, kb + c4, kend);
-            }
-        };
-        auto lstore = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = tid + 256 * i;
-                const int row = f >> 3, c4 = (f & 7) * 4;
-                *reinterpret_cast<float4 *>(&sA[buf][row * LDT + c4]) = ra[i];
-                *reinterpret_cast<float4 *>(&sB[buf][row * LDT + c4]) = rb[i];
-            }
-        };
-
-        gload(0);
-        __syncthreads();                 // previous item's readers are done with both buffers
-        lstore(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) gload(kt + 1);
-            const float *a_base = &sA[cur][lrow * LDT + lk];
-            const float *b_base = &sB[cur][(wave * 32 + lrow) * LDT + lk];
-#pragma unroll
-            for (int g8 = 0; g8 < BK / 8; ++g8) {
-                const float4 bf = *reinterpret_cast<const float4 *>(b_base + g8 * 8);
-                float4 af[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < n_rt) af[r] = *reinterpret_cast<const float4 *>(a_base + r * 32 * LDT + g8 * 8);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < n_rt) {
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].x, bf.x, acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].y, bf.y, acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].z, bf.z, acc[r], 0, 0, 0);
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].w, bf.w, acc[r], 0, 0, 0);
-                    }
-            }
-            if (kt + 1 < nk) lstore(cur ^ 1);
-            __syncthreads();
-        }
-
-        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
         float *slab = part + (size_t)s * capM * N;
-        const int col = n0 + wave * 32 + (lane & 31);
-        if (col < N) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < n_rt) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int row = m0 + r * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        if (row < M) slab[(size_t)row * N + col] = acc[r][e];
-                    }
-                }
+        const int t_lo = mloop ? 0 : item - g * mt, t_hi = mloop ? mt : t_lo + 1;
+        for (int mtile = t_lo; mtile < t_hi; ++mtile) {
+            int strip0, n_rt;                            // live 32-row strips (workgroup-uniform)
+            mtile_rows(strips, mt, mtile, strip0, n_rt);
+            const int m0 = strip0 * 32;
+            switch (n_rt) {
+            case 1: fc_tile<1>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
+            case 2: fc_tile<2>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
+            case 3: fc_tile<3>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
+            default: fc_tile<4>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
+            }
         }
     }
 }
