@@ -26,8 +26,9 @@ struct az_ctx {
     // weights (HBM)
     float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
     // feature map
-    const float *feat = nullptr;
-    float *feat_owned = nullptr;
+    const float *feat = nullptr;        // channel-last copy of the current map (what RoIPool reads)
+    float *feat_owned = nullptr;        // [H][W][C]
+    float *feat_stage = nullptr;        // NCHW staging for host uploads
     size_t feat_owned_elems = 0;
     // level-loop buffers (HBM)
     AzCounts *cnt = nullptr;
@@ -235,7 +236,7 @@ int az_destroy(az_ctx *c)
     free_all(c);
     for (void *p : c->allocs_geom) hipFree(p);
     c->allocs_geom.clear();
-    if (c->feat_owned) hipFree(c->feat_owned);
+    if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
     if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
@@ -288,13 +289,19 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     A(pool5, R * d.K6);
     {
         const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7, pt = (size_t)AZK_TAIL_SPLIT * R * 56;
-        const size_t pm = p6 > p7 ? p6 : p7;
-        A(part, pm > pt ? pm : pt);
+        size_t pm = p6 > p7 ? p6 : p7;
+        pm = pm > pt ? pm : pt;
+        const size_t pw = (size_t)n6 * d.K6;          // also stages W6 for the column permutation
+        A(part, pm > pw ? pm : pw);
     }
     A(h6, R * n6); A(h7, R * d.n7);
 #undef A
     // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
-    HIPCHK(c, hipMemcpy(c->W6, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
+    // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
+    // W6's columns to match (c*49 + p  ->  p*C + c).  `part` is big enough to stage it.
+    HIPCHK(c, hipMemcpy(c->part, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
+    azk_permute_k(c->stream, c->part, c->W6, n6, C, 1);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->b6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
     // int7_1 and int7_2 both read int6: one GEMM with the two weight blocks stacked along N.
     HIPCHK(c, hipMemcpy(c->W7, W71, (size_t)n71 * n6 * 4, hipMemcpyHostToDevice));
@@ -316,37 +323,43 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     return AZ_OK;
 }
 
-int az_set_feature_map_dev(az_ctx *c, const float *dev_ptr, int C, int H, int W)
+static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W)
 {
     int rc = check_ready(c, false);
     if (rc) return rc;
-    if (!dev_ptr || C != c->d.C || H <= 0 || W <= 0)
-        return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
-    c->feat = dev_ptr;
-    c->d.H = H; c->d.W = W;
-    return AZ_OK;
-}
-
-int az_set_feature_map_host(az_ctx *c, const float *host_ptr, int C, int H, int W)
-{
-    int rc = check_ready(c, false);
-    if (rc) return rc;
-    if (!host_ptr || C != c->d.C || H <= 0 || W <= 0)
+    if (!src || C != c->d.C || H <= 0 || W <= 0)
         return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)C * H * W;
     if (n > c->feat_owned_elems) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->feat_owned) hipFree(c->feat_owned);
-        c->feat_owned = nullptr; c->feat_owned_elems = 0;
+        if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
+        c->feat_owned = c->feat_stage = nullptr; c->feat_owned_elems = 0;
         HIPCHK(c, hipMalloc((void **)&c->feat_owned, n * 4));
+        HIPCHK(c, hipMalloc((void **)&c->feat_stage, n * 4));
         c->feat_owned_elems = n;
     }
-    HIPCHK(c, hipMemcpyAsync(c->feat_owned, host_ptr, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const float *nchw = src;
+    if (src_is_host) {
+        HIPCHK(c, hipMemcpyAsync(c->feat_stage, src, n * 4, hipMemcpyHostToDevice, c->stream));
+        nchw = c->feat_stage;
+    }
+    // RoIPool reads the map channel-last: one transpose per image, outside the level loop.
+    azk_nchw_to_nhwc(c->stream, nchw, c->feat_owned, C, H * W);
+    HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may now reuse / free `src`
     c->feat = c->feat_owned;
     c->d.H = H; c->d.W = W;
     return AZ_OK;
+}
+
+int az_set_feature_map_dev(az_ctx *c, const float *dev_ptr, int C, int H, int W)
+{
+    return set_feature_map_common(c, dev_ptr, false, C, H, W);
+}
+
+int az_set_feature_map_host(az_ctx *c, const float *host_ptr, int C, int H, int W)
+{
+    return set_feature_map_common(c, host_ptr, true, C, H, W);
 }
 
 // --------------------------------------------------------------------------------------
@@ -587,8 +600,10 @@ int az_roi_pool(az_ctx *c, const float *rois, int R, float *out)
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!out) return fail(c, AZ_ERR_INVALID, "az_roi_pool: null output");
     azk_roi_pool(c->stream, c->feat, c->d, c->spatial_scale, c->urois, &c->cnt->U[0], c->maxR, c->pool5);
+    // the ABI returns Caffe's [R, C, 7, 7] flattening; HBM holds [R, 49, C]
+    if (R) azk_permute_k(c->stream, c->pool5, c->part, R, c->d.C, 0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (R) HIPCHK(c, hipMemcpy(out, c->pool5, (size_t)R * c->d.K6 * 4, hipMemcpyDeviceToHost));
+    if (R) HIPCHK(c, hipMemcpy(out, c->part, (size_t)R * c->d.K6 * 4, hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 

@@ -80,8 +80,13 @@ void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, 
                      int R, int im_h, int im_w, double eps, double *pred_u, float *score_u);
 
 // ---- launchers (az_head.hip) -----------------------------------------------------------
-void azk_roi_pool(hipStream_t s, const float *feat, AzHeadDims d, float spatial_scale,
+// feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
+// pool5 comes out bin-major: [roi][ph*7+pw][c]
+void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5);
+void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
+// rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
+void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);
 // y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip):
 // _gemm writes the S partial slabs part[s][m][n], _reduce adds them in order + bias (+ReLU).
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,

@@ -16,24 +16,60 @@ namespace {
 // ======================================================================================
 // RoIPool (ROIPooling layer, test_fc.prototxt:14-25; semantics of Fast R-CNN's
 // ROIPoolingLayer: C round() of coord*scale, size >= 1, f32 bin size, floor/ceil edges,
-// clamp, empty bin -> 0).  One thread per output element; consecutive threads walk
-// (c, ph, pw) of one roi, so stores are fully coalesced and the window reads of neighbouring
-// bins hit the same cache lines of the 4.9 MB map (L2-resident).
+// clamp, empty bin -> 0).
+// Layouts are chosen for coalescing, not inherited from Caffe:
+//   * the map is kept channel-last in HBM ([H][W][C], transposed once per image), so a wave
+//     reads 64 consecutive channels of one cell with a single 256-byte load;
+//   * pool5 is written bin-major ([roi][ph*7+pw][c]) so the same wave stores 256 contiguous
+//     bytes; int6's weight columns are permuted to the same order when the head is loaded
+//     (az_load_head), which leaves every dot product's set of terms unchanged.
+// One wave per (roi, bin); it walks the channel chunks, so its loads are independent and stay
+// in flight together.  No LDS, no barrier: at 517 rois that is 25k independent waves.
 // ======================================================================================
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float *__restrict__ in, float *__restrict__ out,
+                                                      int C, int HW)
+{
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        t[i][tx] = (c < C && p < HW) ? in[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (c < C && p < HW) out[(size_t)p * C + c] = t[tx][i];
+    }
+}
+
+// rows [R][C*49]: Caffe order (c*49 + p)  <->  bin-major order (p*C + c)
+__global__ void k_permute_k(const float *__restrict__ in, float *__restrict__ out, long long rows, int C,
+                            int to_bin_major)
+{
+    const long long K = (long long)C * 49, total = rows * K;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / K;
+        const int k = (int)(idx - r * K);            // destination index within the row
+        int src;
+        if (to_bin_major) { const int p = k / C, c = k - p * C; src = c * 49 + p; }
+        else              { const int c = k / 49, p = k - c * 49; src = p * C + c; }
+        out[idx] = in[r * K + src];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat, AzHeadDims d,
                                                   float spatial_scale, const float *__restrict__ urois,
                                                   const int *Uptr, float *__restrict__ pool5)
 {
+    constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     const int U = *Uptr;
-    const int PP = d.pooled * d.pooled;
-    const long long total = (long long)U * d.K6;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int u = (int)(idx / d.K6);
-        const int rem = (int)(idx - (long long)u * d.K6);
-        const int c = rem / PP;
-        const int p = rem - c * PP;
-        const int ph = p / d.pooled, pw = p - ph * d.pooled;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < U * PP; item += nwaves) {
+        const int u = item / PP, p = item - u * PP;
+        const int ph = p / P, pw = p - ph * P;
         const float *roi = urois + 5 * (size_t)u;
         const int rsw = (int)roundf(roi[1] * spatial_scale);
         const int rsh = (int)roundf(roi[2] * spatial_scale);
@@ -41,8 +77,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         const int reh = (int)roundf(roi[4] * spatial_scale);
         int rh = reh - rsh + 1; rh = rh < 1 ? 1 : rh;
         int rw = rew - rsw + 1; rw = rw < 1 ? 1 : rw;
-        const float bh = (float)rh / (float)d.pooled;
-        const float bw = (float)rw / (float)d.pooled;
+        const float bh = (float)rh / (float)P;
+        const float bw = (float)rw / (float)P;
         int hs = (int)floorf((float)ph * bh) + rsh;
         int he = (int)ceilf((float)(ph + 1) * bh) + rsh;
         int ws = (int)floorf((float)pw * bw) + rsw;
@@ -50,14 +86,26 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
         ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
         const bool empty = (he <= hs) || (we <= ws);
-        float m = empty ? 0.0f : -FLT_MAX;
-        const float *plane = feat + (size_t)c * d.H * d.W;
-        for (int h = hs; h < he; ++h)
-            for (int w = ws; w < we; ++w) {
-                const float v = plane[h * d.W + w];
-                m = v > m ? v : m;
+        float *out = pool5 + (size_t)u * d.K6 + (size_t)p * d.C;
+        // up to 8 channel chunks (512 channels) per pass, so 8 independent loads are in flight
+        for (int cb = 0; cb < d.C; cb += 8 * 64) {
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = empty ? 0.0f : -FLT_MAX;
+            for (int h = hs; h < he; ++h) {
+                const float *row = feat + ((size_t)h * d.W + ws) * d.C + cb + lane;
+                for (int w = ws; w < we; ++w, row += d.C) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (cb + 64 * j + lane < d.C) ? row[64 * j] : -FLT_MAX;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                }
             }
-        pool5[idx] = m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (cb + 64 * j + lane < d.C) out[cb + 64 * j + lane] = m[j];
+        }
     }
 }
 
@@ -364,11 +412,21 @@ k_tail_epilogue(const float *__restrict__ part, int capM, int S, const float *__
 }  // namespace
 
 // --------------------------------------------------------------------------------------
-void azk_roi_pool(hipStream_t s, const float *feat, AzHeadDims d, float spatial_scale, const float *urois,
+void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
                   const int *Uptr, int capU, float *pool5)
 {
     (void)capU;
-    hipLaunchKernelGGL(k_roi_pool, dim3(2048), dim3(256), 0, s, feat, d, spatial_scale, urois, Uptr, pool5);
+    hipLaunchKernelGGL(k_roi_pool, dim3(1024), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5);
+}
+
+void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)
+{
+    hipLaunchKernelGGL(k_permute_k, dim3(4096), dim3(256), 0, s, in, out, rows, C, to_bin_major);
+}
+
+void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW)
+{
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((HW + 31) / 32, (C + 31) / 32), dim3(256), 0, s, in, out, C, HW);
 }
 
 // Fixed number of K chunks per layer (independent of M; see the header comment).

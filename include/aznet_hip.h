@@ -92,11 +92,12 @@ int az_load_head(az_ctx *ctx, int C, int n6, int n71, int n72,
                  const float *W72, const float *b72, const float *Was, const float *bas,
                  const float *Wab, const float *bab, const float *Wz, const float *bz);
 
-/* Replaces feeding `conv5_3` to net['fc'] (lib/detect/test.py:229-236).
- * _dev: BORROWED device pointer (NCHW f32, batch 1), e.g. a torch tensor's data_ptr();
- *       the producer's stream must have finished writing it, and it must outlive the
- *       az_propose / az_head_forward calls that use it.
- * _host: copies a host array into ctx-owned HBM. */
+/* Replaces feeding `conv5_3` to net['fc'] (lib/detect/test.py:229-236).  The map (NCHW f32,
+ * batch 1) is transposed once into ctx-owned HBM in the channel-last layout RoIPool reads;
+ * the call returns after that copy, so the source may be reused or freed afterwards.
+ * _dev: device pointer, e.g. a torch tensor's data_ptr(); the producer's stream must have
+ *       finished writing it before the call.
+ * _host: host array. */
 int az_set_feature_map_dev(az_ctx *ctx, const float *dev_ptr, int C, int H, int W);
 int az_set_feature_map_host(az_ctx *ctx, const float *host_ptr, int C, int H, int W);
 
