@@ -41,6 +41,9 @@ struct az_ctx {
     float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr;
     float *zoom_u = nullptr, *score_u = nullptr, *delta_u = nullptr, *Sall = nullptr, *Sout = nullptr;
     int *sel_idx = nullptr;
+    // speculative levels 1-3: provenance of zoomed regions / children / regions, head outputs of the pass
+    int *zr = nullptr, *csrc = nullptr, *choff_all = nullptr, *srcB[2] = {nullptr, nullptr};
+    float *zoom_s = nullptr, *score_s = nullptr, *delta_s = nullptr;
     // nms scratch (grown on demand)
     int nms_cap = 0;
     float *nms_dets = nullptr, *nms_sdets = nullptr;
@@ -114,6 +117,8 @@ int ensure_geom(az_ctx *c)
     A(ubox, R * 4); A(pred_u, R * AZ_NSUB * 4); A(Yall, CAND * 4); A(Z, R * 4); A(child, CH * 4);
     A(Yout, CAND * 4); A(Sout, CAND); A(sel_idx, CAND);
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
+    A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
+    A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -169,8 +174,10 @@ int set_count(az_ctx *c, int *dptr, int v)
     return AZ_OK;
 }
 
-// One forward of the head on the `U` unique rois in ctx->urois / ctx->ubox.
-void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps)
+// One forward of the head on the `U` rois in ctx->urois (anchors in ctx->ubox); scores and
+// deltas go to the given arrays, decoded boxes to ctx->pred_u.
+void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
+                 float *delta)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
@@ -185,7 +192,7 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_reduce(c->stream, c->part, c->b7, Uptr, c->maxR, d.n7, c->S7, c->h7, d.n7, 1); }
     { Timed t(c, "head_tail", level);
       azk_head_tail(c->stream, c->h7, d, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, c->part,
-                    c->zoom_u, c->score_u, c->delta_u, c->pred_u); }
+                    zoom, score, delta, c->pred_u); }
 }
 
 int check_geom(az_ctx *c)
@@ -386,6 +393,26 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);
+    // Speculative evaluation of levels 1-3.  The root is always divided (test.py:383-384), so
+    // level 2's regions are known up front, and level 3's regions are a subset of the children
+    // of ALL level-2 regions.  These few dozen rows cost one pass over the 411 MB int6 weights
+    // instead of three (each of those levels is weight-streaming-bound).  Head outputs are a
+    // fixed function of the roi, so the levels below just look their rows up: bit-identical
+    // results.  (params.reserved bit 0 turns this off.)
+    const int n_spec = (nlev >= 3 && !(p->reserved & 1)) ? 3 : 0;
+    if (n_spec) {
+        Timed t(c, "spec_geometry", -1);
+        // children of the root -> B1 (with _sift_dup), exactly what level 1's divide will produce
+        azk_divide(s, &c->cnt->P[0], &c->cnt->scratch[3], &c->cnt->err, c->maxR, c->maxCh, c->B[0], p->min_side,
+                   c->choff, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
+        azk_dedup_regions(s, c->ckey, &c->cnt->scratch[3], c->maxCh, c->maxR, c->first, c->child, c->B[1],
+                          &c->cnt->specP1, &c->cnt->err, nullptr, nullptr);
+        // children of ALL of B1, before _sift_dup; their offsets identify (parent, child) later
+        azk_divide(s, &c->cnt->specP1, &c->cnt->specCH, &c->cnt->err, c->maxR, c->maxCh, c->B[1], p->min_side,
+                   c->choff_all, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
+        azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
+    }
+    if (n_spec) launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
     for (int l = 0; l < nlev; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
@@ -396,17 +423,27 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         { Timed t(c, "dedup_rois", l);
           azk_dedup_rois(s, c->key, c->grp, Pptr, c->maxR, c->first, c->rois, c->B[cur], c->index, c->inv,
                          c->urois, c->ubox, Uptr); }
-        launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps);
+        if (l < n_spec) {
+            Timed t(c, "spec_lookup", l);
+            azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
+                            p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
+        } else {
+            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u);
+        }
         { Timed t(c, "flags_compact", l);
           azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, c->pred_u, c->score_u,
                             c->zoom_u, p->Tz, p->min_side, l == 0, c->cflag, c->zflag, c->bc_c, c->bc_z,
-                            c->Yall, c->Sall, c->Z); }
+                            c->Yall, c->Sall, c->Z, c->zr); }
         if (l + 1 < nlev) {      // the reference also divides after the last level but never uses it
+            const bool track = (n_spec && l == 1);       // level-3 regions remember their speculative row
             { Timed t(c, "divide", l);
-              azk_divide(s, c->cnt, l, c->maxR, c->maxCh, c->Z, p->min_side, c->choff, c->child, c->ckey); }
+              azk_divide(s, &c->cnt->PZ[l], &c->cnt->CH[l], &c->cnt->err, c->maxR, c->maxCh, c->Z, p->min_side,
+                         c->choff, c->child, c->ckey, track ? c->choff_all : nullptr, c->zr, &c->cnt->specP1, 1,
+                         track ? c->csrc : nullptr); }
             { Timed t(c, "sift_dup", l);
               azk_dedup_regions(s, c->ckey, &c->cnt->CH[l], c->maxCh, c->maxR, c->first, c->child,
-                                c->B[cur ^ 1], &c->cnt->P[l + 1], &c->cnt->err); }
+                                c->B[cur ^ 1], &c->cnt->P[l + 1], &c->cnt->err, track ? c->csrc : nullptr,
+                                c->srcB[cur ^ 1]); }
         }
     }
     { Timed t(c, "select", nlev);
@@ -511,7 +548,7 @@ static int sift_common(az_ctx *c, int C, double min_side, double *out, int cap, 
     int rc = set_count(c, Nptr, C);
     if (rc) return rc;
     azk_region_keys(s, c->child, Nptr, c->maxCh, min_side, c->ckey);
-    azk_dedup_regions(s, c->ckey, Nptr, c->maxCh, c->maxR, c->first, c->child, c->B[1], Pn, err);
+    azk_dedup_regions(s, c->ckey, Nptr, c->maxCh, c->maxR, c->first, c->child, c->B[1], Pn, err, nullptr, nullptr);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->h_cnt->scratch[2]) return fail(c, AZ_ERR_CAPACITY, "sift_dup: region capacity exceeded");
@@ -544,9 +581,10 @@ int az_divide_region(az_ctx *c, const double *regions, int P, double min_side, d
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->Z, regions, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->PZ[0], P)) != AZ_OK) return rc;
-    azk_divide(s, c->cnt, 0, c->maxR, c->maxCh, c->Z, min_side, c->choff, c->child, c->ckey);
+    azk_divide(s, &c->cnt->PZ[0], &c->cnt->CH[0], &c->cnt->err, c->maxR, c->maxCh, c->Z, min_side, c->choff, c->child,
+               c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
     azk_dedup_regions(s, c->ckey, &c->cnt->CH[0], c->maxCh, c->maxR, c->first, c->child, c->B[1], &c->cnt->P[1],
-                      &c->cnt->err);
+                      &c->cnt->err, nullptr, nullptr);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->h_cnt->err) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: ctx capacity exceeded");
@@ -613,7 +651,7 @@ int az_head_forward(az_ctx *c, const float *rois, int R, float *zoom_prob, float
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!(c->profiling & 4)) clear_events(c);
-    launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0);
+    launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0, c->zoom_u, c->score_u, c->delta_u);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (R && zoom_prob) HIPCHK(c, hipMemcpy(zoom_prob, c->zoom_u, (size_t)R * 4, hipMemcpyDeviceToHost));
@@ -646,7 +684,7 @@ int az_decode_filter(az_ctx *c, const double *anchors, const float *deltas, cons
     HIPCHK(c, hipMemsetAsync(c->zoom_u, 0, (size_t)(R > 0 ? R : 1) * 4, s));
     azk_decode_unit(s, c->ubox, c->delta_u, c->Sout, R, im_h, im_w, eps, c->pred_u, c->score_u);
     azk_flags_compact(s, c->cnt, 0, c->maxR, c->maxCand, c->ubox, c->inv, c->pred_u, c->score_u, c->zoom_u, 2.0,
-                      min_side, 0, c->cflag, c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z);
+                      min_side, 0, c->cflag, c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z, c->zr);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const int n = c->h_cnt->NC[0];

@@ -20,6 +20,8 @@ struct AzCounts {
     int nsel;                   // proposals selected at the end
     int err;                    // bit 0: region capacity, bit 1: candidate capacity, bit 2: children
     int scratch[6];
+    // speculative evaluation of levels 1-3 (az_capi.hip): |B1|, children of all of B1, rows forwarded
+    int specP1, specCH, specU, specPad;
 };
 
 // Geometry of one launch of the head on `U` rois (all device pointers).
@@ -68,11 +70,19 @@ void azk_flags_compact(hipStream_t s, AzCounts *cnt, int level, int capR, int ca
                        const double *B, const int *inv, const double *pred_u, const float *score_u,
                        const float *zoom_u, double Tz, double min_side, int force_root,
                        unsigned char *cflag, unsigned char *zflag, int *bc_c, int *bc_z,
-                       double *Yall, float *Sall, double *Z);
-void azk_divide(hipStream_t s, AzCounts *cnt, int level, int capR, int capCh, const double *Z,
-                double min_side, int *choff, double *child, long long *ckey);
+                       double *Yall, float *Sall, double *Z, int *zr);
+// divide_region children of Z[0..*PZptr) (+ optional provenance ids, see az_geom.hip)
+void azk_divide(hipStream_t s, const int *PZptr, int *CHptr, int *err, int capR, int capCh, const double *Z,
+                double min_side, int *choff, double *child, long long *ckey, const int *src_off, const int *zr,
+                const int *src_base, int src_add, int *csrc);
 void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,
-                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err);
+                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err,
+                       const int *csrc, int *srcnext);
+void azk_spec_rois(hipStream_t s, const double *root, const double *B1, const double *C2, AzCounts *cnt, int capR,
+                   double scale, float *urois);
+void azk_spec_lookup(hipStream_t s, int level, const int *Uptr, const int *index, const int *src2,
+                     const double *ubox, const float *zoom_s, const float *score_s, const float *delta_s, int im_h,
+                     int im_w, double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u);
 // decode + flags for the unit entry point az_decode_filter
 void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int cap, double min_side,
                      long long *ckey);

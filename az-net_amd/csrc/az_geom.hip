@@ -136,7 +136,7 @@ __global__ void k_dedup_rois(const long long *__restrict__ key, const int *__res
 // _sift_dup output (lib/utils/div.pyx:85-89): regions[index] in ascending hash order.
 __global__ void k_dedup_regions(const long long *__restrict__ key, const int *Nptr, int capOut,
                                 const unsigned char *__restrict__ first, const double *__restrict__ child,
-                                double *Bnext, int *Pnext, int *err)
+                                double *Bnext, int *Pnext, int *err, const int *__restrict__ csrc, int *srcnext)
 {
     const int N = *Nptr;
     const int lane = lane_id();
@@ -147,7 +147,7 @@ __global__ void k_dedup_regions(const long long *__restrict__ key, const int *Np
         const int slot = dedup_slot(key, nullptr, first, N, i);
         if (slot >= capOut) { if (lane == 0) atomicOr(err, 1); continue; }
         if (lane < 4) Bnext[4 * slot + lane] = child[4 * i + lane];
-        if (lane == 0) ++nfirst;
+        if (lane == 0) { ++nfirst; if (csrc) srcnext[slot] = csrc[i]; }
     }
     if (lane == 0 && nfirst) atomicAdd(Pnext, nfirst);
 }
@@ -209,7 +209,7 @@ __global__ void k_compact(AzCounts *cnt, int level, int capCand, const double *_
                           const int *__restrict__ inv, const double *__restrict__ pred_u,
                           const float *__restrict__ score_u, const unsigned char *__restrict__ cflag,
                           const unsigned char *__restrict__ zflag, const int *__restrict__ bc_c,
-                          const int *__restrict__ bc_z, double *Yall, float *Sall, double *Z)
+                          const int *__restrict__ bc_z, double *Yall, float *Sall, double *Z, int *zr)
 {
     __shared__ int red[TB / 64];
     __shared__ int wsum[17];
@@ -240,6 +240,7 @@ __global__ void k_compact(AzCounts *cnt, int level, int capCand, const double *_
             const int dst = base_z + zoff;
 #pragma unroll
             for (int k = 0; k < 4; ++k) Z[(size_t)dst * 4 + k] = B[(size_t)c * 4 + k];
+            zr[dst] = c;
         }
     }
     if (blockIdx.x == 0) {
@@ -272,12 +273,12 @@ __device__ __forceinline__ DivPlan div_plan(const double *r)
     return p;
 }
 
-// Single workgroup: children per parent + exclusive scan -> child offsets, total in CH[level].
-__global__ void __launch_bounds__(1024) k_divide_scan(AzCounts *cnt, int level, int capCh,
+// Single workgroup: children per parent + exclusive scan -> child offsets, total in *CHptr.
+__global__ void __launch_bounds__(1024) k_divide_scan(const int *PZptr, int *CHptr, int *err, int capCh,
                                                       const double *__restrict__ Z, int *choff)
 {
     __shared__ int wsum[17];
-    const int PZ = cnt->PZ[level];
+    const int PZ = *PZptr;
     int running = 0;
     for (int base = 0; base < PZ; base += blockDim.x) {
         const int z = base + threadIdx.x;
@@ -292,17 +293,20 @@ __global__ void __launch_bounds__(1024) k_divide_scan(AzCounts *cnt, int level, 
         running += tot;
     }
     if (threadIdx.x == 0) {
-        if (running > capCh) { atomicOr(&cnt->err, 4); running = 0; }
-        cnt->CH[level] = running;
+        if (running > capCh) { atomicOr(err, 4); running = 0; }
+        *CHptr = running;
     }
 }
 
-__global__ void k_divide_emit(const AzCounts *cnt, int level, const double *__restrict__ Z,
-                              const int *__restrict__ choff, double min_side, double *child,
-                              long long *ckey)
+// Children of every parent.  With `src_off` the children also get a provenance id
+// *src_base + src_off[zr ? zr[z] : z] + child index (used by the speculative levels).
+__global__ void k_divide_emit(const int *PZptr, const int *CHptr, const double *__restrict__ Z,
+                              const int *__restrict__ choff, double min_side, double *child, long long *ckey,
+                              const int *__restrict__ src_off, const int *__restrict__ zr, const int *src_base,
+                              int src_add, int *csrc)
 {
-    const int PZ = cnt->PZ[level];
-    if (cnt->CH[level] == 0) return;
+    const int PZ = *PZptr;
+    if (*CHptr == 0) return;
     for (int z = blockIdx.x * blockDim.x + threadIdx.x; z < PZ; z += gridDim.x * blockDim.x) {
         const double *r = Z + 4 * (size_t)z;
         const DivPlan p = div_plan(r);
@@ -311,6 +315,7 @@ __global__ void k_divide_emit(const AzCounts *cnt, int level, const double *__re
         const double h_short = p.l_short / 2, h_long = p.l_long / 2;   // div.pyx:58-59
         const int nb = (int)(3 * p.num_long - 1);
         const size_t o = (size_t)choff[z];
+        const int sbase = src_off ? (*src_base + src_add + src_off[zr ? zr[z] : z]) : 0;
         for (int bi = 0; bi < nb; ++bi) {
             double s_lo, s_hi, l_lo, l_hi;      // short-axis / long-axis cell bounds
             if (bi < (int)(2 * p.num_long)) {   // grid cells, index k*num_long + j (div.pyx:47-56)
@@ -334,6 +339,7 @@ __global__ void k_divide_emit(const AzCounts *cnt, int level, const double *__re
                 mult *= 1000;
             }
             ckey[o + bi] = h;
+            if (csrc) csrc[o + bi] = sbase + bi;
         }
     }
 }
@@ -399,30 +405,32 @@ void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const i
 void azk_flags_compact(hipStream_t s, AzCounts *cnt, int level, int capR, int capCand, const double *B,
                        const int *inv, const double *pred_u, const float *score_u, const float *zoom_u,
                        double Tz, double min_side, int force_root, unsigned char *cflag,
-                       unsigned char *zflag, int *bc_c, int *bc_z, double *Yall, float *Sall, double *Z)
+                       unsigned char *zflag, int *bc_c, int *bc_z, double *Yall, float *Sall, double *Z, int *zr)
 {
     const int g = grid_for(capR * AZ_NSUB, TB);
     hipLaunchKernelGGL(k_flags, dim3(g), dim3(TB), 0, s, cnt, level, inv, pred_u, zoom_u, Tz, min_side,
                        force_root, cflag, zflag, bc_c, bc_z);
     hipLaunchKernelGGL(k_compact, dim3(g), dim3(TB), 0, s, cnt, level, capCand, B, inv, pred_u, score_u,
-                       cflag, zflag, bc_c, bc_z, Yall, Sall, Z);
+                       cflag, zflag, bc_c, bc_z, Yall, Sall, Z, zr);
 }
 
-void azk_divide(hipStream_t s, AzCounts *cnt, int level, int capR, int capCh, const double *Z,
-                double min_side, int *choff, double *child, long long *ckey)
+void azk_divide(hipStream_t s, const int *PZptr, int *CHptr, int *err, int capR, int capCh, const double *Z,
+                double min_side, int *choff, double *child, long long *ckey, const int *src_off, const int *zr,
+                const int *src_base, int src_add, int *csrc)
 {
-    hipLaunchKernelGGL(k_divide_scan, dim3(1), dim3(1024), 0, s, cnt, level, capCh, Z, choff);
-    hipLaunchKernelGGL(k_divide_emit, dim3(grid_for(capR, TB)), dim3(TB), 0, s, cnt, level, Z, choff,
-                       min_side, child, ckey);
+    hipLaunchKernelGGL(k_divide_scan, dim3(1), dim3(1024), 0, s, PZptr, CHptr, err, capCh, Z, choff);
+    hipLaunchKernelGGL(k_divide_emit, dim3(grid_for(capR, TB)), dim3(TB), 0, s, PZptr, CHptr, Z, choff, min_side,
+                       child, ckey, src_off, zr, src_base, src_add, csrc);
 }
 
 void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,
-                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err)
+                       unsigned char *first, const double *child, double *Bnext, int *Pnext, int *err,
+                       const int *csrc, int *srcnext)
 {
     const int g = grid_for(cap, TB / 64);      // one wave per element
     hipLaunchKernelGGL(k_first, dim3(g), dim3(TB), 0, s, key, (const int *)nullptr, Nptr, first);
     hipLaunchKernelGGL(k_dedup_regions, dim3(g), dim3(TB), 0, s, key, Nptr, capOut, first, child, Bnext,
-                       Pnext, err);
+                       Pnext, err, csrc, srcnext);
 }
 
 void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int cap, double min_side,
@@ -436,4 +444,67 @@ void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, 
 {
     hipLaunchKernelGGL(k_decode_unit, dim3(grid_for(R * AZ_NSUB, TB)), dim3(TB), 0, s, anchors, deltas,
                        scores, R, im_h, im_w, eps, pred_u, score_u);
+}
+
+namespace {
+// Speculative rows S = [root ; B1 ; all children of all of B1] -> rois (no dedup): row 0 the
+// root, rows 1..P1 = B1 in order, then the children in (parent, child) order.
+__global__ void k_spec_rois(const double *__restrict__ root, const double *__restrict__ B1,
+                            const double *__restrict__ C2, AzCounts *cnt, int capR, double scale, float *urois)
+{
+    const int P1 = cnt->specP1, CH = cnt->specCH;
+    int total = 1 + P1 + CH;
+    if (total > capR) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&cnt->err, 1); total = capR; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt->specU = total;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const double *b = (i == 0) ? root : (i <= P1 ? B1 + 4 * (size_t)(i - 1) : C2 + 4 * (size_t)(i - 1 - P1));
+        urois[5 * (size_t)i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) urois[5 * (size_t)i + 1 + q] = (float)(b[q] * scale);
+    }
+}
+
+// Head outputs of a speculative level: every unique roi's representative region r = index[u]
+// has a row in the speculative pass (level 0: row 0; level 1: 1 + r; level 2: src2[r]); copy its
+// scores and decode its deltas against the representative's own box.
+__global__ void k_spec_lookup(int level, const int *Uptr, const int *__restrict__ index,
+                              const int *__restrict__ src2, const double *__restrict__ ubox,
+                              const float *__restrict__ zoom_s, const float *__restrict__ score_s,
+                              const float *__restrict__ delta_s, int im_h, int im_w, double eps, float *zoom_u,
+                              float *score_u, float *delta_u, double *pred_u)
+{
+    const int U = *Uptr;
+    const int total = U * (AZ_NSUB + 1);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int u = idx / (AZ_NSUB + 1), t = idx - u * (AZ_NSUB + 1);
+        const int r = index[u];
+        const int srow = level == 0 ? 0 : (level == 1 ? 1 + r : src2[r]);
+        if (t < AZ_NSUB) {
+            score_u[(size_t)u * AZ_NSUB + t] = score_s[(size_t)srow * AZ_NSUB + t];
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d4[q] = delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * t + q];
+                delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
+            }
+            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+        } else {
+            zoom_u[u] = zoom_s[srow];
+        }
+    }
+}
+}  // namespace
+
+void azk_spec_rois(hipStream_t s, const double *root, const double *B1, const double *C2, AzCounts *cnt, int capR,
+                   double scale, float *urois)
+{
+    hipLaunchKernelGGL(k_spec_rois, dim3(8), dim3(TB), 0, s, root, B1, C2, cnt, capR, scale, urois);
+}
+
+void azk_spec_lookup(hipStream_t s, int level, const int *Uptr, const int *index, const int *src2,
+                     const double *ubox, const float *zoom_s, const float *score_s, const float *delta_s, int im_h,
+                     int im_w, double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+{
+    hipLaunchKernelGGL(k_spec_lookup, dim3(64), dim3(TB), 0, s, level, Uptr, index, src2, ubox, zoom_s, score_s,
+                       delta_s, im_h, im_w, eps, zoom_u, score_u, delta_u, pred_u);
 }

@@ -287,6 +287,26 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
         assert np.abs(Y - b).max(axis=1).min() < 1e-3
 
 
+@pytest.mark.parametrize("H,W,tz", [(600, 1000, 0.0), (375, 500, 0.6), (640, 853, 0.55), (200, 90, 0.0)])
+def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
+    """Levels 1-3 evaluated in one pass (default) vs one by one: identical bits."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    scale = 600.0 / min(H, W)
+    if np.round(scale * max(H, W)) > 1000:
+        scale = 1000.0 / max(H, W)
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    net.set_conv(synth.make_feature_map(6, synth.SMALL_DIMS["C"], fh, fw))
+    outs = []
+    for spec in (True, False):
+        p = ffi.AzContext.make_params(H, W, scale, tz, speculate=spec)
+        Y, S, st = net.propose(p, want_scores=True, want_stats=True)
+        Ya, Sa = net.ctx.last_candidates()
+        outs.append((Y, S, Ya, Sa, list(st.level_regions), list(st.level_unique), list(st.level_zoomed)))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
 def test_threshold_mode(small, mods):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
