@@ -55,9 +55,10 @@ def gather_proposals(local, cap, device=None, group=None):
     t = torch.from_numpy(buf)
     if device is not None:
         t = t.to(device)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t, group=group)
-    out = out.cpu().numpy()
+    # concatenated form (world * n_local rows): the layout both RCCL and gloo accept
+    out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    out = out.cpu().numpy().reshape(world, t.shape[0], t.shape[1])
     res = []
     for j in range(len(local)):
         for r in range(world):

@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: the image sharding + fixed-size proposal gather that runs over
+RCCL on the GPUs (aznet_hip.dist).  Rank order must reproduce serial image order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from aznet_hip import dist as azdist
+
+
+def _fake(i, cap):
+    rng = np.random.RandomState(100 + i)
+    n = cap if i % 3 else max(1, cap // 2 - i)         # ragged: some images yield fewer proposals
+    return rng.uniform(0, 1000, (n, 4)), rng.uniform(0, 1, n).astype(np.float32)
+
+
+def _worker(rank, world, port, num_images, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = azdist.shard_indices(num_images, rank, world)
+        local = [_fake(i, cap) for i in mine]
+        allp = azdist.gather_proposals(local, cap)
+        ok = len(allp) == num_images
+        for i, (b, s) in enumerate(allp):
+            rb, rs = _fake(i, cap)
+            ok = ok and np.array_equal(b, rb) and np.array_equal(s, rs)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("num_images,cap", [(8, 300), (2, 16)])
+def test_gather_two_ranks(num_images, cap):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, num_images, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_record_roundtrip_and_sharding():
+    b, s = _fake(1, 300)
+    rec = azdist.pack_record(b, s, 300)
+    assert rec.shape == (azdist.record_len(300),) and rec.dtype == np.float64
+    b2, s2 = azdist.unpack_record(rec, 300)
+    assert np.array_equal(b, b2) and np.array_equal(s, s2)
+    e = azdist.pack_record(np.zeros((0, 4)), np.zeros(0, dtype=np.float32), 300)
+    assert azdist.unpack_record(e, 300)[0].shape == (0, 4)
+    assert azdist.shard_indices(8, 1, 4) == [1, 5] and azdist.shard_indices(3, 2, 4) == [2]
+    # single process: gather is the identity
+    assert len(azdist.gather_proposals([(b, s)], 300)) == 1

@@ -1,0 +1,83 @@
+"""CPU: host-side mirror of the reference's config / driver interface (no GPU calls)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+
+def test_config_defaults_and_yaml_merge(tmp_path):
+    from detect import config as C
+    cfg = C.cfg
+    assert cfg.TEST.SCALES == (600,) and cfg.TEST.MAX_SIZE == 1000 and cfg.TEST.NUM_PROPOSALS == 300
+    assert cfg.SEAR.MIN_SIDE == 10 and cfg.SEAR.BATCH_SIZE == 10000 and cfg.DEDUP_BOXES == 1. / 16.
+    assert cfg.SEAR.NUM_SUBREG == 11 and cfg.EPS == 1e-14 and cfg.SEAR.FIXED_PROPOSAL_NUM is True
+    y = tmp_path / "voc.yml"
+    y.write_text("TEST:\n  MAX_SIZE: 800\nSEAR:\n  BATCH_SIZE: 1000\n  AZ_CONV: [conv5_3]\n")
+    C.cfg_from_file(str(y))
+    assert cfg.TEST.MAX_SIZE == 800 and cfg.SEAR.BATCH_SIZE == 1000
+    bad = tmp_path / "bad.yml"
+    bad.write_text("TEST:\n  NOPE: 1\n")
+    with pytest.raises(KeyError):
+        C.cfg_from_file(str(bad))
+    bad.write_text("TEST:\n  MAX_SIZE: 'x'\n")
+    with pytest.raises(ValueError):
+        C.cfg_from_file(str(bad))
+    C.cfg_set_mode("Test", 0.25)
+    assert cfg.SEAR.Tz == 0.25 and cfg.SEAR.NUM_PROPOSALS == 300
+    C.cfg_set_mode("Train")
+    assert cfg.SEAR.Tz == 0.0 and cfg.SEAR.NUM_PROPOSALS == 2000
+    with pytest.raises(AssertionError):
+        C.cfg_set_mode("Test")
+    t = tmp_path / "thresh.pkl"
+    t.write_bytes(pickle.dumps(0.4321, protocol=2))
+    assert C.cfg_load_thresh(str(t)) == 0.4321
+    C.cfg_set_path(None)
+    assert cfg.EXP_DIR == "default"
+    C.cfg_set_path("exp1")
+
+    class Imdb(object):
+        name = "voc_2007_test"
+
+    class Net(object):
+        name = "net1"
+    assert C.get_output_dir(Imdb(), Net()).endswith(os.path.join("output", "exp1", "voc_2007_test", "net1"))
+    cfg.TEST.MAX_SIZE = 1000
+    cfg.SEAR.BATCH_SIZE = 10000
+    C.cfg_set_path(None)
+
+
+def test_image_scale_and_blob():
+    from detect import test as T
+    from detect.config import cfg
+    cfg.TEST.MAX_SIZE = 1000
+    assert T._im_scale((600, 1000, 3)) == [1.0]
+    assert T._im_scale((375, 500, 3)) == [1.6]
+    assert abs(T._im_scale((500, 1000, 3))[0] - 1.0) < 1e-12          # capped by MAX_SIZE
+    im = np.full((600, 1000, 3), 128, dtype=np.uint8)
+    blob, scales = T._get_image_blob(im)
+    assert blob.shape == (1, 3, 600, 1000) and blob.dtype == np.float32 and scales[0] == 1.0
+    np.testing.assert_allclose(blob[0, :, 0, 0], 128 - cfg.PIXEL_MEANS.ravel(), rtol=0, atol=1e-4)
+
+
+def test_synthetic_imdb_and_timer():
+    from aznet_hip.imdb import get_imdb
+    from utils.timer import Timer
+    db = get_imdb("synthetic_600x1000_3")
+    assert len(db.image_index) == 3 and db.image_at(1).shape == (600, 1000, 3) and db.name == "synthetic_600x1000_3"
+    assert np.array_equal(db.image_at(2), db.image_at(2))
+    with pytest.raises(KeyError):
+        get_imdb("voc_2007_test")
+    t = Timer()
+    t.tic()
+    assert t.toc() >= 0 and t.calls == 1
+
+
+def test_ffi_struct_layout_matches_header():
+    """az_params / az_stats in ffi.py must mirror include/aznet_hip.h field for field."""
+    import ctypes
+    from aznet_hip import ffi
+    assert ctypes.sizeof(ffi.AzParams) == 8 + 6 * 8 + 4 * 4
+    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4
+    p = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, num_proposals=300, batch_size=1000, speculate=False)
+    assert (p.im_h, p.im_w, p.Tz, p.batch_size, p.fixed_num, p.reserved) == (600, 1000, 0.3, 1000, 1, 1)
