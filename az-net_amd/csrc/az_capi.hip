@@ -400,7 +400,15 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     // fixed function of the roi, so the levels below just look their rows up: bit-identical
     // results.  (params.reserved bit 0 turns this off.)
     const int n_spec = (nlev >= 3 && !(p->reserved & 1)) ? 3 : 0;
-    if (n_spec) {
+    // The geometry of those three levels is a few dozen elements per stage: by default it runs
+    // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
+    // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
+    const bool fused = n_spec && !(p->reserved & 2);
+    if (fused) {
+        Timed t(c, "spec_prepass", -1);
+        azk_spec_prepass(s, c->cnt, c->B[0], c->B[1], c->child, c->choff_all, c->urois, p->scale, p->min_side,
+                         c->maxR, c->maxCh);
+    } else if (n_spec) {
         Timed t(c, "spec_geometry", -1);
         // children of the root -> B1 (with _sift_dup), exactly what level 1's divide will produce
         azk_divide(s, &c->cnt->P[0], &c->cnt->scratch[3], &c->cnt->err, c->maxR, c->maxCh, c->B[0], p->min_side,
@@ -413,7 +421,22 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
     }
     if (n_spec) launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
-    for (int l = 0; l < nlev; ++l) {
+    if (fused) {
+        Timed t(c, "spec_levels", 0);
+        AzFusedArgs a;
+        a.cnt = c->cnt;
+        a.B[0] = c->B[0]; a.B[1] = c->B[1]; a.srcB[0] = c->srcB[0]; a.srcB[1] = c->srcB[1];
+        a.index = c->index; a.inv = c->inv; a.zr = c->zr; a.choff = c->choff; a.csrc = c->csrc;
+        a.choff_all = c->choff_all;
+        a.ubox = c->ubox; a.pred_u = c->pred_u; a.Yall = c->Yall; a.Z = c->Z; a.child = c->child;
+        a.zoom_u = c->zoom_u; a.score_u = c->score_u; a.delta_u = c->delta_u; a.Sall = c->Sall;
+        a.zoom_s = c->zoom_s; a.score_s = c->score_s; a.delta_s = c->delta_s;
+        a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
+        a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
+        a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
+        azk_spec_levels(s, a);
+    }
+    for (int l = fused ? n_spec : 0; l < nlev; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];

@@ -89,6 +89,25 @@ void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int 
 void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, const float *scores,
                      int R, int im_h, int im_w, double eps, double *pred_u, float *score_u);
 
+// ---- launchers (az_fused.hip): the first levels inside one workgroup ---------------------
+struct AzFusedArgs {
+    AzCounts *cnt;
+    double *B[2];
+    int *srcB[2];
+    int *index, *inv, *zr, *choff, *csrc;
+    const int *choff_all;
+    double *ubox, *pred_u, *Yall, *Z, *child;
+    float *zoom_u, *score_u, *delta_u, *Sall;
+    const float *zoom_s, *score_s, *delta_s;
+    double scale, Tz, min_side, eps;
+    float dedup;
+    int batch, im_h, im_w, nlev, n_fused, capR, capCh, capCand;
+};
+
+void azk_spec_prepass(hipStream_t s, AzCounts *cnt, const double *root, double *B1, double *child, int *choff_all,
+                      float *urois, double scale, double min_side, int capR, int capCh);
+void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
+
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 // feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
 // pool5 comes out bin-major: [roi][ph*7+pw][c]

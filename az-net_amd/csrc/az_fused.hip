@@ -1,0 +1,299 @@
+// az_fused.hip -- the first three levels of the search as two single-workgroup kernels.
+//
+// Levels 1-3 hold a few dozen regions (1, then the root's children, then their children), so
+// each of their geometry stages is a handful of elements: as separate launches they cost ~40
+// dependent kernel boundaries of pure latency.  Because the head outputs for these levels come
+// from one speculative pass (az_capi.hip), everything else for them -- roi keys + 1/16 dedup,
+// lookup + box decode, candidate filter + ordered compaction, zoom selection, divide_region,
+// _sift_dup -- runs here inside ONE workgroup with __syncthreads() between stages.
+// Same device helpers (az_geom_dev.h) as the multi-workgroup kernels, so same bits.
+#include "az_geom_dev.h"
+
+namespace {
+
+constexpr int NT = 1024;          // threads of the single workgroup
+constexpr int LIM_R = 1024;       // regions per fused level
+constexpr int LIM_C = 2048;       // children per fused level
+
+// ---- stage helpers (whole workgroup participates; all end with data visible after a sync) ----
+
+// first-occurrence flags + rank among distinct keys (np.unique semantics) for N <= limit
+// elements whose keys are in LDS.  slot[i] = position of i's key in ascending unique order.
+template <typename GrpFn>
+__device__ void unique_slots(const long long *skey, GrpFn grp, int N, unsigned char *sfirst, int *slot_out,
+                             int *count_out, int *wsum)
+{
+    for (int i = threadIdx.x; i < N; i += NT) {
+        const long long ki = skey[i];
+        const int gi = grp(i);
+        bool dup = false;
+        for (int j = 0; j < i; ++j) dup |= (skey[j] == ki) & (grp(j) == gi);
+        sfirst[i] = dup ? 0 : 1;
+    }
+    __syncthreads();
+    int nf = 0;
+    for (int i = threadIdx.x; i < N; i += NT) {
+        const long long ki = skey[i];
+        const int gi = grp(i);
+        int slot = 0;
+        for (int j = 0; j < N; ++j) {
+            const int gj = grp(j);
+            slot += (sfirst[j] != 0) & ((gj < gi) | ((gj == gi) & (skey[j] < ki)));
+        }
+        slot_out[i] = slot;
+        nf += sfirst[i];
+    }
+    int tot;
+    block_excl_scan(nf, &tot, wsum);
+    *count_out = tot;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// Speculative pre-pass: B1 = divide_region(root) (with _sift_dup), all children of all of B1
+// (without _sift_dup, offsets in choff_all), and the rois of S = [root ; B1 ; children].
+// ==========================================================================================
+__global__ void __launch_bounds__(NT)
+k_spec_prepass(AzCounts *cnt, const double *__restrict__ root, double *B1, double *child, int *choff_all,
+               float *urois, double scale, double min_side, int capR, int capCh)
+{
+    __shared__ long long skey[LIM_R];
+    __shared__ unsigned char sfirst[LIM_R];
+    __shared__ int sslot[LIM_R];
+    __shared__ int wsum[17];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+
+    // children of the root
+    const DivPlan pr = div_plan(root);
+    const int n1 = div_nchildren(pr);
+    if (n1 > LIM_R || n1 > capCh) { if (tid == 0) atomicOr(&cnt->err, 4); return; }
+    for (int bi = tid; bi < n1; bi += NT) {
+        double c[4];
+        skey[bi] = div_child(root, pr, bi, min_side, c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) child[(size_t)bi * 4 + q] = c[q];
+    }
+    __syncthreads();
+    int P1;
+    unique_slots(skey, [](int) { return 0; }, n1, sfirst, sslot, &P1, wsum);
+    if (P1 > capR) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
+    for (int i = tid; i < n1; i += NT)
+        if (sfirst[i]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) B1[(size_t)sslot[i] * 4 + q] = child[(size_t)i * 4 + q];
+        }
+    __syncthreads();
+
+    // children of ALL of B1, no dedup
+    int running = 0;
+    for (int base = 0; base < P1; base += NT) {
+        const int z = base + tid;
+        const int n = z < P1 ? div_nchildren(div_plan(B1 + 4 * (size_t)z)) : 0;
+        int tot;
+        const int ex = block_excl_scan(n, &tot, wsum);
+        if (z < P1) choff_all[z] = running + ex;
+        running += tot;
+    }
+    const int CH = running;
+    if (CH > capCh || 1 + P1 + CH > capR) { if (tid == 0) atomicOr(&cnt->err, 4); return; }
+    __syncthreads();                              // everyone has read child[] (B1 is complete)
+    for (int z = tid; z < P1; z += NT) {
+        const double *r = B1 + 4 * (size_t)z;
+        const DivPlan p = div_plan(r);
+        const int nb = div_nchildren(p);
+        const size_t o = (size_t)choff_all[z];
+        for (int bi = 0; bi < nb; ++bi) {
+            double c[4];
+            div_child(r, p, bi, min_side, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) child[(o + bi) * 4 + q] = c[q];
+        }
+    }
+    __syncthreads();
+    const int total = 1 + P1 + CH;
+    for (int i = tid; i < total; i += NT) {
+        const double *b = (i == 0) ? root : (i <= P1 ? B1 + 4 * (size_t)(i - 1) : child + 4 * (size_t)(i - 1 - P1));
+        urois[5 * (size_t)i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) urois[5 * (size_t)i + 1 + q] = (float)(b[q] * scale);
+    }
+    if (tid == 0) { cnt->specP1 = P1; cnt->specCH = CH; cnt->specU = total; }
+    (void)s_n;
+}
+
+// ==========================================================================================
+// Levels 0 .. n_fused-1 of the search loop (lib/detect/test.py:373-391), head outputs looked up
+// in the speculative pass (zoom_s / score_s / delta_s).
+// ==========================================================================================
+__global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
+{
+    __shared__ long long skey[LIM_R];
+    __shared__ long long skeyC[LIM_C];
+    __shared__ unsigned char sfirst[LIM_C];
+    __shared__ int sslot[LIM_C];
+    __shared__ int sidx[LIM_R];
+    __shared__ int wsum[17];
+    const int tid = threadIdx.x;
+    AzCounts *cnt = a.cnt;
+
+    for (int l = 0; l < a.n_fused; ++l) {
+        const int cur = l & 1;
+        const double *B = a.B[cur];
+        const int P = cnt->P[l];
+        if (P == 0) {                                // Z was empty: the reference's loop breaks
+            if (tid == 0)
+                for (int ll = l; ll < a.n_fused; ++ll) cnt->ytot[ll + 1] = cnt->ytot[l];
+            return;
+        }
+        if (P > LIM_R) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
+
+        // ---- roi projection + feature-space dedup (test.py:61-97, 210-218) -------------------
+        for (int r = tid; r < P; r += NT) {
+            float roi5[5];
+            skey[r] = roi_and_key(B + 4 * (size_t)r, a.scale, a.dedup, roi5);
+        }
+        __syncthreads();
+        int U;
+        const int batch = a.batch;
+        unique_slots(skey, [batch](int i) { return i / batch; }, P, sfirst, sslot, &U, wsum);
+        for (int i = tid; i < P; i += NT) {
+            const int slot = sslot[i];
+            a.inv[i] = slot;
+            if (sfirst[i]) {
+                sidx[slot] = i;
+                a.index[slot] = i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.ubox[(size_t)slot * 4 + q] = B[(size_t)i * 4 + q];
+            }
+        }
+        if (tid == 0) cnt->U[l] = U;
+        __syncthreads();
+
+        // ---- head outputs: look the representative's speculative row up, decode + clip ----------
+        for (int idx = tid; idx < U * (AZ_NSUB + 1); idx += NT) {
+            const int u = idx / (AZ_NSUB + 1), t = idx - u * (AZ_NSUB + 1);
+            const int r = sidx[u];
+            const int srow = l == 0 ? 0 : (l == 1 ? 1 + r : a.srcB[cur][r]);
+            if (t < AZ_NSUB) {
+                a.score_u[(size_t)u * AZ_NSUB + t] = a.score_s[(size_t)srow * AZ_NSUB + t];
+                float d4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    d4[q] = a.delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * t + q];
+                    a.delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
+                }
+                az_decode_box(a.ubox + 4 * (size_t)u, d4, a.im_h, a.im_w, a.eps,
+                              a.pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+            } else {
+                a.zoom_u[u] = a.zoom_s[srow];
+            }
+        }
+        __syncthreads();
+
+        // ---- candidates: filter + ordered append to Y / aScores (test.py:171-187, 380-381) ------
+        const int ybase = cnt->ytot[l];
+        int run = 0;
+        for (int base = 0; base < P * AZ_NSUB; base += NT) {
+            const int c = base + tid;
+            int fl = 0;
+            size_t src = 0;
+            if (c < P * AZ_NSUB) {
+                const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
+                src = (size_t)a.inv[r] * AZ_NSUB + s;
+                fl = cand_keep(a.pred_u + src * 4, a.min_side);
+            }
+            int tot;
+            const int off = block_excl_scan(fl, &tot, wsum);
+            const int dst = ybase + run + off;
+            if (fl && dst < a.capCand) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = a.pred_u[src * 4 + q];
+                a.Sall[dst] = a.score_u[src];
+            }
+            run += tot;
+        }
+        int nc = run;
+        if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0) atomicOr(&cnt->err, 2); }
+        // ---- zoom selection (test.py:383-387) -------------------------------------------------------
+        int PZ = 0;
+        for (int base = 0; base < P; base += NT) {
+            const int r = base + tid;
+            int zf = 0;
+            if (r < P) {
+                float z = a.zoom_u[a.inv[r]];
+                if (l == 0 && r == 0) z = 1.0f;
+                zf = ((double)z >= a.Tz);
+            }
+            int tot;
+            const int off = block_excl_scan(zf, &tot, wsum);
+            if (zf) {
+                const int dst = PZ + off;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.Z[(size_t)dst * 4 + q] = B[(size_t)r * 4 + q];
+                a.zr[dst] = r;
+            }
+            PZ += tot;
+        }
+        if (tid == 0) { cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc; cnt->PZ[l] = PZ; }
+        __syncthreads();
+        if (l + 1 >= a.nlev) return;
+
+        // ---- divide_region + _sift_dup (div.pyx:15-89) ---------------------------------------------
+        int CH = 0;
+        for (int base = 0; base < PZ; base += NT) {
+            const int z = base + tid;
+            const int n = z < PZ ? div_nchildren(div_plan(a.Z + 4 * (size_t)z)) : 0;
+            int tot;
+            const int ex = block_excl_scan(n, &tot, wsum);
+            if (z < PZ) a.choff[z] = CH + ex;
+            CH += tot;
+        }
+        if (CH > LIM_C || CH > a.capCh) { if (tid == 0) { atomicOr(&cnt->err, 4); cnt->CH[l] = 0; } return; }
+        __syncthreads();
+        const bool track = (l == 1);                 // level-3 regions remember their speculative row
+        const int sbase0 = 1 + cnt->specP1;
+        for (int z = tid; z < PZ; z += NT) {
+            const double *r = a.Z + 4 * (size_t)z;
+            const DivPlan p = div_plan(r);
+            const int nb = div_nchildren(p);
+            const int o = a.choff[z];
+            const int sb = track ? sbase0 + a.choff_all[a.zr[z]] : 0;
+            for (int bi = 0; bi < nb; ++bi) {
+                double c[4];
+                skeyC[o + bi] = div_child(r, p, bi, a.min_side, c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.child[(size_t)(o + bi) * 4 + q] = c[q];
+                if (track) a.csrc[o + bi] = sb + bi;
+            }
+        }
+        __syncthreads();
+        int Pn;
+        unique_slots(skeyC, [](int) { return 0; }, CH, sfirst, sslot, &Pn, wsum);
+        if (Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
+        double *Bn = a.B[cur ^ 1];
+        for (int i = tid; i < CH; i += NT)
+            if (sfirst[i]) {
+                const int slot = sslot[i];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Bn[(size_t)slot * 4 + q] = a.child[(size_t)i * 4 + q];
+                if (track) a.srcB[cur ^ 1][slot] = a.csrc[i];
+            }
+        if (tid == 0) { cnt->CH[l] = CH; cnt->P[l + 1] = Pn; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+void azk_spec_prepass(hipStream_t s, AzCounts *cnt, const double *root, double *B1, double *child, int *choff_all,
+                      float *urois, double scale, double min_side, int capR, int capCh)
+{
+    hipLaunchKernelGGL(k_spec_prepass, dim3(1), dim3(NT), 0, s, cnt, root, B1, child, choff_all, urois, scale,
+                       min_side, capR, capCh);
+}
+
+void azk_spec_levels(hipStream_t s, const AzFusedArgs &a)
+{
+    hipLaunchKernelGGL(k_spec_levels, dim3(1), dim3(NT), 0, s, a);
+}

@@ -3,36 +3,11 @@
 // 10-px-grid _sift_dup.  All of it is HBM/latency-bound integer and f64 work (no MFMA);
 // built with -ffp-contract=off so every f64/f32 expression rounds once per operation,
 // in the reference's operation order.
-#include "az_dev.h"
+#include "az_geom_dev.h"
 
 namespace {
 
 constexpr int TB = 256;
-
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
-// Exclusive prefix sum of one int per thread across the block (blockDim.x <= 1024).
-__device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints of LDS */)
-{
-    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    __syncthreads();                       // wsum may still be read from a previous call
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int w = 0; w < nw; ++w) { int t = wsum[w]; wsum[w] = run; run += t; }
-        wsum[16] = run;
-    }
-    __syncthreads();
-    *total = wsum[16];
-    return wsum[wid] + inc - v;
-}
 
 // ----------------------------------------------------------------------------------------
 __global__ void k_init_root(AzCounts *cnt, double *B0, int im_h, int im_w)
@@ -49,17 +24,7 @@ __global__ void k_rois_keys(const double *__restrict__ B, const int *Pptr, doubl
 {
     const int P = *Pptr;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P; r += gridDim.x * blockDim.x) {
-        long long h = 0, mult = 1000;
-        rois[5 * r] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float x = (float)(B[4 * r + c] * scale);
-            rois[5 * r + 1 + c] = x;
-            float t = rintf(x * dedup);            // np.round: half to even, in f32
-            h += (long long)t * mult;
-            mult *= 1000;
-        }
-        key[r] = h;
+        key[r] = roi_and_key(B + 4 * (size_t)r, scale, dedup, rois + 5 * (size_t)r);
         grp[r] = r / batch;                        // dedup is per BATCH_SIZE chunk (test.py:195-218)
     }
 }
@@ -169,11 +134,7 @@ __global__ void k_flags(const AzCounts *cnt, int level, const int *__restrict__ 
         int fl = 0;
         if (c < NCAND) {
             const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
-            const double *bx = pred_u + ((size_t)inv[r] * AZ_NSUB + s) * 4;
-            const double h = bx[3] - bx[1] + 1;
-            const double w = bx[2] - bx[0] + 1;
-            const double side = (h < w) ? h : w;          // np.minimum(heights, widths)
-            fl = side >= min_side;
+            fl = cand_keep(pred_u + ((size_t)inv[r] * AZ_NSUB + s) * 4, min_side);
             cflag[c] = (unsigned char)fl;
         }
         int zf = 0;
@@ -257,22 +218,6 @@ __global__ void k_compact(AzCounts *cnt, int level, int capCand, const double *_
 }
 
 // ----------------------------------------------------------------------------------------
-// divide_region, lib/utils/div.pyx:15-76.
-struct DivPlan { int min_ind; unsigned num_long; double l_short, l_long; };
-
-__device__ __forceinline__ DivPlan div_plan(const double *r)
-{
-    DivPlan p;
-    const double L0 = r[2] - r[0] + 1.0, L1 = r[3] - r[1] + 1.0;   // div.pyx:32-33
-    p.min_ind = (L1 < L0) ? 1 : 0;                                 // np.argmin: tie -> width
-    const double Lmin = p.min_ind ? L1 : L0, Lmax = p.min_ind ? L0 : L1;
-    p.l_short = Lmin / 2;                                          // div.pyx:40
-    const double q = Lmax / p.l_short;
-    p.num_long = (p.l_short > 0.0 && q < 1.0e6) ? (unsigned)q : 0u;   // int(): truncation, div.pyx:42
-    p.l_long = p.num_long ? Lmax / p.num_long : 0.0;               // div.pyx:43
-    return p;
-}
-
 // Single workgroup: children per parent + exclusive scan -> child offsets, total in *CHptr.
 __global__ void __launch_bounds__(1024) k_divide_scan(const int *PZptr, int *CHptr, int *err, int capCh,
                                                       const double *__restrict__ Z, int *choff)
@@ -285,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_divide_scan(const int *PZptr, int *CHp
         int n = 0;
         if (z < PZ) {
             const DivPlan p = div_plan(Z + 4 * (size_t)z);
-            n = p.num_long ? (int)(3 * p.num_long - 1) : 0;        // div.pyx:45
+            n = div_nchildren(p);
         }
         int tot;
         const int ex = block_excl_scan(n, &tot, wsum);
@@ -311,34 +256,14 @@ __global__ void k_divide_emit(const int *PZptr, const int *CHptr, const double *
         const double *r = Z + 4 * (size_t)z;
         const DivPlan p = div_plan(r);
         if (!p.num_long) continue;
-        const double x0 = r[0], y0 = r[1];
-        const double h_short = p.l_short / 2, h_long = p.l_long / 2;   // div.pyx:58-59
-        const int nb = (int)(3 * p.num_long - 1);
+        const int nb = div_nchildren(p);
         const size_t o = (size_t)choff[z];
         const int sbase = src_off ? (*src_base + src_add + src_off[zr ? zr[z] : z]) : 0;
         for (int bi = 0; bi < nb; ++bi) {
-            double s_lo, s_hi, l_lo, l_hi;      // short-axis / long-axis cell bounds
-            if (bi < (int)(2 * p.num_long)) {   // grid cells, index k*num_long + j (div.pyx:47-56)
-                const unsigned k = (unsigned)bi / p.num_long, j = (unsigned)bi - k * p.num_long;
-                s_lo = k * p.l_short; s_hi = (k + 1) * p.l_short;
-                l_lo = j * p.l_long;  l_hi = (j + 1) * p.l_long;
-            } else {                            // half-offset cells, k = 0 (div.pyx:60-69)
-                const unsigned j = (unsigned)bi - 2 * p.num_long;
-                s_lo = 0 * p.l_short + h_short; s_hi = (0 + 1) * p.l_short + h_short;
-                l_lo = j * p.l_long + h_long;   l_hi = (j + 1) * p.l_long + h_long;
-            }
             double c[4];
-            if (p.min_ind == 0) { c[0] = s_lo; c[1] = l_lo; c[2] = s_hi; c[3] = l_hi; }
-            else                { c[0] = l_lo; c[1] = s_lo; c[2] = l_hi; c[3] = s_hi; }
-            c[0] += x0; c[2] += x0; c[1] += y0; c[3] += y0;            // div.pyx:71-72
-            long long h = 0, mult = 1;
+            ckey[o + bi] = div_child(r, p, bi, min_side, c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                child[(o + bi) * 4 + q] = c[q];
-                h += (long long)rint(c[q] / min_side) * mult;          // div.pyx:86
-                mult *= 1000;
-            }
-            ckey[o + bi] = h;
+            for (int q = 0; q < 4; ++q) child[(o + bi) * 4 + q] = c[q];
             if (csrc) csrc[o + bi] = sbase + bi;
         }
     }

@@ -195,12 +195,13 @@ class AzContext(object):
     # ---- hot path -----------------------------------------------------------------
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
-                    dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True):
+                    dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
-        slower); it exists for tests and measurements."""
+        slower); fused=False keeps the geometry of those levels as separate launches.  Both
+        exist for tests and measurements."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
-                        1 if fixed_num else 0, 0 if speculate else 1)
+                        1 if fixed_num else 0, (0 if speculate else 1) | (0 if fused else 2))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates

@@ -56,7 +56,8 @@ typedef struct {
     int32_t batch_size;       /* cfg.SEAR.BATCH_SIZE (config.py:189): dedup chunk size */
     int32_t num_proposals;    /* cfg.SEAR.NUM_PROPOSALS (config.py:133, 279)           */
     int32_t fixed_num;        /* cfg.SEAR.FIXED_PROPOSAL_NUM (config.py:172)           */
-    int32_t reserved;         /* flags; bit 0: evaluate levels 1-3 one by one (no speculation) */
+    int32_t reserved;         /* flags; bit 0: evaluate levels 1-3 one by one (no speculation);
+                                 bit 1: keep their geometry as separate launches (same bits)   */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */

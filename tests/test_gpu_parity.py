@@ -289,7 +289,8 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
 
 @pytest.mark.parametrize("H,W,tz", [(600, 1000, 0.0), (375, 500, 0.6), (640, 853, 0.55), (200, 90, 0.0)])
 def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
-    """Levels 1-3 evaluated in one pass (default) vs one by one: identical bits."""
+    """Levels 1-3: one speculative pass + single-workgroup geometry (default) vs speculative
+    pass + separate launches vs level by level: identical bits."""
     ffi, synth, HipAZNet, orc = mods
     net, head = small
     scale = 600.0 / min(H, W)
@@ -298,13 +299,14 @@ def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
     fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
     net.set_conv(synth.make_feature_map(6, synth.SMALL_DIMS["C"], fh, fw))
     outs = []
-    for spec in (True, False):
-        p = ffi.AzContext.make_params(H, W, scale, tz, speculate=spec)
+    for spec, fused in ((True, True), (True, False), (False, False)):
+        p = ffi.AzContext.make_params(H, W, scale, tz, speculate=spec, fused=fused)
         Y, S, st = net.propose(p, want_scores=True, want_stats=True)
         Ya, Sa = net.ctx.last_candidates()
         outs.append((Y, S, Ya, Sa, list(st.level_regions), list(st.level_unique), list(st.level_zoomed)))
-    for a, b in zip(outs[0], outs[1]):
-        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
 
 
 def test_threshold_mode(small, mods):
