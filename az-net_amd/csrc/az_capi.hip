@@ -57,6 +57,7 @@ struct az_ctx {
     int h_cap = 0;
     // last launch
     az_params last{};
+    int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels overflowed
     int last_nlev = 0;
     // profiling
     int profiling = 0;
@@ -403,7 +404,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     // The geometry of those three levels is a few dozen elements per stage: by default it runs
     // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
     // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
-    const bool fused = n_spec && !(p->reserved & 2);
+    const bool fused = n_spec && !(p->reserved & 2) && !(p->im_h == c->nofuse_h && p->im_w == c->nofuse_w);
     if (fused) {
         Timed t(c, "spec_prepass", -1);
         azk_spec_prepass(s, c->cnt, c->B[0], c->B[1], c->child, c->choff_all, c->urois, p->scale, p->min_side,
@@ -524,6 +525,16 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
             st->num_eval += h.P[l];
             if (h.P[l] > 0) st->depth = l + 1;
         }
+    }
+    if ((h.err & 8) && !(c->last.reserved & 2)) {
+        // a fused level outgrew its LDS tables: rerun with the multi-launch kernels and remember
+        // the image shape so that later calls skip the fused attempt
+        c->nofuse_h = c->last.im_h; c->nofuse_w = c->last.im_w;
+        az_params p2 = c->last;
+        p2.reserved |= 2;
+        int rc2 = az_propose_launch(c, &p2);
+        if (rc2) return rc2;
+        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
     }
     if (h.err)
         return fail(c, AZ_ERR_CAPACITY,

@@ -13,7 +13,6 @@ namespace {
 
 constexpr int NT = 1024;          // threads of the single workgroup
 constexpr int LIM_R = 1024;       // regions per fused level
-constexpr int LIM_C = 2048;       // children per fused level
 
 // ---- stage helpers (whole workgroup participates; all end with data visible after a sync) ----
 
@@ -125,92 +124,90 @@ k_spec_prepass(AzCounts *cnt, const double *__restrict__ root, double *B1, doubl
 
 // ==========================================================================================
 // Levels 0 .. n_fused-1 of the search loop (lib/detect/test.py:373-391), head outputs looked up
-// in the speculative pass (zoom_s / score_s / delta_s).
+// in the speculative pass (zoom_s / score_s / delta_s).  All per-level state (regions, keys,
+// dedup slots, zoom set, child keys) lives in LDS; global memory is touched only to read the
+// speculative head outputs and to append candidates, so a level costs one memory round trip
+// instead of one per stage.  If a level outgrows the LDS tables the kernel reports bit 3 of
+// cnt->err and the host reruns the search with the multi-launch kernels.
 // ==========================================================================================
+constexpr int FL_R = 256;         // regions per fused level (LDS-resident)
+constexpr int FL_C = 2048;        // children per fused level
+
 __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
 {
-    __shared__ long long skey[LIM_R];
-    __shared__ long long skeyC[LIM_C];
-    __shared__ unsigned char sfirst[LIM_C];
-    __shared__ int sslot[LIM_C];
-    __shared__ int sidx[LIM_R];
+    __shared__ double sB[2][FL_R * 4];
+    __shared__ int ssrc[2][FL_R];
+    __shared__ long long skey[FL_R];
+    __shared__ long long skeyC[FL_C];
+    __shared__ unsigned char sfirst[FL_C];
+    __shared__ int sslot[FL_C];
+    __shared__ int sczi[FL_C];
+    __shared__ int sidx[FL_R], szr[FL_R], schoff[FL_R];
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
     AzCounts *cnt = a.cnt;
 
+    if (tid == 0) {                                  // lib/detect/test.py:355
+        sB[0][0] = 0.0; sB[0][1] = 0.0; sB[0][2] = a.im_w - 1.0; sB[0][3] = a.im_h - 1.0;
+    }
+    __syncthreads();
+    int P = 1;
+    int ybase = 0;
+    const int P1spec = cnt->specP1;
     for (int l = 0; l < a.n_fused; ++l) {
         const int cur = l & 1;
-        const double *B = a.B[cur];
-        const int P = cnt->P[l];
+        const double *B = sB[cur];
+        if (tid == 0) { cnt->P[l] = P; cnt->ytot[l] = ybase; }
         if (P == 0) {                                // Z was empty: the reference's loop breaks
             if (tid == 0)
-                for (int ll = l; ll < a.n_fused; ++ll) cnt->ytot[ll + 1] = cnt->ytot[l];
+                for (int ll = l; ll < a.n_fused; ++ll) { cnt->P[ll] = 0; cnt->ytot[ll + 1] = ybase; }
             return;
         }
-        if (P > LIM_R) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
 
         // ---- roi projection + feature-space dedup (test.py:61-97, 210-218) -------------------
         for (int r = tid; r < P; r += NT) {
             float roi5[5];
-            skey[r] = roi_and_key(B + 4 * (size_t)r, a.scale, a.dedup, roi5);
+            skey[r] = roi_and_key(B + 4 * r, a.scale, a.dedup, roi5);
         }
         __syncthreads();
         int U;
         const int batch = a.batch;
         unique_slots(skey, [batch](int i) { return i / batch; }, P, sfirst, sslot, &U, wsum);
-        for (int i = tid; i < P; i += NT) {
-            const int slot = sslot[i];
-            a.inv[i] = slot;
-            if (sfirst[i]) {
-                sidx[slot] = i;
-                a.index[slot] = i;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a.ubox[(size_t)slot * 4 + q] = B[(size_t)i * 4 + q];
-            }
-        }
-        if (tid == 0) cnt->U[l] = U;
+        for (int i = tid; i < P; i += NT)
+            if (sfirst[i]) sidx[sslot[i]] = i;       // index[]: representative of each unique roi
         __syncthreads();
+        // speculative row of region r's representative (level 0: the root; 1: 1 + index; 2: carried)
+        auto spec_row = [&](int r, int &rep) {
+            rep = sidx[sslot[r]];
+            return l == 0 ? 0 : (l == 1 ? 1 + rep : ssrc[cur][rep]);
+        };
 
-        // ---- head outputs: look the representative's speculative row up, decode + clip ----------
-        for (int idx = tid; idx < U * (AZ_NSUB + 1); idx += NT) {
-            const int u = idx / (AZ_NSUB + 1), t = idx - u * (AZ_NSUB + 1);
-            const int r = sidx[u];
-            const int srow = l == 0 ? 0 : (l == 1 ? 1 + r : a.srcB[cur][r]);
-            if (t < AZ_NSUB) {
-                a.score_u[(size_t)u * AZ_NSUB + t] = a.score_s[(size_t)srow * AZ_NSUB + t];
-                float d4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    d4[q] = a.delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * t + q];
-                    a.delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
-                }
-                az_decode_box(a.ubox + 4 * (size_t)u, d4, a.im_h, a.im_w, a.eps,
-                              a.pred_u + ((size_t)u * AZ_NSUB + t) * 4);
-            } else {
-                a.zoom_u[u] = a.zoom_s[srow];
-            }
-        }
-        __syncthreads();
-
-        // ---- candidates: filter + ordered append to Y / aScores (test.py:171-187, 380-381) ------
-        const int ybase = cnt->ytot[l];
+        // ---- candidates: decode + clip against the representative's box (test.py:106-151), filter,
+        //      ordered append to Y / aScores (test.py:171-187, 380-381) ------------------------------
         int run = 0;
         for (int base = 0; base < P * AZ_NSUB; base += NT) {
             const int c = base + tid;
             int fl = 0;
-            size_t src = 0;
+            double bx[4];
+            float sc = 0.f;
             if (c < P * AZ_NSUB) {
                 const int r = c / AZ_NSUB, s = c - r * AZ_NSUB;
-                src = (size_t)a.inv[r] * AZ_NSUB + s;
-                fl = cand_keep(a.pred_u + src * 4, a.min_side);
+                int rep;
+                const int srow = spec_row(r, rep);
+                float d4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d4[q] = a.delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * s + q];
+                az_decode_box(B + 4 * rep, d4, a.im_h, a.im_w, a.eps, bx);
+                fl = cand_keep(bx, a.min_side);
+                sc = a.score_s[(size_t)srow * AZ_NSUB + s];
             }
             int tot;
             const int off = block_excl_scan(fl, &tot, wsum);
             const int dst = ybase + run + off;
             if (fl && dst < a.capCand) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = a.pred_u[src * 4 + q];
-                a.Sall[dst] = a.score_u[src];
+                for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = bx[q];
+                a.Sall[dst] = sc;
             }
             run += tot;
         }
@@ -222,21 +219,18 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
             const int r = base + tid;
             int zf = 0;
             if (r < P) {
-                float z = a.zoom_u[a.inv[r]];
+                int rep;
+                float z = a.zoom_s[spec_row(r, rep)];
                 if (l == 0 && r == 0) z = 1.0f;
                 zf = ((double)z >= a.Tz);
             }
             int tot;
             const int off = block_excl_scan(zf, &tot, wsum);
-            if (zf) {
-                const int dst = PZ + off;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a.Z[(size_t)dst * 4 + q] = B[(size_t)r * 4 + q];
-                a.zr[dst] = r;
-            }
+            if (zf) szr[PZ + off] = r;
             PZ += tot;
         }
-        if (tid == 0) { cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc; cnt->PZ[l] = PZ; }
+        if (tid == 0) { cnt->U[l] = U; cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc; cnt->PZ[l] = PZ; }
+        ybase += nc;
         __syncthreads();
         if (l + 1 >= a.nlev) return;
 
@@ -244,45 +238,47 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         int CH = 0;
         for (int base = 0; base < PZ; base += NT) {
             const int z = base + tid;
-            const int n = z < PZ ? div_nchildren(div_plan(a.Z + 4 * (size_t)z)) : 0;
+            const int n = z < PZ ? div_nchildren(div_plan(B + 4 * szr[z])) : 0;
             int tot;
             const int ex = block_excl_scan(n, &tot, wsum);
-            if (z < PZ) a.choff[z] = CH + ex;
+            if (z < PZ) schoff[z] = CH + ex;
             CH += tot;
         }
-        if (CH > LIM_C || CH > a.capCh) { if (tid == 0) { atomicOr(&cnt->err, 4); cnt->CH[l] = 0; } return; }
+        if (CH > FL_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
         __syncthreads();
-        const bool track = (l == 1);                 // level-3 regions remember their speculative row
-        const int sbase0 = 1 + cnt->specP1;
         for (int z = tid; z < PZ; z += NT) {
-            const double *r = a.Z + 4 * (size_t)z;
+            const double *r = B + 4 * szr[z];
             const DivPlan p = div_plan(r);
             const int nb = div_nchildren(p);
-            const int o = a.choff[z];
-            const int sb = track ? sbase0 + a.choff_all[a.zr[z]] : 0;
+            const int o = schoff[z];
             for (int bi = 0; bi < nb; ++bi) {
                 double c[4];
                 skeyC[o + bi] = div_child(r, p, bi, a.min_side, c);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a.child[(size_t)(o + bi) * 4 + q] = c[q];
-                if (track) a.csrc[o + bi] = sb + bi;
+                sczi[o + bi] = (z << 16) | bi;
             }
         }
         __syncthreads();
         int Pn;
         unique_slots(skeyC, [](int) { return 0; }, CH, sfirst, sslot, &Pn, wsum);
-        if (Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
-        double *Bn = a.B[cur ^ 1];
+        if (Pn > FL_R || Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
         for (int i = tid; i < CH; i += NT)
             if (sfirst[i]) {
                 const int slot = sslot[i];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Bn[(size_t)slot * 4 + q] = a.child[(size_t)i * 4 + q];
-                if (track) a.srcB[cur ^ 1][slot] = a.csrc[i];
+                const int z = sczi[i] >> 16, bi = sczi[i] & 0xFFFF;
+                const int pr = szr[z];
+                const double *r = B + 4 * pr;
+                div_child(r, div_plan(r), bi, a.min_side, &sB[cur ^ 1][4 * slot]);
+                // level-3 regions remember their row in the speculative pass: (parent in B1, child)
+                ssrc[cur ^ 1][slot] = (l == 1) ? 1 + P1spec + a.choff_all[pr] + bi : 0;
             }
-        if (tid == 0) { cnt->CH[l] = CH; cnt->P[l + 1] = Pn; }
+        if (tid == 0) cnt->CH[l] = CH;
+        P = Pn;
         __syncthreads();
     }
+    // hand the next level's regions to the multi-workgroup kernels
+    const int nxt = a.n_fused & 1;
+    for (int i = tid; i < P * 4; i += NT) a.B[nxt][i] = sB[nxt][i];
+    if (tid == 0) cnt->P[a.n_fused] = P;
 }
 
 // ------------------------------------------------------------------------------------------

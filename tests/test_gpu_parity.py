@@ -287,7 +287,8 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
         assert np.abs(Y - b).max(axis=1).min() < 1e-3
 
 
-@pytest.mark.parametrize("H,W,tz", [(600, 1000, 0.0), (375, 500, 0.6), (640, 853, 0.55), (200, 90, 0.0)])
+@pytest.mark.parametrize("H,W,tz", [(600, 1000, 0.0), (375, 500, 0.6), (640, 853, 0.55), (200, 90, 0.0),
+                                    (60, 1000, 0.0), (1000, 40, 0.3)])
 def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
     """Levels 1-3: one speculative pass + single-workgroup geometry (default) vs speculative
     pass + separate launches vs level by level: identical bits."""
