@@ -242,41 +242,117 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 #pragma unroll
         for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].w, bf.w, acc[r], 0, 0, 0);
     };
-    static_assert(BK == 32, "the step body below is written for four 8-wide k groups");
-    // One K-step: MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 into (rl_a, rl_b) and
-    // write tile kt+1 from (rw_a, rw_b) into LDS[buf^1].
-    auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
-                    const float4 (&rw_b)[4]) {
-        float4 a0[NRT], a1[NRT], b0, b1;
-        frag(buf, 0, a0, b0);
-        gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: keeps the vmcnt bookkeeping exact
-        __builtin_amdgcn_sched_barrier(0);
-        frag(buf, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        frag(buf, 2, a0, b0);
-        lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: writes a tile nobody reads)
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        frag(buf, 3, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma8(a1, b1);
-        __syncthreads();
-    };
-
+    static_assert(BK == 32, "the step bodies below are written for four 8-wide k groups");
     float4 ra0[NRT], rb0[4], ra1[NRT], rb1[4];
     gload(0, ra0, rb0);
     gload(nk > 1 ? 1 : 0, ra1, rb1);
     __syncthreads();                 // the previous work item's readers are done with both buffers
     lstore(0, 0, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, 0, ra0, rb0, ra1, rb1);
-        if (kt + 1 < nk) step(kt + 1, 1, ra1, rb1, ra0, rb0);
+
+    if constexpr (NRT >= 3) {
+        // MFMA-bound shape.  The barrier sits in the MIDDLE of the K-step: when a wave reaches it
+        // two of its four k groups (32 MFMAs, ~2000 cycles) are still queued with their operands
+        // already in registers, so barrier skew and the first fragment reads of the next tile
+        // hide behind them and the matrix pipe never drains.  Inside a group the other
+        // instructions are interleaved one per MFMA issue slot (sched_group_barrier).
+        //   a0/a1 hold the fragments of k groups 0/1 of tile kt on entry.
+        float4 a0[NRT], a1[NRT], b0, b1;
+        frag(0, 0, a0, b0);
+        frag(0, 1, a1, b1);
+        auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
+                        const float4 (&rw_b)[4]) {
+            __builtin_amdgcn_sched_barrier(0);
+            // group 0 MFMAs | request tile kt+2 | fragments of group 2
+            gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
+            float4 a2[NRT], b2;
+            frag(buf, 2, a2, b2);
+            mfma8(a0, b0);
+#pragma unroll
+            for (int i = 0; i < NRT + 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+            }
+#pragma unroll
+            for (int i = 0; i < NRT + 1; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (2 * NRT + 5), 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 1 MFMAs | tile kt+1 -> LDS[buf^1] | fragments of group 3
+            lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
+            float4 a3[NRT], b3;
+            frag(buf, 3, a3, b3);
+            mfma8(a1, b1);
+#pragma unroll
+            for (int i = 0; i < NRT + 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);   // 1 DS write
+            }
+#pragma unroll
+            for (int i = 0; i < NRT + 1; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (2 * NRT + 5), 1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();         // LDS[buf^1] (tile kt+1) complete; everyone's reads of LDS[buf] issued
+            __builtin_amdgcn_sched_barrier(0);
+            // group 2 MFMAs | fragments of group 0 of tile kt+1
+            frag(buf ^ 1, 0, a0, b0);
+            mfma8(a2, b2);
+#pragma unroll
+            for (int i = 0; i < NRT + 1; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (NRT + 1), 2);
+            __builtin_amdgcn_sched_barrier(0);
+            // group 3 MFMAs | fragments of group 1 of tile kt+1
+            frag(buf ^ 1, 1, a1, b1);
+            mfma8(a3, b3);
+#pragma unroll
+            for (int i = 0; i < NRT + 1; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 3);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (NRT + 1), 3);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, 0, ra0, rb0, ra1, rb1);
+            if (kt + 1 < nk) step(kt + 1, 1, ra1, rb1, ra0, rb0);
+        }
+    } else {
+        // Weight-streaming-bound shape (<= 64 rows): what matters is bytes in flight, not MFMA
+        // density.  MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 and write tile kt+1.
+        auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
+                        const float4 (&rw_b)[4]) {
+            float4 a0[NRT], a1[NRT], b0, b1;
+            frag(buf, 0, a0, b0);
+            gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
+            __builtin_amdgcn_sched_barrier(0);
+            frag(buf, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(buf, 2, a0, b0);
+            lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            frag(buf, 3, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma8(a1, b1);
+            __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(kt, 0, ra0, rb0, ra1, rb1);
+            if (kt + 1 < nk) step(kt + 1, 1, ra1, rb1, ra0, rb0);
+        }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8*(e >> 2) + 4*(lane >> 5).
