@@ -10,6 +10,7 @@
 // makes the result independent of cfg.SEAR.BATCH_SIZE chunking.
 #include "az_dev.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -129,6 +130,12 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;          // padded LDS row (floats): 144 B, conflict-free b128 reads
 constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
+static int gemm_grid()
+{
+    static int g = -1;
+    if (g < 0) { const char *e = getenv("AZ_GEMM_GRID"); g = e ? atoi(e) : GEMM_GRID; }
+    return g;
+}
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -524,7 +531,7 @@ static int fc_chunk(int K, int S)
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
                  int N, int K, int S, float *part)
 {
-    hipLaunchKernelGGL(k_fc_splitk, dim3(GEMM_GRID), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
+    hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
                        fc_chunk(K, S), part);
 }
 

@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--gather-every", type=int, default=8, help="images per rank per RCCL gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="images in flight per GPU (each on its own az_ctx/stream); 1 = strictly one at a time")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
     args = ap.parse_args()
 
@@ -119,25 +121,45 @@ def main():
         torch.cuda.synchronize()
 
     pending = []
+    # extra contexts for pipelining independent images on one GPU (same weights, same map)
+    nets = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
+                    for _ in range(args.inflight - 1)]
+    for n in nets[1:]:
+        n.set_conv(conv)
 
-    def step(i):
-        Y, S = net.propose(params, want_scores=True)
+    def finish(Y, S, i):
         if world > 1:
             pending.append((Y, S))
             if len(pending) == args.gather_every or i == args.steps - 1:
                 azdist.gather_proposals(pending, NUM_PROPOSALS, device=dev)
                 del pending[:]
-        return Y
 
-    for i in range(args.warmup):
-        step(-1)
+    def run(nsteps, timed):
+        if args.inflight == 1:
+            for i in range(nsteps):
+                Y, S = net.propose(params, want_scores=True)
+                finish(Y, S, i if timed else -1)
+            return
+        q = []
+        for i in range(nsteps):
+            n = nets[i % len(nets)]
+            if len(q) == len(nets):
+                m, j = q.pop(0)
+                Y, S = m.ctx.propose_fetch(want_scores=True)
+                finish(Y, S, j if timed else -1)
+            n.ctx.propose_launch(params)
+            q.append((n, i))
+        for m, j in q:
+            Y, S = m.ctx.propose_fetch(want_scores=True)
+            finish(Y, S, j if timed else -1)
+
+    run(args.warmup, False)
     del pending[:]
     net.ctx.set_profiling(0)
     net.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -180,7 +202,7 @@ def main():
                                    "conv5_3 [1,512,38,63] resident in HBM" %
                                    (args.tz, regions, uniq, NUM_PROPOSALS, st.n_candidates),
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
-                       "parallelism": "image-shard x%d" % world,
+                       "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
                        "gather": ("RCCL all_gather every %d images/rank" % args.gather_every) if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": "k_fc_splitk (fc6+fc7 GEMM, v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
