@@ -191,9 +191,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
     { Timed t(c, "fc7_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b7, Uptr, c->maxR, d.n7, c->S7, c->h7, d.n7, 1); }
-    { Timed t(c, "head_tail", level);
-      azk_head_tail(c->stream, c->h7, d, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, c->part,
-                    zoom, score, delta, c->pred_u); }
+    { Timed t(c, "tail_gemm", level, 1);
+      azk_fc_gemm(c->stream, c->h7, d.n7, c->Wt, d.n7, Uptr, c->maxR, AZK_TAIL_NOUT, d.n7, AZK_TAIL_SPLIT, c->part); }
+    { Timed t(c, "tail_epilogue", level);
+      azk_tail_epilogue(c->stream, c->part, AZK_TAIL_SPLIT, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom,
+                        score, delta, c->pred_u); }
 }
 
 int check_geom(az_ctx *c)

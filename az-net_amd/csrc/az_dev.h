@@ -122,12 +122,13 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
                  int N, int K, int S, float *part);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu);
-// adj_score + adj_bbox + zoom_score as one more GEMM over Wt [56, n71+n72] (zero-padded rows),
-// then slab sum + bias + sigmoid + box decode/clip.  `part` is GEMM scratch.
+// adj_score + adj_bbox + zoom_score are one more azk_fc_gemm over Wt [56, n71+n72] (zero-padded
+// rows, AZK_TAIL_SPLIT chunks); this finishes them: slab sum + bias + sigmoid + box decode/clip.
 #define AZK_TAIL_SPLIT 8
-void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
-                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *part,
-                   float *zoom_u, float *score_u, float *delta_u, double *pred_u);
+#define AZK_TAIL_NOUT 56
+void azk_tail_epilogue(hipStream_t s, const float *part, int S, const float *bt, const double *ubox,
+                       const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
+                       float *delta_u, double *pred_u);
 int azk_fc_split(int K);
 
 // ---- launchers (az_select.hip) ---------------------------------------------------------

@@ -541,12 +541,10 @@ void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const in
     hipLaunchKernelGGL(k_fc_reduce, dim3(1024), dim3(256), 0, s, part, bias, Mptr, capM, N, S, y, ldy, relu);
 }
 
-void azk_head_tail(hipStream_t s, const float *h7, AzHeadDims d, const float *Wt, const float *bt,
-                   const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *part,
-                   float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+void azk_tail_epilogue(hipStream_t s, const float *part, int S, const float *bt, const double *ubox,
+                       const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
+                       float *delta_u, double *pred_u)
 {
-    const int S = AZK_TAIL_SPLIT;
-    azk_fc_gemm(s, h7, d.n7, Wt, d.n7, Uptr, capU, NOUT, d.n7, S, part);
     hipLaunchKernelGGL(k_tail_epilogue, dim3(256), dim3(256), 0, s, part, capU, S, bt, ubox, Uptr, im_h, im_w,
                        eps, zoom_u, score_u, delta_u, pred_u);
 }
