@@ -44,6 +44,13 @@ struct az_ctx {
     // speculative levels 1-3: provenance of zoomed regions / children / regions, head outputs of the pass
     int *zr = nullptr, *csrc = nullptr, *choff_all = nullptr, *srcB[2] = {nullptr, nullptr};
     float *zoom_s = nullptr, *score_s = nullptr, *delta_s = nullptr;
+    // Fast R-CNN head on the shared map (az_load_det_head)
+    bool det_loaded = false;
+    int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
+    std::vector<void *> allocs_det;
+    float *dW6 = nullptr, *db6 = nullptr, *dW7 = nullptr, *db7 = nullptr, *dWt = nullptr, *dbt = nullptr;
+    float *dh6 = nullptr, *dh7 = nullptr, *dpart = nullptr, *dprob_u = nullptr, *ddelta_u = nullptr, *dprob = nullptr;
+    double *dpred_u = nullptr, *dpred = nullptr;
     // nms scratch (grown on demand)
     int nms_cap = 0;
     float *nms_dets = nullptr, *nms_sdets = nullptr;
@@ -91,6 +98,17 @@ int dalloc(az_ctx *c, T **p, size_t n, bool geom = false)
         return fail(c, AZ_ERR_HIP, std::string("hipMalloc(") + std::to_string(n * sizeof(T)) + " B): " +
                                        hipGetErrorString(e));
     (geom ? c->allocs_geom : c->allocs).push_back(q);
+    *p = (T *)q;
+    return AZ_OK;
+}
+
+template <typename T>
+int dalloc_det(az_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+    if (e != hipSuccess) return fail(c, AZ_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->allocs_det.push_back(q);
     *p = (T *)q;
     return AZ_OK;
 }
@@ -246,6 +264,8 @@ int az_destroy(az_ctx *c)
     free_all(c);
     for (void *p : c->allocs_geom) hipFree(p);
     c->allocs_geom.clear();
+    for (void *p : c->allocs_det) hipFree(p);
+    c->allocs_det.clear();
     if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
     if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
@@ -783,6 +803,132 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
     HIPCHK(c, hipGetLastError());
     *n_keep = h_nk;
     if (h_nk) HIPCHK(c, hipMemcpy(keep, c->nms_keep, (size_t)h_nk * 8, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+
+// --------------------------------------------------------------------------------------
+// Fast R-CNN head on the shared conv map (lib/detect/test.py:259-318,432-445).
+int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6, const float *b6,
+                     const float *W7, const float *b7, const float *Wc, const float *bc, const float *Wb,
+                     const float *bb)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (!W6 || !b6 || !W7 || !b7 || !Wc || !bc || !Wb || !bb) return fail(c, AZ_ERR_INVALID, "az_load_det_head: null pointer");
+    if (C <= 0 || (C & 3) || n6 <= 0 || (n6 & 3) || n7 <= 0 || (n7 & 3) || ncls < 2 || ncls > 64)
+        return fail(c, AZ_ERR_INVALID, "az_load_det_head: C, n6, n7 multiples of 4; 2 <= ncls <= 64");
+    if (c->head_loaded && C != c->d.C) return fail(c, AZ_ERR_INVALID, "az_load_det_head: C differs from the AZ head's");
+    int rc = ensure_geom(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (void *p : c->allocs_det) hipFree(p);
+    c->allocs_det.clear();
+    c->det_loaded = false;
+    const size_t R = (size_t)c->maxR, K6 = (size_t)C * 49, NO = (size_t)5 * ncls;
+    c->det_n6 = n6; c->det_n7 = n7; c->det_ncls = ncls;
+    c->det_S6 = azk_fc_split((int)K6); c->det_S7 = azk_fc_split(n6);
+#define A(p, n) if ((rc = dalloc_det(c, &c->p, (n))) != AZ_OK) return rc
+    A(dW6, (size_t)n6 * K6); A(db6, n6); A(dW7, (size_t)n7 * n6); A(db7, n7); A(dWt, NO * n7); A(dbt, NO);
+    A(dh6, R * n6); A(dh7, R * n7);
+    {
+        size_t pm = (size_t)c->det_S6 * R * n6;
+        const size_t p7 = (size_t)c->det_S7 * R * n7, pt = (size_t)AZK_TAIL_SPLIT * R * NO, pw = (size_t)n6 * K6;
+        pm = pm > p7 ? pm : p7; pm = pm > pt ? pm : pt; pm = pm > pw ? pm : pw;
+        A(dpart, pm);
+    }
+    A(dprob_u, R * ncls); A(ddelta_u, R * 4 * ncls); A(dpred_u, R * ncls * 4); A(dprob, R * ncls); A(dpred, R * ncls * 4);
+    if (!c->pool5) { A(pool5, R * K6); }     // normally the AZ head's buffer is shared
+#undef A
+    if (!c->head_loaded) { c->d.C = C; c->d.pooled = 7; c->d.K6 = (int)K6; }
+    HIPCHK(c, hipMemcpy(c->dpart, W6, (size_t)n6 * K6 * 4, hipMemcpyHostToDevice));
+    azk_permute_k(c->stream, c->dpart, c->dW6, n6, C, 1);          // bin-major columns, like the AZ head
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->db6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dW7, W7, (size_t)n7 * n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->db7, b7, (size_t)n7 * 4, hipMemcpyHostToDevice));
+    // rows 0..ncls-1 cls_score, ncls..5*ncls-1 bbox_pred
+    HIPCHK(c, hipMemcpy(c->dWt, Wc, (size_t)ncls * n7 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dWt + (size_t)ncls * n7, Wb, (size_t)4 * ncls * n7 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dbt, bc, (size_t)ncls * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->dbt + ncls, bb, (size_t)4 * ncls * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->det_loaded = true;
+    return AZ_OK;
+}
+
+// the detection head on the `U` rois in ctx->urois / ctx->ubox
+static void launch_det_head(az_ctx *c, const int *Uptr, int im_h, int im_w, double eps)
+{
+    AzHeadDims d = c->d;
+    const int K6 = d.C * 49, NO = 5 * c->det_ncls;
+    d.K6 = K6;
+    { Timed t(c, "det_roi_pool", 0);
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5); }
+    { Timed t(c, "det_fc6_gemm", 0, 1);
+      azk_fc_gemm(c->stream, c->pool5, K6, c->dW6, K6, Uptr, c->maxR, c->det_n6, K6, c->det_S6, c->dpart); }
+    { Timed t(c, "det_fc6_reduce", 0);
+      azk_fc_reduce(c->stream, c->dpart, c->db6, Uptr, c->maxR, c->det_n6, c->det_S6, c->dh6, c->det_n6, 1); }
+    { Timed t(c, "det_fc7_gemm", 0, 1);
+      azk_fc_gemm(c->stream, c->dh6, c->det_n6, c->dW7, c->det_n6, Uptr, c->maxR, c->det_n7, c->det_n6, c->det_S7,
+                  c->dpart); }
+    { Timed t(c, "det_fc7_reduce", 0);
+      azk_fc_reduce(c->stream, c->dpart, c->db7, Uptr, c->maxR, c->det_n7, c->det_S7, c->dh7, c->det_n7, 1); }
+    { Timed t(c, "det_tail_gemm", 0, 1);
+      azk_fc_gemm(c->stream, c->dh7, c->det_n7, c->dWt, c->det_n7, Uptr, c->maxR, NO, c->det_n7, AZK_TAIL_SPLIT,
+                  c->dpart); }
+    { Timed t(c, "det_epilogue", 0);
+      azk_det_epilogue(c->stream, c->dpart, AZK_TAIL_SPLIT, c->det_ncls, c->dbt, c->ubox, Uptr, c->maxR, im_h, im_w,
+                       eps, c->dprob_u, c->ddelta_u, c->dpred_u); }
+}
+
+static int check_det(az_ctx *c)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (!c->det_loaded) return fail(c, AZ_ERR_STATE, "az_load_det_head has not been called");
+    if (!c->feat) return fail(c, AZ_ERR_STATE, "no feature map set");
+    return AZ_OK;
+}
+
+int az_det_forward(az_ctx *c, const float *rois, int R, float *cls_prob, float *bbox_pred)
+{
+    int rc = check_det(c);
+    if (rc) return rc;
+    if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
+    if (!(c->profiling & 4)) clear_events(c);
+    launch_det_head(c, &c->cnt->U[0], 1, 1, 0.0);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    const size_t nc = (size_t)c->det_ncls;
+    if (R && cls_prob) HIPCHK(c, hipMemcpy(cls_prob, c->dprob_u, (size_t)R * nc * 4, hipMemcpyDeviceToHost));
+    if (R && bbox_pred) HIPCHK(c, hipMemcpy(bbox_pred, c->ddelta_u, (size_t)R * 4 * nc * 4, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup, int batch_size, int im_h,
+              int im_w, double eps, float *scores_out, double *boxes_out)
+{
+    int rc = check_det(c);
+    if (rc) return rc;
+    if (P < 0 || (P && !boxes) || batch_size <= 0 || !(scale > 0)) return fail(c, AZ_ERR_INVALID, "az_detect: bad arguments");
+    if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_detect: too many boxes");
+    if (P == 0) return AZ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!(c->profiling & 4)) clear_events(c);
+    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+    HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
+    azk_rois_keys(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp);
+    azk_dedup_rois(s, c->key, c->grp, &c->cnt->P[0], c->maxR, c->first, c->rois, c->B[0], c->index, c->inv,
+                   c->urois, c->ubox, &c->cnt->U[0]);
+    launch_det_head(c, &c->cnt->U[0], im_h, im_w, eps);
+    azk_det_gather(s, &c->cnt->P[0], c->inv, c->det_ncls, c->dprob_u, c->dpred_u, c->dprob, c->dpred);
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    const size_t nc = (size_t)c->det_ncls;
+    if (scores_out) HIPCHK(c, hipMemcpy(scores_out, c->dprob, (size_t)P * nc * 4, hipMemcpyDeviceToHost));
+    if (boxes_out) HIPCHK(c, hipMemcpy(boxes_out, c->dpred, (size_t)P * nc * 4 * sizeof(double), hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 

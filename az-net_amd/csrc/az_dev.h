@@ -130,6 +130,13 @@ void azk_tail_epilogue(hipStream_t s, const float *part, int S, const float *bt,
                        const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
                        float *delta_u, double *pred_u);
 int azk_fc_split(int K);
+// Fast R-CNN head: cls_score | bbox_pred come from one azk_fc_gemm over [5*ncls, n7] weights;
+// softmax + per-class box decode per unique roi, then the un-dedup gather.
+void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,
+                      const int *Uptr, int capU, int im_h, int im_w, double eps, float *prob_u, float *delta_u,
+                      double *pred_u);
+void azk_det_gather(hipStream_t s, const int *Pptr, const int *inv, int ncls, const float *prob_u,
+                    const double *pred_u, float *prob, double *pred);
 
 // ---- launchers (az_select.hip) ---------------------------------------------------------
 // Top-k by score (descending, ties: lower index first).  With Yall/Sall/Yout/Sout non-NULL the

@@ -492,6 +492,68 @@ k_tail_epilogue(const float *__restrict__ part, int capM, int S, const float *__
     }
 }
 
+// ======================================================================================
+// Fast R-CNN head epilogue (models/Pascal/VGG16/frcnn/test_fc.prototxt:91-145, driver
+// lib/detect/test.py:259-318): cls_score (ncls) and bbox_pred (4*ncls) are one azk_fc_gemm over
+// the stacked [5*ncls, n7] weights; this finishes them per unique roi: slab sum + bias, Softmax
+// over the classes (Caffe: subtract the max, exp, sum in channel order, divide -- all f32), and
+// _bbox_pred + _clip_boxes of every class box against the roi's own anchor.
+// One wave per roi; lane c handles class c (ncls <= 64).
+// ======================================================================================
+__global__ void __launch_bounds__(256)
+k_det_epilogue(const float *__restrict__ part, int capM, int S, int ncls, const float *__restrict__ bt,
+               const double *__restrict__ ubox, const int *Uptr, int im_h, int im_w, double eps,
+               float *prob_u, float *delta_u, double *pred_u)
+{
+    const int U = *Uptr;
+    const int NO = 5 * ncls;
+    const size_t slab = (size_t)capM * NO;
+    const int lane = threadIdx.x & 63;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < U; u += nwaves) {
+        const float *row = part + (size_t)u * NO;
+        auto out = [&](int o) {
+            float a = row[o];
+            for (int s = 1; s < S; ++s) a += row[o + s * slab];
+            return a + bt[o];
+        };
+        const bool live = lane < ncls;
+        const float x = live ? out(lane) : -FLT_MAX;
+        float m = x;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const float t = __shfl_xor(m, d, 64); m = t > m ? t : m; }
+        const float e = live ? expf(x - m) : 0.f;
+        float sum = 0.f;                                   // channel order, like Caffe's gemv with ones
+        for (int c = 0; c < ncls; ++c) sum += __shfl(e, c, 64);
+        if (live) {
+            prob_u[(size_t)u * ncls + lane] = e / sum;
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                d4[q] = out(ncls + 4 * lane + q);
+                delta_u[(size_t)u * 4 * ncls + 4 * lane + q] = d4[q];
+            }
+            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * ncls + lane) * 4);
+        }
+    }
+}
+
+// scores / boxes of every input region = those of its unique roi (test.py:310-312)
+__global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int ncls, const float *__restrict__ prob_u,
+                             const double *__restrict__ pred_u, float *prob, double *pred)
+{
+    const int P = *Pptr;
+    const long long total = (long long)P * ncls;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / ncls), c = (int)(i - (long long)r * ncls);
+        const size_t src = (size_t)inv[r] * ncls + c;
+        prob[i] = prob_u[src];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pred[(size_t)i * 4 + q] = pred_u[src * 4 + q];
+    }
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------
@@ -547,4 +609,18 @@ void azk_tail_epilogue(hipStream_t s, const float *part, int S, const float *bt,
 {
     hipLaunchKernelGGL(k_tail_epilogue, dim3(256), dim3(256), 0, s, part, capU, S, bt, ubox, Uptr, im_h, im_w,
                        eps, zoom_u, score_u, delta_u, pred_u);
+}
+
+void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,
+                      const int *Uptr, int capU, int im_h, int im_w, double eps, float *prob_u, float *delta_u,
+                      double *pred_u)
+{
+    hipLaunchKernelGGL(k_det_epilogue, dim3(256), dim3(256), 0, s, part, capU, S, ncls, bt, ubox, Uptr, im_h, im_w,
+                       eps, prob_u, delta_u, pred_u);
+}
+
+void azk_det_gather(hipStream_t s, const int *Pptr, const int *inv, int ncls, const float *prob_u,
+                    const double *pred_u, float *prob, double *pred)
+{
+    hipLaunchKernelGGL(k_det_gather, dim3(256), dim3(256), 0, s, Pptr, inv, ncls, prob_u, pred_u, prob, pred);
 }

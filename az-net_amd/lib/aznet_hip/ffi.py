@@ -26,7 +26,7 @@ SYMBOLS = [
     "az_set_feature_map_dev", "az_set_feature_map_host", "az_propose", "az_propose_launch",
     "az_propose_fetch", "az_last_candidates", "az_divide_region", "az_sift_dup", "az_roi_dedup",
     "az_roi_pool", "az_head_forward", "az_decode_filter", "az_topk", "az_nms", "az_set_profiling",
-    "az_last_kernel_times", "az_stream",
+    "az_last_kernel_times", "az_stream", "az_load_det_head", "az_det_forward", "az_detect",
 ]
 
 
@@ -94,6 +94,9 @@ def load_library(path=None):
     L.az_decode_filter.argtypes = [vp, dp, fp, fp, ci, ci, ci, cd, cd, dp, fp, ci, cip]
     L.az_topk.argtypes = [vp, fp, ci, ci, ip, cip]
     L.az_nms.argtypes = [vp, fp, ci, cd, i64p, cip]
+    L.az_load_det_head.argtypes = [vp, ci, ci, ci, ci] + [fp] * 8
+    L.az_det_forward.argtypes = [vp, fp, ci, fp, fp]
+    L.az_detect.argtypes = [vp, dp, ci, cd, cd, ci, ci, ci, cd, fp, dp]
     L.az_set_profiling.argtypes = [vp, ci]
     L.az_last_kernel_times.argtypes = [vp, ctypes.c_char_p, fp, ip, ci, cip]
     L.az_stream.restype = vp
@@ -332,6 +335,42 @@ class AzContext(object):
         self._chk(self.L.az_nms(self.h, _p(dets, ctypes.c_float), N, float(thresh), _p(keep, ctypes.c_int64),
                                 ctypes.byref(n)))
         return keep[:n.value].copy()
+
+    # ---- Fast R-CNN head on the shared map -----------------------------------------------
+    def load_det_head(self, head):
+        """head: dict of Caffe-layout fp32 arrays W6,b6 (fc6), W7,b7 (fc7), Wc,bc (cls_score),
+        Wb,bb (bbox_pred)."""
+        W6 = _f32(head["W6"])
+        n6, K6 = W6.shape
+        assert K6 % 49 == 0
+        C = K6 // 49
+        n7 = head["W7"].shape[0]
+        ncls = head["Wc"].shape[0]
+        assert head["W7"].shape == (n7, n6) and head["Wc"].shape == (ncls, n7) and head["Wb"].shape == (4 * ncls, n7)
+        arrs = [W6] + [_f32(head[k]) for k in ("b6", "W7", "b7", "Wc", "bc", "Wb", "bb")]
+        self._chk(self.L.az_load_det_head(self.h, C, n6, n7, ncls, *[_p(a, ctypes.c_float) for a in arrs]))
+        self.det_dims = dict(C=C, n6=n6, n7=n7, ncls=ncls)
+
+    def det_forward(self, rois):
+        rois = _f32(rois).reshape(-1, 5)
+        R = rois.shape[0]
+        nc = self.det_dims["ncls"]
+        p = np.empty((max(R, 1), nc), dtype=np.float32)
+        b = np.empty((max(R, 1), 4 * nc), dtype=np.float32)
+        self._chk(self.L.az_det_forward(self.h, _p(rois, ctypes.c_float), R, _p(p, ctypes.c_float),
+                                        _p(b, ctypes.c_float)))
+        return p[:R], b[:R]
+
+    def detect(self, boxes, scale, im_h, im_w, dedup=1. / 16., batch_size=10000, eps=1e-14):
+        boxes = _f64(boxes).reshape(-1, 4)
+        P = boxes.shape[0]
+        nc = self.det_dims["ncls"]
+        s = np.empty((max(P, 1), nc), dtype=np.float32)
+        b = np.empty((max(P, 1), 4 * nc), dtype=np.float64)
+        self._chk(self.L.az_detect(self.h, _p(boxes, ctypes.c_double), P, float(scale), float(dedup),
+                                   int(batch_size), int(im_h), int(im_w), float(eps), _p(s, ctypes.c_float),
+                                   _p(b, ctypes.c_double)))
+        return s[:P], b[:P]
 
     # ---- measurement -----------------------------------------------------------------
     def set_profiling(self, mode):

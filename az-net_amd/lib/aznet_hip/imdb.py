@@ -14,6 +14,7 @@ class SyntheticImdb(object):
     def __init__(self, height=600, width=1000, num_images=8, name=None):
         self.height, self.width = int(height), int(width)
         self.image_index = list(range(int(num_images)))
+        self.num_classes = 21            # VOC: background + 20 (models/Pascal)
         self.name = name or "synthetic_%dx%d_%d" % (self.height, self.width, len(self.image_index))
 
     def image_at(self, i):

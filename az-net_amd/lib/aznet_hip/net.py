@@ -81,3 +81,39 @@ class HipAZNet(object):
             for b in blobs:
                 out[b] = self._conv
         return out
+
+
+class HipDetNet(object):
+    """Fast R-CNN detection net on the shared conv map: stands where the reference's
+    `frcnn_nets = {'fc': caffe.Net(frcnn/test_fc.prototxt, ...)}` stood (tools/test_shared.py).
+    It shares the AZ net's az_ctx, so both heads read the same channel-last map in HBM.
+    Also pycaffe-shaped (`forward(rois=, conv5_3=)` -> cls_prob, bbox_pred; test.py:302-307)."""
+
+    def __init__(self, det_head, az_net, name="vgg16_frcnn_hip"):
+        self.ctx = az_net.ctx
+        self.az_net = az_net
+        self.ctx.load_det_head(det_head)
+        self.num_classes = self.ctx.det_dims["ncls"]
+        self.name = name
+        self.blobs = {k: _Blob() for k in ("data", "rois", "conv5_3")}
+
+    def __getitem__(self, k):
+        if k == "fc":
+            return self
+        raise KeyError(k)
+
+    def keys(self):
+        return ["fc"]
+
+    def __contains__(self, k):
+        return k == "fc"
+
+    def detect(self, boxes, scale, im_shape, dedup, batch_size, eps):
+        return self.ctx.detect(boxes, scale, im_shape[0], im_shape[1], dedup=dedup, batch_size=batch_size, eps=eps)
+
+    def forward(self, blobs=None, **kw):
+        rois = np.ascontiguousarray(kw["rois"], dtype=np.float32)
+        if "conv5_3" in kw and kw["conv5_3"] is not self.az_net._conv:
+            self.az_net.set_conv(kw["conv5_3"])
+        p, b = self.ctx.det_forward(rois)
+        return {"cls_prob": p, "bbox_pred": b}

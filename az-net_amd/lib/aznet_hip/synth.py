@@ -52,3 +52,28 @@ def conv_out_size(n):
     for _ in range(4):
         n = (n + 1) // 2
     return n
+
+
+# Fast R-CNN head (models/Pascal/VGG16/frcnn/test_fc.prototxt): roi_pool5 -> fc6 -> fc7 ->
+# {cls_score ncls (softmax), bbox_pred 4*ncls}; VOC has 21 classes.
+FULL_DET_DIMS = dict(C=512, n6=4096, n7=4096, ncls=21)
+SMALL_DET_DIMS = dict(C=16, n6=128, n7=96, ncls=21)
+
+
+def make_det_head(seed=4242, C=512, n6=4096, n7=4096, ncls=21, pooled=7):
+    """Random fp32 detection-head weights (Caffe [out, in] layout)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    K6 = C * pooled * pooled
+
+    def w(n_out, n_in, gain):
+        a = rng.standard_normal((n_out, n_in), dtype=np.float32)
+        a *= np.float32(gain / np.sqrt(n_in))
+        return a
+
+    head = {
+        "W6": w(n6, K6, 1.0), "b6": 0.1 * rng.standard_normal(n6, dtype=np.float32),
+        "W7": w(n7, n6, 1.4), "b7": 0.1 * rng.standard_normal(n7, dtype=np.float32),
+        "Wc": w(ncls, n7, 3.0), "bc": np.zeros(ncls, dtype=np.float32),
+        "Wb": w(4 * ncls, n7, 0.3), "bb": np.zeros(4 * ncls, dtype=np.float32),
+    }
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in head.items()}

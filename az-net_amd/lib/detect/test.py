@@ -121,6 +121,36 @@ def im_propose(net, im, return_conv=False, num_proposals=None, conv=None):
     return Y
 
 
+def _frcnn_forward(net, im, all_boxes, num_classes, conv=None):
+    """Fast R-CNN head over proposals on the cached conv map (test.py:259-318): one az_detect
+    call (roi projection + dedup, RoIPool, fc6/fc7, cls_score softmax, bbox_pred decode + clip for
+    every class, un-dedup).  Returns scores [R, K] and boxes [R, 4K] as float64, and conv."""
+    dnet = net["fc"] if isinstance(net, dict) else net
+    if conv is not None:
+        c = conv[cfg.SEAR.FRCNN_CONV[0]]
+        if c is not dnet.az_net._conv:
+            dnet.az_net.set_conv(c)
+    scale = _im_scale(im.shape)[0]
+    assert num_classes == dnet.num_classes
+    scores, boxes = dnet.detect(np.ascontiguousarray(all_boxes[:, 0:4], dtype=np.float64), scale, im.shape,
+                                cfg.DEDUP_BOXES, cfg.SEAR.BATCH_SIZE, cfg.EPS)
+    return scores.astype(np.float64), boxes, conv
+
+
+def im_detect(net, im, boxes, num_classes):
+    """Object classes for given proposals (test.py:416-430); the conv map of `im` must already
+    be in the shared context (im_propose / set_conv)."""
+    scores, pred_boxes, _ = _frcnn_forward(net, im, boxes, num_classes)
+    return scores, pred_boxes
+
+
+def im_detect_shared(az_net, frcnn_net, im, num_classes):
+    """AZ-Net proposals + Fast R-CNN detection on shared convolutional layers (test.py:432-445)."""
+    boxes, conv = im_propose(az_net, im, return_conv=True)
+    scores, pred_boxes, _ = _frcnn_forward(frcnn_net, im, boxes, num_classes, conv)
+    return scores, pred_boxes
+
+
 def apply_nms(all_boxes, thresh):
     """Per-class, per-image NMS over detections (test.py:467-484)."""
     num_classes = len(all_boxes)
@@ -167,3 +197,63 @@ def test_proposals(net, imdb):
     print('On average, {0} boxes per image are generated'.format(num_boxes / num_images))
     print('The average proposal generation time is {:.3f}s'.format(_t['im_prop'].average_time))
     return prop_file
+
+
+def test_net_shared(sc_net, frcnn_net, imdb):
+    """Detection over an imdb with shared conv layers (test.py:670-778): per class keep scores
+    above an adaptive threshold, at most 100 per image and `800 / (K-1)` per image on average
+    over the set (min-heap), write detections.pkl, apply NMS (cfg.TEST.NMS) and hand the result to
+    imdb.evaluate_detections when the imdb has one."""
+    import heapq
+    num_images = len(imdb.image_index)
+    num_classes = imdb.num_classes
+    max_per_set = 800 // (num_classes - 1) * num_images          # Python-2 integer division (test.py:676)
+    max_per_image = 100
+    thresh = -np.inf * np.ones(num_classes)
+    top_scores = [[] for _ in range(num_classes)]
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    num_boxes = 0.0
+    hnet = sc_net["full"] if isinstance(sc_net, dict) else sc_net
+    output_dir = get_output_dir(imdb, hnet)
+    if not os.path.exists(output_dir):
+        os.makedirs(output_dir)
+    _t = {'im_detect': Timer(), 'misc': Timer()}
+    for i in range(num_images):
+        im = imdb.image_at(i) if hasattr(imdb, "image_at") else np.load(imdb.image_path_at(i))
+        _t['im_detect'].tic()
+        scores, boxes = im_detect_shared(sc_net, frcnn_net, im, num_classes)
+        num_boxes += scores.shape[0]
+        _t['im_detect'].toc()
+        _t['misc'].tic()
+        for j in range(1, num_classes):
+            inds = np.where((scores[:, j] > thresh[j]))[0]
+            cls_scores = scores[inds, j]
+            cls_boxes = boxes[inds, j * 4:(j + 1) * 4]
+            top_inds = np.argsort(-cls_scores)[:max_per_image]
+            cls_scores = cls_scores[top_inds]
+            cls_boxes = cls_boxes[top_inds, :]
+            for val in cls_scores:
+                heapq.heappush(top_scores[j], val)
+            if len(top_scores[j]) > max_per_set:
+                while len(top_scores[j]) > max_per_set:
+                    heapq.heappop(top_scores[j])
+                thresh[j] = top_scores[j][0]
+            all_boxes[j][i] = np.hstack((cls_boxes, cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+        _t['misc'].toc()
+        print('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(i + 1, num_images, _t['im_detect'].average_time,
+                                                          _t['misc'].average_time))
+    for j in range(1, num_classes):
+        for i in range(num_images):
+            inds = np.where(all_boxes[j][i][:, -1] > thresh[j])[0]
+            all_boxes[j][i] = all_boxes[j][i][inds, :]
+    det_file = os.path.join(output_dir, 'detections.pkl')
+    with open(det_file, 'wb') as f:
+        pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+    print('Applying NMS to all detections')
+    nms_dets = apply_nms(all_boxes, cfg.TEST.NMS)
+    if hasattr(imdb, "evaluate_detections"):
+        print('Evaluating detections')
+        imdb.evaluate_detections(nms_dets, output_dir)
+    print('The average detection time is {:.3f}s'.format(_t['im_detect'].average_time))
+    print('On average, {0} boxes per image are proposed'.format(num_boxes / num_images))
+    return nms_dets

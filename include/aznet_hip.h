@@ -151,6 +151,22 @@ int az_topk(az_ctx *ctx, const float *scores, int n, int k, int32_t *idx_out, in
  * (lib/detect/test.py:467-484); it is NOT on the proposal path. */
 int az_nms(az_ctx *ctx, const float *dets, int n, double thresh, int64_t *keep, int *n_keep);
 
+/* ---- Fast R-CNN head on the shared conv map (BASELINE config 3) ---------------------- */
+/* Replaces caffe.Net(frcnn/test_fc.prototxt, caffemodel) (tools/test_shared.py): the detection
+ * head models/Pascal/VGG16/frcnn/test_fc.prototxt:14-145 -- fc6 [n6, C*49], fc7 [n7, n6],
+ * cls_score [ncls, n7] (+Softmax), bbox_pred [4*ncls, n7]; Caffe [out, in] layout. */
+int az_load_det_head(az_ctx *ctx, int C, int n6, int n7, int ncls, const float *W6, const float *b6,
+                     const float *W7, const float *b7, const float *Wc, const float *bc,
+                     const float *Wb, const float *bb);
+/* frcnn_net['fc'].forward(rois=..., conv5_3=...) (lib/detect/test.py:302-307): cls_prob [R,ncls],
+ * bbox_pred [R,4*ncls], f32. */
+int az_det_forward(az_ctx *ctx, const float *rois, int R, float *cls_prob, float *bbox_pred);
+/* _frcnn_forward (lib/detect/test.py:259-318) for the proposals `boxes` [P,4] f64 of one image:
+ * roi projection + 1/16 dedup per batch_size chunk, head, _bbox_pred + _clip_boxes of every
+ * class, un-dedup.  scores_out [P,ncls] f32, boxes_out [P,4*ncls] f64. */
+int az_detect(az_ctx *ctx, const double *boxes, int P, double scale, double dedup, int batch_size,
+              int im_h, int im_w, double eps, float *scores_out, double *boxes_out);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /
  * az_head_forward.  mode bits: 1 = time only the fc GEMM launches, 2 = time every launch

@@ -416,3 +416,72 @@ def im_propose(net, im_shape, scale, cfg, data_blob=None, num_proposals=None,
         return Yout, {"levels": levels, "Y_all": Y, "aScores": aScores, "indA": indA,
                       "num_eval": num_eval, "depth": k, "conv": conv}
     return Yout
+
+
+# --------------------------------------------------------------------------
+# Fast R-CNN head on the shared map (BASELINE config 3).
+# --------------------------------------------------------------------------
+def softmax(x):
+    """Caffe Softmax over the channel axis in f32: subtract the max, exp, sum, divide."""
+    x = x.astype(np.float32, copy=False)
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    return (e / e.sum(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)
+
+
+def det_head_forward(head, feat, rois, pooled=7, spatial_scale=0.0625):
+    """models/Pascal/VGG16/frcnn/test_fc.prototxt:14-145 (PARITY UNPINNED, see module header):
+    roi_pool5 -> fc6+relu -> fc7+relu -> {cls_score -> Softmax = cls_prob, bbox_pred}."""
+    pool5 = roi_pool(feat, rois, pooled, spatial_scale)
+    h6 = fc(pool5, head["W6"], head["b6"], True)
+    h7 = fc(h6, head["W7"], head["b7"], True)
+    cls_prob = softmax(fc(h7, head["Wc"], head["bc"], False))
+    bbox = fc(h7, head["Wb"], head["bb"], False)
+    return cls_prob, bbox
+
+
+class OracleDetNet(object):
+    """pycaffe-shaped Fast R-CNN net for `_frcnn_forward` (test.py:289-307)."""
+
+    def __init__(self, head, name="oracle_det"):
+        self.head = head
+        self.name = name
+        self.blobs = {k: OracleNet._Blob() for k in ("data", "rois", "conv5_3")}
+
+    def forward(self, blobs=None, **kw):
+        p, b = det_head_forward(self.head, kw["conv5_3"][0], kw["rois"])
+        return {"cls_prob": p, "bbox_pred": b}
+
+
+def frcnn_forward(net, im_shape, scale, all_boxes, num_classes, conv, cfg):
+    """test.py:259-318 with a cached conv (the shared path always has one)."""
+    batch = cfg.BATCH_SIZE
+    num_batches = int(np.ceil(all_boxes.shape[0] / float(batch)))
+    all_pred_boxes = np.zeros((0, 4 * num_classes))
+    all_scores = np.zeros((0, num_classes))
+    for bid in range(num_batches):
+        start = batch * bid
+        end = min(all_boxes.shape[0], batch * (bid + 1))
+        boxes = all_boxes[start:end, 0:4]
+        rois = get_rois_blob(boxes, scale)
+        index, inv_index = roi_dedup(rois, cfg.DEDUP_BOXES)
+        rois = rois[index, :]
+        boxes = boxes[index, :]
+        net["fc"].blobs["conv5_3"].reshape(*conv["conv5_3"].shape)
+        net["fc"].blobs["rois"].reshape(*rois.shape)
+        out = net["fc"].forward(rois=rois.astype(np.float32, copy=False), **conv)
+        pred_scores = out["cls_prob"]
+        box_deltas = out["bbox_pred"]
+        pred_boxes = bbox_pred(boxes, box_deltas, cfg.EPS)
+        pred_boxes = clip_boxes(pred_boxes, im_shape)
+        pred_scores = pred_scores[inv_index, :]
+        pred_boxes = pred_boxes[inv_index, :]
+        all_scores = np.vstack((all_scores, pred_scores))
+        all_pred_boxes = np.vstack((all_pred_boxes, pred_boxes))
+    return all_scores, all_pred_boxes
+
+
+def im_detect_shared(az_net, frcnn_net, im_shape, scale, num_classes, cfg):
+    """test.py:432-445."""
+    boxes, tr = im_propose(az_net, im_shape, scale, cfg, return_trace=True)
+    scores, pred_boxes = frcnn_forward(frcnn_net, im_shape, scale, boxes, num_classes, tr["conv"], cfg)
+    return scores, pred_boxes, boxes

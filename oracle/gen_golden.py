@@ -302,6 +302,47 @@ def main():
                   "Y", Y.shape)
         C.cfg.TEST.MAX_SIZE = 1000
         C.cfg.SEAR.BATCH_SIZE = 10000
+
+        # ---------------- G9 im_detect_shared / _frcnn_forward (config 3) --------------------------
+        class RecDet(orc.OracleDetNet):
+            def __init__(self, *a, **kw):
+                orc.OracleDetNet.__init__(self, *a, **kw)
+                self.rec = []
+
+            def forward(self, blobs=None, **kw):
+                out = orc.OracleDetNet.forward(self, blobs=blobs, **kw)
+                self.rec.append({"rois": kw["rois"].copy(), "cls_prob": out["cls_prob"].copy(),
+                                 "bbox_pred": out["bbox_pred"].copy()})
+                return out
+
+        dhead = synth.make_det_head(seed=99, **synth.SMALL_DET_DIMS)
+        for tag, H, W, tzv, batch in (("a", 375, 500, 0.6, 10000), ("b", 600, 1000, 0.0, 100)):
+            C.cfg.SEAR.BATCH_SIZE = batch
+            C.cfg_set_mode("Test", tzv)
+            im = synth.make_image(4, H, W)
+            scale = 600.0 / min(H, W)
+            if np.round(scale * max(H, W)) > 1000:
+                scale = 1000.0 / max(H, W)
+            fmap = synth.make_feature_map(8, synth.SMALL_DIMS["C"], synth.conv_out_size(int(round(H * scale))),
+                                          synth.conv_out_size(int(round(W * scale))))
+            full = RecordingNet(head, feat_fn=lambda data: fmap)
+            fcn = RecordingNet(head)
+            det = RecDet(dhead)
+            scores, pboxes = T.im_detect_shared({"full": full, "fc": fcn}, {"fc": det}, im, 21)
+            g = {"H": np.array(H), "W": np.array(W), "Tz": np.array(tzv), "batch": np.array(batch),
+                 "scale": np.array(scale), "scores": scores, "pred_boxes": pboxes,
+                 "ndet": np.array(len(det.rec)), "fmap_seed": np.array(8)}
+            # the proposals fed to the detector = union of the recorded det rois is not enough (dedup);
+            # re-run the proposal step alone to record them
+            full2 = RecordingNet(head, feat_fn=lambda data: fmap)
+            fcn2 = RecordingNet(head)
+            g["proposals"] = T.im_propose({"full": full2, "fc": fcn2}, im)
+            for i, r in enumerate(det.rec):
+                for k in ("rois", "cls_prob", "bbox_pred"):
+                    g["d%d_%s" % (i, k)] = r[k]
+            np.savez_compressed(os.path.join(GOLD, "g9_detect_%s.npz" % tag), **g)
+            print("detect", tag, scores.shape, pboxes.shape, "det calls", [r["rois"].shape[0] for r in det.rec])
+        C.cfg.SEAR.BATCH_SIZE = 10000
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     print("golden fixtures written to", GOLD)

@@ -58,3 +58,22 @@ def replay_nets(g):
 
 
 TRACES = ["a", "b", "c", "d", "e", "f"]
+
+
+class ReplayDetNet(object):
+    """Replays the Fast R-CNN head outputs recorded during the REFERENCE's im_detect_shared run
+    (tests/golden/g9_detect_*.npz), asserting it is fed the same rois."""
+
+    def __init__(self, g, name="replay_det"):
+        self.g = g
+        self.name = name
+        self.blobs = {k: _Blob() for k in ("data", "rois", "conv5_3")}
+        self.pos = 0
+
+    def forward(self, blobs=None, **kw):
+        i = self.pos
+        self.pos += 1
+        ref = self.g["d%d_rois" % i]
+        rois = kw["rois"]
+        assert rois.dtype == np.float32 and rois.shape == ref.shape and np.array_equal(rois, ref)
+        return {"cls_prob": self.g["d%d_cls_prob" % i], "bbox_pred": self.g["d%d_bbox_pred" % i]}

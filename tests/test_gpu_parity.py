@@ -354,3 +354,84 @@ def test_full_size_fused_loop(full, mods):
     zr, pr, dr = orc.head_forward(head, fmap[0], rois[idx][:16])
     np.testing.assert_allclose(z[:16], zr, rtol=0, atol=1e-4)
     np.testing.assert_allclose(p[:16], pr, rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------- Fast R-CNN head (config 3)
+@pytest.fixture(scope="module")
+def det_small(small, mods):
+    ffi, synth, HipAZNet, orc = mods
+    from aznet_hip.net import HipDetNet
+    net, head = small
+    dhead = synth.make_det_head(seed=99, **synth.SMALL_DET_DIMS)
+    return HipDetNet(dhead, net), dhead
+
+
+@pytest.mark.parametrize("R", [1, 40, 300])
+def test_det_head_forward(det_small, small, mods, R):
+    ffi, synth, HipAZNet, orc = mods
+    dnet, dhead = det_small
+    net, head = small
+    fmap = synth.make_feature_map(8, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(R + 5), R, 1000, 600)
+    p, b = net.ctx.det_forward(rois)
+    pr, br = orc.det_head_forward(dhead, fmap[0], rois)
+    np.testing.assert_allclose(p, pr, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(b, br, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(p.sum(1), 1.0, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_detect_vs_oracle_loop(det_small, small, mods, tag):
+    """az_detect (dedup + head + per-class decode + un-dedup in one call) against the oracle's
+    _frcnn_forward driven by the HIP detection head through the pycaffe-shaped seam, on the
+    proposals of the reference's own run."""
+    ffi, synth, HipAZNet, orc = mods
+    dnet, dhead = det_small
+    net, head = small
+    g = load("g9_detect_%s.npz" % tag)
+    H, W, scale, batch = int(g["H"]), int(g["W"]), float(g["scale"]), int(g["batch"])
+    fmap = synth.make_feature_map(8, synth.SMALL_DIMS["C"], synth.conv_out_size(int(round(H * scale))),
+                                  synth.conv_out_size(int(round(W * scale))))
+    net.set_conv(fmap)
+    props = g["proposals"]
+    s, b = net.ctx.detect(props, scale, H, W, batch_size=batch)
+    cfg = orc.OracleCfg(BATCH_SIZE=batch)
+
+    class Inj(object):
+        blobs = dnet.blobs
+
+        def forward(self, blobs=None, **kw):
+            kw["conv5_3"] = fmap
+            return dnet.forward(blobs=blobs, **kw)
+
+    sr, br = orc.frcnn_forward({"fc": Inj()}, (H, W), scale, props, 21, {"conv5_3": fmap}, cfg)
+    assert s.shape == (props.shape[0], 21) and b.shape == (props.shape[0], 84)
+    assert np.array_equal(s.astype(np.float64), sr)                 # same head, same bits
+    np.testing.assert_allclose(b, br, rtol=0, atol=1e-4)              # decode: f32-exp ulps, px
+    # and against the recorded CPU run of the reference (BLAS head): within tolerance
+    np.testing.assert_allclose(s, g["scores"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(b, g["pred_boxes"], rtol=1e-4, atol=1e-3)
+
+
+def test_im_detect_shared_and_apply_nms(det_small, small, mods):
+    """Host API of config 3: im_detect_shared -> per-class boxes, apply_nms through az_nms."""
+    ffi, synth, HipAZNet, orc = mods
+    from detect import test as T
+    from detect.config import cfg, cfg_set_mode
+    dnet, dhead = det_small
+    net, head = small
+    cfg_set_mode("Test", 0.0)
+    fmap = synth.make_feature_map(8, synth.SMALL_DIMS["C"], 38, 63)
+    im = synth.make_image(4, 600, 1000)
+    boxes = T.im_propose(net, im, conv={"conv5_3": fmap})
+    scores, pred = T.im_detect(dnet, im, boxes, 21)
+    assert scores.shape == (300, 21) and pred.shape == (300, 84) and scores.dtype == np.float64
+    all_boxes = [[[]] for _ in range(21)]
+    for j in range(1, 21):
+        top = np.argsort(-scores[:, j])[:100]
+        all_boxes[j][0] = np.hstack((pred[top, 4 * j:4 * j + 4], scores[top, j:j + 1])).astype(np.float32)
+    nmsd = T.apply_nms(all_boxes, 0.5)
+    for j in range(1, 21):
+        ref = orc.nms(all_boxes[j][0], 0.5)
+        assert np.array_equal(nmsd[j][0], all_boxes[j][0][ref])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import az_oracle as orc
-from helpers import load, unpack_list, replay_nets, TRACES
+from helpers import load, unpack_list, replay_nets, TRACES, ReplayDetNet
 
 
 def test_divide_region_roots_bit_exact():
@@ -121,3 +121,27 @@ def test_fc_blas_vs_plain():
 def test_num_levels():
     assert orc.num_levels(600, 1000) == 6 and orc.num_levels(375, 500) == 6
     assert orc.num_levels(640, 853) == 7 and orc.num_levels(800, 1200) == 7
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_frcnn_forward_against_reference_trace(tag):
+    """_frcnn_forward (test.py:259-318): the oracle, fed the detection-head outputs recorded in
+    the reference's own run, must send the head the same deduplicated rois (per BATCH_SIZE chunk)
+    and return the reference's scores and per-class boxes."""
+    g = load("g9_detect_%s.npz" % tag)
+    cfg = orc.OracleCfg(Tz=float(g["Tz"]), BATCH_SIZE=int(g["batch"]))
+    det = ReplayDetNet(g)
+    conv = {"conv5_3": np.zeros((1, 1, 1, 1), dtype=np.float32)}
+    scores, boxes = orc.frcnn_forward({"fc": det}, (int(g["H"]), int(g["W"])), float(g["scale"]),
+                                      g["proposals"], 21, conv, cfg)
+    assert det.pos == int(g["ndet"])
+    assert np.array_equal(scores, g["scores"])
+    np.testing.assert_allclose(boxes, g["pred_boxes"], rtol=0, atol=1e-6)
+
+
+def test_softmax_matches_definition():
+    x = np.random.RandomState(0).randn(7, 21).astype(np.float32) * 5
+    p = orc.softmax(x)
+    assert p.dtype == np.float32 and np.allclose(p.sum(1), 1, atol=1e-6)
+    ref = np.exp(x.astype(np.float64) - x.max(1, keepdims=True))
+    np.testing.assert_allclose(p, ref / ref.sum(1, keepdims=True), rtol=1e-5, atol=1e-7)
