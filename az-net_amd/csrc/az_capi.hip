@@ -22,6 +22,10 @@ struct az_ctx {
     bool head_loaded = false, launched = false;
     AzHeadDims d{};
     int S6 = 1, S7 = 1;
+    // int6 on the bf16 matrix cores for launches of > 64 rows: 0 = off (fp32 MFMA everywhere),
+    // 2 = two bf16 terms / 3 MFMAs per product (~2^-16), 3 = three terms / 6 MFMAs (fp32-grade)
+    int gemm_parts = 0;
+    unsigned short *W6p = nullptr, *pool5p = nullptr;
     float spatial_scale = 0.0625f;                 // test_fc.prototxt:22
     // weights (HBM)
     float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
@@ -200,9 +204,14 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
-      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5); }
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
+                   (size_t)c->maxR * d.K6, c->gemm_parts, 0); }
     { Timed t(c, "fc6_gemm", level, 1);
-      azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part); }
+      if (c->gemm_parts)
+          azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
+                           c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part);
+      else
+          azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part); }
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
     { Timed t(c, "fc7_gemm", level, 1);
@@ -289,6 +298,14 @@ int az_set_limits(az_ctx *c, int max_regions, int max_candidates)
     return AZ_OK;
 }
 
+int az_set_gemm_mode(az_ctx *c, int parts)
+{
+    if (!c || !(parts == 0 || parts == 2)) return fail(c, AZ_ERR_INVALID, "az_set_gemm_mode: 0 or 2");
+    if (c->head_loaded) return fail(c, AZ_ERR_STATE, "az_set_gemm_mode must precede az_load_head");
+    c->gemm_parts = parts;
+    return AZ_OK;
+}
+
 int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, const float *b6,
                  const float *W71, const float *b71, const float *W72, const float *b72, const float *Was,
                  const float *bas, const float *Wab, const float *bab, const float *Wz, const float *bz)
@@ -325,6 +342,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         A(part, pm > pw ? pm : pw);
     }
     A(h6, R * n6); A(h7, R * d.n7);
+    if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * n6 * d.K6); A(pool5p, (size_t)c->gemm_parts * R * d.K6); }
 #undef A
     // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
     // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
@@ -332,6 +350,10 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipMemcpy(c->part, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
     azk_permute_k(c->stream, c->part, c->W6, n6, C, 1);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->gemm_parts) {          // bf16 round-off planes of the (permuted) int6 weights
+        azk_split_planes(c->stream, c->W6, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     HIPCHK(c, hipMemcpy(c->b6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
     // int7_1 and int7_2 both read int6: one GEMM with the two weight blocks stacked along N.
     HIPCHK(c, hipMemcpy(c->W7, W71, (size_t)n71 * n6 * 4, hipMemcpyHostToDevice));
@@ -693,7 +715,8 @@ int az_roi_pool(az_ctx *c, const float *rois, int R, float *out)
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!out) return fail(c, AZ_ERR_INVALID, "az_roi_pool: null output");
-    azk_roi_pool(c->stream, c->feat, c->d, c->spatial_scale, c->urois, &c->cnt->U[0], c->maxR, c->pool5);
+    azk_roi_pool(c->stream, c->feat, c->d, c->spatial_scale, c->urois, &c->cnt->U[0], c->maxR, c->pool5, nullptr, 0, 0,
+                 0);
     // the ABI returns Caffe's [R, C, 7, 7] flattening; HBM holds [R, 49, C]
     if (R) azk_permute_k(c->stream, c->pool5, c->part, R, c->d.C, 0);
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -864,7 +887,7 @@ static void launch_det_head(az_ctx *c, const int *Uptr, int im_h, int im_w, doub
     const int K6 = d.C * 49, NO = 5 * c->det_ncls;
     d.K6 = K6;
     { Timed t(c, "det_roi_pool", 0);
-      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5); }
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, nullptr, 0, 0, 0); }
     { Timed t(c, "det_fc6_gemm", 0, 1);
       azk_fc_gemm(c->stream, c->pool5, K6, c->dW6, K6, Uptr, c->maxR, c->det_n6, K6, c->det_S6, c->dpart); }
     { Timed t(c, "det_fc6_reduce", 0);

@@ -111,15 +111,26 @@ void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 // feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
 // pool5 comes out bin-major: [roi][ph*7+pw][c]
+// With parts > 0, launches of >= min_strips 32-row strips write bf16 round-off planes
+// (planes[q * plane_stride + ...]) instead of fp32 pool5, for the split-bf16 GEMM.
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
-                  const float *urois, const int *Uptr, int capU, float *pool5);
+                  const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
+                  size_t plane_stride, int parts, int min_strips);
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
 // rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);
 // y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip):
 // _gemm writes the S partial slabs part[s][m][n], _reduce adds them in order + bias (+ReLU).
+// (launches with more than max_strips 32-row strips are skipped: another kernel owns them)
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
-                 int N, int K, int S, float *part);
+                 int N, int K, int S, float *part, int max_strips = 1 << 30);
+int azk_fc_chunk(int K, int S);
+int azk_gemm_grid();
+// split-bf16 GEMM (az_head_bf16.hip): operands as `parts` bf16 round-off planes
+void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long long n, long long plane_stride,
+                      int parts);
+int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
+                     int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu);
 // adj_score + adj_bbox + zoom_score are one more azk_fc_gemm over Wt [56, n71+n72] (zero-padded

@@ -62,10 +62,14 @@ __global__ void k_permute_k(const float *__restrict__ in, float *__restrict__ ou
 
 __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat, AzHeadDims d,
                                                   float spatial_scale, const float *__restrict__ urois,
-                                                  const int *Uptr, float *__restrict__ pool5)
+                                                  const int *Uptr, float *__restrict__ pool5,
+                                                  unsigned short *__restrict__ planes, size_t plane_stride,
+                                                  int parts, int min_strips)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     const int U = *Uptr;
+    // launches that the split-bf16 GEMM will consume get their bf16 terms written here directly
+    const bool to_planes = parts > 0 && ((U + 31) >> 5) >= min_strips;
     const int lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < U * PP; item += nwaves) {
@@ -105,7 +109,20 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (cb + 64 * j + lane < d.C) out[cb + 64 * j + lane] = m[j];
+                if (cb + 64 * j + lane < d.C) {
+                    if (!to_planes) {
+                        out[cb + 64 * j + lane] = m[j];
+                    } else {
+                        float x = m[j];
+                        unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane;
+                        for (int q = 0; q < parts; ++q) {
+                            unsigned b = __float_as_uint(x);
+                            b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
+                            po[q * plane_stride] = (unsigned short)(b >> 16);
+                            x -= __uint_as_float(b & 0xFFFF0000u);
+                        }
+                    }
+                }
         }
     }
 }
@@ -377,7 +394,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 
 __global__ void __launch_bounds__(256, 2)
 k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
-            const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part)
+            const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part, int max_strips)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
@@ -385,6 +402,7 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     const int M = *Mptr;
     if (M <= 0) return;
     const int strips = (M + 31) >> 5;
+    if (strips > max_strips) return;            // larger launches of this layer run on the split-bf16 kernel
     const int mt = (strips + 3) >> 2;
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
@@ -558,10 +576,12 @@ __global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int n
 
 // --------------------------------------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
-                  const int *Uptr, int capU, float *pool5)
+                  const int *Uptr, int capU, float *pool5, unsigned short *planes, size_t plane_stride, int parts,
+                  int min_strips)
 {
     (void)capU;
-    hipLaunchKernelGGL(k_roi_pool, dim3(1024), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5);
+    hipLaunchKernelGGL(k_roi_pool, dim3(1024), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
+                       planes, plane_stride, parts, min_strips);
 }
 
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)
@@ -591,11 +611,14 @@ static int fc_chunk(int K, int S)
 }
 
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
-                 int N, int K, int S, float *part)
+                 int N, int K, int S, float *part, int max_strips)
 {
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
-                       fc_chunk(K, S), part);
+                       fc_chunk(K, S), part, max_strips);
 }
+
+int azk_fc_chunk(int K, int S) { return fc_chunk(K, S); }
+int azk_gemm_grid() { return gemm_grid(); }
 
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu)

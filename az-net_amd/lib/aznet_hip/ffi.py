@@ -27,6 +27,7 @@ SYMBOLS = [
     "az_propose_fetch", "az_last_candidates", "az_divide_region", "az_sift_dup", "az_roi_dedup",
     "az_roi_pool", "az_head_forward", "az_decode_filter", "az_topk", "az_nms", "az_set_profiling",
     "az_last_kernel_times", "az_stream", "az_load_det_head", "az_det_forward", "az_detect",
+    "az_set_gemm_mode",
 ]
 
 
@@ -79,6 +80,7 @@ def load_library(path=None):
     L.az_last_error.restype = ctypes.c_char_p
     L.az_last_error.argtypes = [vp]
     L.az_set_limits.argtypes = [vp, ci, ci]
+    L.az_set_gemm_mode.argtypes = [vp, ci]
     L.az_load_head.argtypes = [vp, ci, ci, ci, ci] + [fp] * 12
     L.az_set_feature_map_dev.argtypes = [vp, vp, ci, ci, ci]
     L.az_set_feature_map_host.argtypes = [vp, fp, ci, ci, ci]
@@ -124,7 +126,10 @@ def _p(a, ct):
 class AzContext(object):
     """One GPU's search context (az_ctx).  Not thread-safe; one per process/GPU."""
 
-    def __init__(self, device=0, max_regions=None, max_candidates=None):
+    def __init__(self, device=0, max_regions=None, max_candidates=None, gemm_mode=None):
+        """gemm_mode: 0 fp32 MFMA (default), 3 / 2 = int6 on the bf16 matrix cores with fp32 operands
+        split into 3 / 2 bf16 terms for launches of > 64 rois (az_set_gemm_mode); None reads the
+        AZ_GEMM_MODE environment variable."""
         self.L = load_library()
         h = ctypes.c_void_p()
         rc = self.L.az_create(int(device), ctypes.byref(h))
@@ -139,6 +144,11 @@ class AzContext(object):
         if max_regions is not None:
             self._chk(self.L.az_set_limits(self.h, int(max_regions),
                                            int(max_candidates or max_regions * AZ_NUM_SUBREG)))
+        if gemm_mode is None:
+            gemm_mode = int(os.environ.get("AZ_GEMM_MODE", "0"))
+        self.gemm_mode = int(gemm_mode)
+        if self.gemm_mode:
+            self._chk(self.L.az_set_gemm_mode(self.h, self.gemm_mode))
         self.max_regions = max_regions or 16384
         self.max_candidates = max_candidates or self.max_regions * AZ_NUM_SUBREG
 

@@ -26,8 +26,8 @@ class _Blob(object):
 
 class HipAZNet(object):
     def __init__(self, head, backbone=None, device=0, name="vgg16_az_net_hip", ctx=None,
-                 max_regions=None):
-        self.ctx = ctx or ffi.AzContext(device, max_regions=max_regions)
+                 max_regions=None, gemm_mode=None):
+        self.ctx = ctx or ffi.AzContext(device, max_regions=max_regions, gemm_mode=gemm_mode)
         self.ctx.load_head(head)
         self.backbone = backbone
         self.name = name

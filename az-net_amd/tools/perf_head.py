@@ -16,7 +16,7 @@ def main():
     Rs = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 8, 32, 64, 130, 517, 1024, 2048]
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    net = HipAZNet(head, max_regions=4096)
+    net = HipAZNet(head, max_regions=4096)          # AZ_GEMM_MODE=0|2|3 selects the int6 kernel
     fmap = synth.make_feature_map(4, 512, 38, 63)
     net.set_conv(fmap)
     rng = np.random.RandomState(0)
@@ -37,7 +37,7 @@ def main():
         tf = R * flop6 / (med["fc6_gemm"] * 1e-6) / 1e12
         bw = 411041792 / (med["fc6_gemm"] * 1e-6) / 1e12
         print("R=%5d  " % R + "  ".join("%s %7.1f" % (k, med[k]) for k in
-              ("roi_pool", "fc6_gemm", "fc6_reduce", "fc7_gemm", "fc7_reduce", "head_tail")) +
+              ("roi_pool", "fc6_gemm", "fc6_reduce", "fc7_gemm", "fc7_reduce", "tail_gemm", "tail_epilogue")) +
               "  | fc6 %.1f TF/s  W-stream %.2f TB/s" % (tf, bw))
 
 

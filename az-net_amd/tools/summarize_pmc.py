@@ -28,7 +28,7 @@ def main():
     with open(out, "w") as o:
         o.write("kernel,launches,avg_us," + ",".join("avg_" + c for c in counters) + "\n")
         for k in sorted(agg, key=lambda k: -sum(dur[k])):
-            if not k.startswith("k_"):
+            if not (k.startswith("k_") or k.startswith("void k_")):
                 continue
             n = max(len(v) for v in agg[k].values())
             o.write("%s,%d,%.2f," % (k, n, sum(dur[k]) / len(dur[k])) +

@@ -87,6 +87,7 @@ def main():
                     help="images in flight per GPU in the timed region (each on its own az_ctx/stream); "
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 2-images-in-flight measurement")
+    ap.add_argument("--no-fast", action="store_true", help="skip the extra split-bf16 (gemm_mode 2) measurement")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
     args = ap.parse_args()
 
@@ -253,6 +254,50 @@ def main():
                                 "note": "independent images overlapped on two az_ctx/streams: the latency-bound "
                                         "geometry kernels of one image hide under the other's GEMMs"}
         del nets2[1]
+    # ---- opt-in fast mode: int6 on the bf16 matrix cores, fp32 operands split in two bf16 terms ----
+    if not args.no_fast and ffi.AzContext.make_params and net.ctx.gemm_mode == 0:
+        nf = [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=2)
+              for _ in range(2)]
+        for n in nf:
+            n.set_conv(conv)
+        n_f = max(20, args.steps // 2)
+        for _ in range(10):
+            nf[0].propose(params)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_f):
+            nf[0].propose(params)
+        barrier()
+        d1 = time.perf_counter() - t0
+
+        def runf(k):
+            q = []
+            for i in range(k):
+                n = nf[i % 2]
+                if len(q) == 2:
+                    q.pop(0).ctx.propose_fetch()
+                n.ctx.propose_launch(params)
+                q.append(n)
+            for m in q:
+                m.ctx.propose_fetch()
+        runf(10)
+        barrier()
+        t0 = time.perf_counter()
+        runf(n_f)
+        barrier()
+        d2 = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d1, d2], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d1, d2 = float(tt[0].item()), float(tt[1].item())
+        if rank == 0:
+            out["split_bf16_mode"] = {
+                "value": world * NUM_PROPOSALS * n_f / d1, "unit": "proposals/s", "ms_per_image": d1 / n_f * 1e3,
+                "pipelined_value": world * NUM_PROPOSALS * n_f / d2, "pipelined_ms_per_image": d2 / n_f * 1e3,
+                "dtype": "bf16x3 (az_set_gemm_mode 2: int6 operands as two bf16 terms, 3 bf16 MFMAs per "
+                         "product, fp32 accumulate)",
+                "note": "opt-in; scores / box deltas stay within 1e-5 of the fp32 path (tolerance 1e-4)"}
+        del nf
     # ---- backbone + hot path, for context (not `value`) -----------------------------------
     if not args.no_e2e:
         for _ in range(3):

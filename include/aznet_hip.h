@@ -82,6 +82,15 @@ const char *az_last_error(const az_ctx *ctx);
  * candidate capacity (default 16384*11).  Buffers are sized once, for 288 GB of HBM. */
 int az_set_limits(az_ctx *ctx, int max_regions, int max_candidates);
 
+/* Optional, before az_load_head.  How int6 (95 % of the head's FLOPs) is evaluated for launches of
+ * more than 64 rois:
+ *   0 (default)  fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain;
+ *   3            fp32 operands split into three bf16 round-off terms, six bf16 MFMAs per product
+ *                with fp32 accumulation: products good to 2^-24 (fp32-grade), 6/16 of the cost;
+ *   2            two terms, three MFMAs: products good to ~2^-16 (outputs still within 1e-4), 3/16.
+ * Launches of <= 64 rois are weight-streaming bound and always use the fp32 kernel. */
+int az_set_gemm_mode(az_ctx *ctx, int parts);
+
 /* Replaces caffe.Net(test_fc.prototxt, caffemodel) (tools/prop_az.py:95-96): the AZ head
  * models/Pascal/VGG16/az-net/test_fc.prototxt:14-232.  Weights are Caffe InnerProduct
  * blobs, row-major [out, in]; they are copied (and re-tiled) into HBM.

@@ -97,7 +97,7 @@ def test_decode_filter_golden(small):
     g = load("g4_decode.npz")
     b, s = ctx.decode_filter(g["boxes"], g["deltas"], g["scores"], 600, 1000)
     assert b.shape == g["unwrap_boxes"].shape            # same candidates survive the filter
-    np.testing.assert_allclose(b, g["unwrap_boxes"], rtol=0, atol=1e-4)      # px; f32-exp ulps x box size
+    np.testing.assert_allclose(b, g["unwrap_boxes"], rtol=1e-6, atol=1e-4)   # px; f32-exp ulps x box size
     assert np.array_equal(s, g["unwrap_scores"])
 
 
@@ -255,7 +255,7 @@ def test_fused_loop_equals_per_level_loop(small, mods, H, W, tzq, batch):
     Yall, Sall = net.ctx.last_candidates()
     assert Yall.shape == tr["Y_all"].shape
     assert np.array_equal(Sall.astype(np.float64), tr["aScores"])          # scores: same bits
-    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=0, atol=1e-4)       # decode: f32-exp ulps, px
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-6, atol=1e-4)    # decode: f32-exp ulps (px)
     # selection: identical candidate indices in identical order (stable ties)
     ref_idx = np.argsort(-tr["aScores"], kind="stable")[:300]
     assert Y.shape == (min(300, Yall.shape[0]), 4)
@@ -279,12 +279,14 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
     Yall, Sall = net.ctx.last_candidates()
     assert Yall.shape == tr["Y_all"].shape
     np.testing.assert_allclose(Sall, tr["aScores"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=1e-3)
+    # px: fp32 head <= 1e-3; the split-bf16 int6 path (gemm_mode 2) keeps deltas within 1e-5, which a
+    # 1700-px-wide unclipped box turns into <= 2e-2 px
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2 if net.ctx.gemm_mode else 1e-3)
     # top-300 sets agree except where scores tie within the tolerance
     kth = np.sort(tr["aScores"])[::-1][299]
     sure = tr["aScores"] > kth + 2e-4
     for b in tr["Y_all"][sure]:
-        assert np.abs(Y - b).max(axis=1).min() < 1e-3
+        assert np.abs(Y - b).max(axis=1).min() < (3e-2 if net.ctx.gemm_mode else 1e-3)
 
 
 @pytest.mark.parametrize("H,W,tz", [(600, 1000, 0.0), (375, 500, 0.6), (640, 853, 0.55), (200, 90, 0.0),
@@ -408,7 +410,7 @@ def test_detect_vs_oracle_loop(det_small, small, mods, tag):
     sr, br = orc.frcnn_forward({"fc": Inj()}, (H, W), scale, props, 21, {"conv5_3": fmap}, cfg)
     assert s.shape == (props.shape[0], 21) and b.shape == (props.shape[0], 84)
     assert np.array_equal(s.astype(np.float64), sr)                 # same head, same bits
-    np.testing.assert_allclose(b, br, rtol=0, atol=1e-4)              # decode: f32-exp ulps, px
+    np.testing.assert_allclose(b, br, rtol=1e-6, atol=1e-4)           # decode: f32-exp ulps, px
     # and against the recorded CPU run of the reference (BLAS head): within tolerance
     np.testing.assert_allclose(s, g["scores"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(b, g["pred_boxes"], rtol=1e-4, atol=1e-3)
@@ -435,3 +437,36 @@ def test_im_detect_shared_and_apply_nms(det_small, small, mods):
     for j in range(1, 21):
         ref = orc.nms(all_boxes[j][0], 0.5)
         assert np.array_equal(nmsd[j][0], all_boxes[j][0][ref])
+
+
+# ---------------------------------------------------------------- split-bf16 int6 (gemm_mode 2)
+def test_split_bf16_mode_accuracy_and_row_independence(mods):
+    """az_set_gemm_mode(2): int6 on the bf16 matrix cores with fp32 operands split into two bf16
+    terms.  Outputs stay within 1e-4 of the fp32 path and of the BLAS oracle (measured ~1e-5),
+    and a roi's bits do not depend on the batch (both tile shapes use the same per-row arithmetic)."""
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    fmap = synth.make_feature_map(3, synth.SMALL_DIMS["C"], 38, 63)
+    rois = _rand_rois(np.random.RandomState(11), 300, 1000, 600)
+    ref = orc.head_forward(head, fmap[0], rois)
+    nets = {m: HipAZNet(head, name="m%d" % m, max_regions=1024, gemm_mode=m) for m in (0, 2)}
+    out = {}
+    for m, net in nets.items():
+        net.set_conv(fmap)
+        out[m] = net.ctx.head_forward(rois)
+    for a, b, r in zip(out[2], out[0], ref):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-4)
+    for n in (1, 40, 64, 65, 130):          # 1-2 strips: 4-wave shape; >= 3 strips: 8-wave shape
+        sub = nets[2].ctx.head_forward(rois[:n])
+        for a, b in zip(sub, out[2]):
+            assert np.array_equal(a, b[:n])
+    # whole search in mode 2 vs mode 0: same tree, scores within 1e-4
+    p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0)
+    res = {m: nets[m].propose(p, want_scores=True, want_stats=True) for m in (0, 2)}
+    assert list(res[0][2].level_unique[:5]) == list(res[2][2].level_unique[:5])
+    c0, c2 = nets[0].ctx.last_candidates(), nets[2].ctx.last_candidates()
+    assert c0[0].shape == c2[0].shape
+    np.testing.assert_allclose(c2[1], c0[1], rtol=0, atol=1e-4)
+    with pytest.raises(ffi.AzError):
+        ffi.AzContext(0, gemm_mode=5)
