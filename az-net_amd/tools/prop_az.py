@@ -2,9 +2,9 @@
 """Use AZ-Net to generate object proposals on an image database -- the MI355X counterpart of
 the reference's tools/prop_az.py (same flags, same thresh.pkl input, same proposals.pkl
 output).  Differences forced by what exists offline:
-  --net   a .npz with Caffe-layout arrays (head: W6,b6,W71,b71,W72,b72,Was,bas,Wab,bab,Wz,bz;
-          optional backbone: conv1_1_w/conv1_1_b ...), or `synthetic[:seed]`.  A .caffemodel
-          reader is a listed next step.
+  --net   a .caffemodel (read with aznet_hip.caffemodel, no Caffe needed), an .npz with Caffe-layout
+          arrays (head: W6,b6,W71,b71,W72,b72,Was,bas,Wab,bab,Wz,bz; optional backbone:
+          conv1_1_w/conv1_1_b ...), or `synthetic[:seed]`.
   --def / --def_fc  accepted for command-line compatibility; the layer graph is fixed
           (models/Pascal/VGG16/az-net/test.prototxt, test_fc.prototxt).
   --imdb  `synthetic_<H>x<W>_<N>` or `npy:<dir>`.
@@ -56,6 +56,12 @@ def load_net(spec, device):
         backbone = VGG16Conv5(device='cuda:%d' % device, seed=seed + 1)
         backbone.normalize_output(np.zeros((1, 3, 600, 1000), dtype=np.float32) + 1.0)
         name = 'vgg16_az_net_synthetic_%d' % seed
+    elif spec.endswith('.caffemodel'):
+        from aznet_hip import caffemodel as cm
+        layers = cm.load_caffemodel(spec)
+        head = cm.az_head_from_layers(layers)
+        backbone = VGG16Conv5(device='cuda:%d' % device, weights=cm.backbone_from_layers(layers))
+        name = os.path.splitext(os.path.basename(spec))[0]
     else:
         z = np.load(spec)
         head = {k: z[k] for k in ("W6", "b6", "W71", "b71", "W72", "b72", "Was", "bas", "Wab", "bab", "Wz", "bz")}

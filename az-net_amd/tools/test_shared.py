@@ -45,6 +45,9 @@ def load_det_head(spec):
     if spec.startswith('synthetic'):
         seed = int(spec.split(':')[1]) if ':' in spec else 4242
         return synth.make_det_head(seed=seed, **synth.FULL_DET_DIMS), 'vgg16_frcnn_synthetic_%d' % seed
+    if spec.endswith('.caffemodel'):
+        from aznet_hip import caffemodel as cm
+        return cm.det_head_from_layers(cm.load_caffemodel(spec)), os.path.splitext(os.path.basename(spec))[0]
     z = np.load(spec)
     return ({k: z[k] for k in ("W6", "b6", "W7", "b7", "Wc", "bc", "Wb", "bb")},
             os.path.splitext(os.path.basename(spec))[0])
