@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Accuracy of the split-bf16 int6 path (gemm_mode 2) vs the fp32-MFMA path and the BLAS oracle,
-plus row-independence across batch sizes.  Development tool (imports the oracle)."""
+plus row-independence across batch sizes.  Checker script (imports the oracle, so it lives under tests/; not collected by pytest)."""
 import os
 import sys
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, "..", "lib"))
-sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, "..", "az-net_amd", "lib"))
+sys.path.insert(0, os.path.join(HERE, ".."))
 from aznet_hip import synth              # noqa: E402
 from aznet_hip.net import HipAZNet       # noqa: E402
 from oracle import az_oracle as orc      # noqa: E402
