@@ -61,6 +61,17 @@ struct az_ctx {
     int *nms_order = nullptr;
     unsigned long long *nms_mask = nullptr;
     long long *nms_keep = nullptr;
+    // tuner (az_eval.hip): anchor history of the last search, score pool over an image set
+    double *hisB = nullptr;
+    float *hisZ = nullptr;
+    int capHis = 0;
+    float *pool = nullptr, *pool_tmp = nullptr;
+    unsigned long long *pool_n = nullptr, *pool_hist = nullptr;      // [2], [256]
+    long long pool_cap = 0;
+    // grow-on-demand scratch of the evaluation / front-end entry points
+    void *ev_a = nullptr, *ev_b = nullptr, *ev_c = nullptr, *ev_d = nullptr, *ev_e = nullptr, *ev_f = nullptr,
+         *ev_g = nullptr, *ev_h = nullptr;
+    size_t ev_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // pinned host staging
     AzCounts *h_cnt = nullptr;
     double *h_Y = nullptr;
@@ -225,6 +236,20 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
                         score, delta, c->pred_u); }
 }
 
+// Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
+int ev_grow(az_ctx *c, int i, void **slot, size_t bytes)
+{
+    if (bytes <= c->ev_sz[i] && *slot) return AZ_OK;
+    if (*slot) hipFree(*slot);
+    *slot = nullptr;
+    c->ev_sz[i] = 0;
+    const size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipMalloc(slot, want);
+    if (e != hipSuccess) return fail(c, AZ_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    c->ev_sz[i] = want;
+    return AZ_OK;
+}
+
 int check_geom(az_ctx *c)
 {
     if (!c) return AZ_ERR_INVALID;
@@ -276,6 +301,9 @@ int az_destroy(az_ctx *c)
     for (void *p : c->allocs_det) hipFree(p);
     c->allocs_det.clear();
     if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
+    for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
+                    (void *)c->hisZ, (void *)c->pool, (void *)c->pool_tmp, (void *)c->pool_n, (void *)c->pool_hist})
+        if (p) hipFree(p);
     if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
@@ -422,7 +450,11 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     if (!p || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) || p->batch_size <= 0 || !(p->min_side > 0))
         return fail(c, AZ_ERR_INVALID, "az_propose: bad parameters");
     const int K = num_levels(p->im_h, p->im_w, p->min_side);
-    const int nlev = K - 1;
+    // The tuner's variant of the search (lib/detect/tune.py:256-316, params.reserved bit 2) runs
+    // `for k in xrange(K)` -- one level more than test.py:373 --, applies Tz from the second level
+    // on (the first compares against 0), never forces the root, and keeps the anchor history Bhis.
+    const bool tune = (p->reserved & 4) != 0;
+    const int nlev = tune ? K : K - 1;
     if (nlev < 1)
         return fail(c, AZ_ERR_INVALID,
                     "az_propose: image too small for one search level (the reference's loop at "
@@ -444,7 +476,12 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     // instead of three (each of those levels is weight-streaming-bound).  Head outputs are a
     // fixed function of the roi, so the levels below just look their rows up: bit-identical
     // results.  (params.reserved bit 0 turns this off.)
-    const int n_spec = (nlev >= 3 && !(p->reserved & 1)) ? 3 : 0;
+    const int n_spec = (nlev >= 3 && !(p->reserved & 1) && !tune) ? 3 : 0;
+    if (tune && !c->hisB) {
+        c->capHis = 2 * c->maxR;
+        HIPCHK(c, hipMalloc((void **)&c->hisB, (size_t)c->capHis * 4 * sizeof(double)));
+        HIPCHK(c, hipMalloc((void **)&c->hisZ, (size_t)c->capHis * sizeof(float)));
+    }
     // The geometry of those three levels is a few dozen elements per stage: by default it runs
     // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
     // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
@@ -498,10 +535,15 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         } else {
             launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u);
         }
+        if (tune) {
+            Timed t(c, "record_anchors", l);
+            azk_record_anchors(s, c->cnt, l, c->maxR, c->capHis, c->B[cur], c->inv, c->zoom_u, c->hisB, c->hisZ,
+                               &c->cnt->nhis, &c->cnt->err);
+        }
         { Timed t(c, "flags_compact", l);
           azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, c->pred_u, c->score_u,
-                            c->zoom_u, p->Tz, p->min_side, l == 0, c->cflag, c->zflag, c->bc_c, c->bc_z,
-                            c->Yall, c->Sall, c->Z, c->zr); }
+                            c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
+                            c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z, c->zr); }
         if (l + 1 < nlev) {      // the reference also divides after the last level but never uses it
             const bool track = (n_spec && l == 1);       // level-3 regions remember their speculative row
             { Timed t(c, "divide", l);
@@ -521,6 +563,10 @@ int az_propose_launch(az_ctx *c, const az_params *p)
       else
           azk_thresh_select_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, p->Tc, c->maxCand, c->sel_idx,
                                  &c->cnt->nsel, c->Yall, c->Sall, c->Yout, c->Sout); }
+    if (tune && c->pool) {
+        Timed t(c, "pool_append", nlev);
+        azk_pool_append(s, c->hisZ, &c->cnt->nhis, c->capHis, c->pool, c->pool_n, c->pool_cap);
+    }
     HIPCHK(c, hipGetLastError());
     c->last = *p;
     c->last_nlev = nlev;
@@ -567,7 +613,7 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
             st->level_unique[l] = h.U[l];
             st->level_zoomed[l] = h.PZ[l];
             st->num_eval += h.P[l];
-            if (h.P[l] > 0) st->depth = l + 1;
+            if (h.P[l] > 0) st->depth = (c->last.reserved & 4) ? l : l + 1;   // tune.py counts k from 0
         }
     }
     if ((h.err & 8) && !(c->last.reserved & 2)) {
@@ -956,6 +1002,266 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
 }
 
 // --------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------
+// Tuner (lib/detect/tune.py): anchor history and the global k-th largest zoom score.
+int az_last_anchors(az_ctx *c, double *regions_out, float *zoom_out, int cap, int *n_out)
+{
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!n_out) return AZ_ERR_INVALID;
+    if (!(c->last.reserved & 4) || !c->hisB)
+        return fail(c, AZ_ERR_STATE, "az_last_anchors: the last az_propose was not a tuner search (reserved bit 2)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n = c->h_cnt->nhis;
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_last_anchors: cap too small");
+    if (regions_out) HIPCHK(c, hipMemcpy(regions_out, c->hisB, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+    if (zoom_out) HIPCHK(c, hipMemcpy(zoom_out, c->hisZ, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+int az_tune_begin(az_ctx *c, long long capacity)
+{
+    if (!c || capacity <= 0) return fail(c, AZ_ERR_INVALID, "az_tune_begin: bad capacity");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (capacity > c->pool_cap) {
+        if (c->pool) { hipFree(c->pool); hipFree(c->pool_tmp); c->pool = c->pool_tmp = nullptr; c->pool_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->pool, (size_t)capacity * sizeof(float)));
+        HIPCHK(c, hipMalloc((void **)&c->pool_tmp, (size_t)capacity * sizeof(float)));
+        c->pool_cap = capacity;
+    }
+    if (!c->pool_n) {
+        HIPCHK(c, hipMalloc((void **)&c->pool_n, 4 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc((void **)&c->pool_hist, 256 * sizeof(unsigned long long)));
+    }
+    HIPCHK(c, hipMemsetAsync(c->pool_n, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+int az_tune_end(az_ctx *c)
+{
+    if (!c) return AZ_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pool) { hipFree(c->pool); hipFree(c->pool_tmp); }
+    c->pool = c->pool_tmp = nullptr;
+    c->pool_cap = 0;
+    return AZ_OK;
+}
+
+static int pool_size(az_ctx *c, long long *n, long long *dropped)
+{
+    if (!c->pool) return fail(c, AZ_ERR_STATE, "az_tune_begin has not been called");
+    unsigned long long h[2];
+    HIPCHK(c, hipMemcpyAsync(h, c->pool_n, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n = (long long)h[0];
+    *dropped = (long long)h[1];
+    return AZ_OK;
+}
+
+int az_tune_push(az_ctx *c, const float *scores, long long n)
+{
+    if (!c || n < 0 || (n && !scores)) return fail(c, AZ_ERR_INVALID, "az_tune_push: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long have, dropped;
+    int rc = pool_size(c, &have, &dropped);
+    if (rc) return rc;
+    if (have + n > c->pool_cap) return fail(c, AZ_ERR_CAPACITY, "az_tune_push: pool capacity exceeded");
+    if (n) HIPCHK(c, hipMemcpyAsync(c->pool + have, scores, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const unsigned long long nn = (unsigned long long)(have + n);
+    HIPCHK(c, hipMemcpyAsync(c->pool_n, &nn, sizeof(nn), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AZ_OK;
+}
+
+// MSB-first radix select over order-preserving keys: the key of the k-th largest score.
+static int pool_kth_key(az_ctx *c, long long n, long long k, unsigned int *key_out)
+{
+    unsigned int prefix = 0;
+    long long want = k;                       // rank (1-based, from the top) inside the current bucket
+    unsigned long long h[256];
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        HIPCHK(c, hipMemsetAsync(c->pool_hist, 0, sizeof(h), c->stream));
+        azk_pool_hist(c->stream, c->pool, n, prefix, shift, c->pool_hist);
+        HIPCHK(c, hipMemcpyAsync(h, c->pool_hist, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int b = 255;
+        for (; b > 0; --b) {
+            if ((long long)h[b] >= want) break;
+            want -= (long long)h[b];
+        }
+        prefix |= (unsigned int)b << shift;
+    }
+    *key_out = prefix;
+    return AZ_OK;
+}
+
+static float key_to_float(unsigned int k)
+{
+    const unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
+
+int az_tune_kth_largest(az_ctx *c, long long k, float *value_out, long long *n_total)
+{
+    if (!c || k <= 0 || !value_out) return fail(c, AZ_ERR_INVALID, "az_tune_kth_largest: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long n, dropped;
+    int rc = pool_size(c, &n, &dropped);
+    if (rc) return rc;
+    if (n_total) *n_total = n;
+    if (dropped) return fail(c, AZ_ERR_CAPACITY, "az_tune: score pool overflowed; raise az_tune_begin's capacity");
+    if (n <= k) { *value_out = -INFINITY; return AZ_OK; }     // the heap of tune.py:343-350 never overflowed
+    unsigned int key;
+    if ((rc = pool_kth_key(c, n, k, &key)) != AZ_OK) return rc;
+    *value_out = key_to_float(key);
+    return AZ_OK;
+}
+
+int az_tune_top(az_ctx *c, long long k, float *scores_out, long long cap, long long *n_out)
+{
+    if (!c || k <= 0 || !n_out) return fail(c, AZ_ERR_INVALID, "az_tune_top: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long n, dropped;
+    int rc = pool_size(c, &n, &dropped);
+    if (rc) return rc;
+    if (dropped) return fail(c, AZ_ERR_CAPACITY, "az_tune: score pool overflowed; raise az_tune_begin's capacity");
+    unsigned int key = 0;
+    if (n > k && (rc = pool_kth_key(c, n, k, &key)) != AZ_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(&c->pool_n[2], 0, sizeof(unsigned long long), c->stream));
+    azk_pool_keep(c->stream, c->pool, n, key, c->pool_tmp, &c->pool_n[2]);
+    unsigned long long m = 0;
+    HIPCHK(c, hipMemcpyAsync(&m, &c->pool_n[2], sizeof(m), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_out = (long long)m;
+    if ((long long)m > cap) return fail(c, AZ_ERR_CAPACITY, "az_tune_top: cap too small");
+    if (m && scores_out) HIPCHK(c, hipMemcpy(scores_out, c->pool_tmp, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Recall evaluation (lib/datasets/imdb.py:120-159) and utils.cython_bbox.bbox_overlaps.
+int az_bbox_overlaps(az_ctx *c, const double *boxes, int N, const double *query, int K, double *overlaps_out)
+{
+    if (!c || N < 0 || K < 0 || ((N && !boxes) || (K && !query)) || (N && K && !overlaps_out))
+        return fail(c, AZ_ERR_INVALID, "az_bbox_overlaps: bad arguments");
+    if (N == 0 || K == 0) return AZ_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ev_grow(c, 0, &c->ev_a, (size_t)N * 4 * sizeof(double))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 1, &c->ev_b, (size_t)K * 4 * sizeof(double))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 2, &c->ev_c, (size_t)N * K * sizeof(double))) != AZ_OK) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->ev_a, boxes, (size_t)N * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ev_b, query, (size_t)K * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    azk_bbox_overlaps(s, (const double *)c->ev_a, N, (const double *)c->ev_b, K, (double *)c->ev_c);
+    HIPCHK(c, hipMemcpyAsync(overlaps_out, c->ev_c, (size_t)N * K * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+int az_recall_match(az_ctx *c, int n_images, const double *boxes, const int32_t *box_off, const double *gt,
+                    const int32_t *gt_off, double *gt_overlaps_out)
+{
+    if (!c || n_images < 0 || (n_images && (!box_off || !gt_off)))
+        return fail(c, AZ_ERR_INVALID, "az_recall_match: bad arguments");
+    if (n_images == 0) return AZ_OK;
+    const int NB = box_off[n_images], NG = gt_off[n_images];
+    std::vector<long long> ov_off((size_t)n_images + 1, 0);
+    for (int i = 0; i < n_images; ++i) {
+        const long long n = box_off[i + 1] - box_off[i], k = gt_off[i + 1] - gt_off[i];
+        if (n < 0 || k < 0) return fail(c, AZ_ERR_INVALID, "az_recall_match: offsets must ascend");
+        if (n == 0 && k > 0)
+            return fail(c, AZ_ERR_INVALID, "az_recall_match: an image without boxes (imdb.py:128-129 skips those)");
+        ov_off[i + 1] = ov_off[i] + n * k;
+    }
+    if (NG == 0) return AZ_OK;
+    if (!boxes || !gt || !gt_overlaps_out) return fail(c, AZ_ERR_INVALID, "az_recall_match: NULL array");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t offb = ((size_t)n_images + 1) * sizeof(int32_t);
+    if ((rc = ev_grow(c, 0, &c->ev_a, (size_t)NB * 4 * sizeof(double))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 1, &c->ev_b, (size_t)NG * 4 * sizeof(double))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 2, &c->ev_c, (size_t)ov_off[n_images] * sizeof(double) + 8)) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 3, &c->ev_d, offb)) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 4, &c->ev_e, offb)) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 5, &c->ev_f, ((size_t)n_images + 1) * sizeof(long long))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 6, &c->ev_g, (size_t)NG * sizeof(double))) != AZ_OK) return rc;
+    if ((rc = ev_grow(c, 7, &c->ev_h, (size_t)n_images * sizeof(int))) != AZ_OK) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->ev_a, boxes, (size_t)NB * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ev_b, gt, (size_t)NG * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ev_d, box_off, offb, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ev_e, gt_off, offb, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->ev_f, ov_off.data(), ((size_t)n_images + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(c->ev_h, 0, (size_t)n_images * sizeof(int), s));
+    azk_recall_match(s, n_images, (const double *)c->ev_a, (const int *)c->ev_d, (const double *)c->ev_b,
+                     (const int *)c->ev_e, (const long long *)c->ev_f, (double *)c->ev_c, (double *)c->ev_g,
+                     (int *)c->ev_h);
+    std::vector<int> bad((size_t)n_images);
+    HIPCHK(c, hipMemcpyAsync(gt_overlaps_out, c->ev_g, (size_t)NG * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(bad.data(), c->ev_h, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));     // ov_off / bad live on this frame
+    for (int i = 0; i < n_images; ++i)
+        if (bad[i])
+            return fail(c, AZ_ERR_INVALID,
+                        "az_recall_match: image " + std::to_string(i) +
+                            " has more ground-truth boxes than candidates (assert gt_ovr >= 0, imdb.py:139)");
+    return AZ_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Image front-end (_get_image_blob, lib/detect/test.py:27-59).
+int az_image_blob_size(int h, int w, double scale, int *oh, int *ow)
+{
+    if (h <= 0 || w <= 0 || !(scale > 0) || !oh || !ow) return AZ_ERR_INVALID;
+    *oh = (int)std::nearbyint((double)h * scale);      // cv2: saturate_cast<int>(rows * fy), ties to even
+    *ow = (int)std::nearbyint((double)w * scale);
+    return (*oh > 0 && *ow > 0) ? AZ_OK : AZ_ERR_INVALID;
+}
+
+static int image_blob_common(az_ctx *c, const uint8_t *im, int h, int w, const float *means, double scale,
+                             float *out, bool out_is_dev, int oh, int ow)
+{
+    int eh, ew;
+    if (!c || !im || !means || !out || az_image_blob_size(h, w, scale, &eh, &ew) != AZ_OK || eh != oh || ew != ow)
+        return fail(c, AZ_ERR_INVALID, "az_image_blob: bad arguments (output size must come from az_image_blob_size)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t nin = (size_t)h * w * 3, nout = (size_t)oh * ow * 3;
+    if ((rc = ev_grow(c, 0, &c->ev_a, nin)) != AZ_OK) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->ev_a, im, nin, hipMemcpyHostToDevice, s));
+    float *dst = out;
+    if (!out_is_dev) {
+        if ((rc = ev_grow(c, 1, &c->ev_b, nout * sizeof(float))) != AZ_OK) return rc;
+        dst = (float *)c->ev_b;
+    }
+    azk_image_blob(s, (const unsigned char *)c->ev_a, h, w, means, 1.0 / scale, 1.0 / scale, oh, ow, dst);
+    if (!out_is_dev) HIPCHK(c, hipMemcpyAsync(out, dst, nout * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return AZ_OK;
+}
+
+int az_image_blob_host(az_ctx *c, const uint8_t *im, int h, int w, const float *means, double scale, float *blob_out,
+                       int oh, int ow)
+{
+    return image_blob_common(c, im, h, w, means, scale, blob_out, false, oh, ow);
+}
+
+int az_image_blob_dev(az_ctx *c, const uint8_t *im, int h, int w, const float *means, double scale, float *blob_dev,
+                      int oh, int ow)
+{
+    return image_blob_common(c, im, h, w, means, scale, blob_dev, true, oh, ow);
+}
+
+
 int az_set_profiling(az_ctx *c, int on)
 {
     if (!c) return AZ_ERR_INVALID;

@@ -22,6 +22,8 @@ struct AzCounts {
     int scratch[6];
     // speculative evaluation of levels 1-3 (az_capi.hip): |B1|, children of all of B1, rows forwarded
     int specP1, specCH, specU, specPad;
+    // tuner's search (lib/detect/tune.py:256-316): rows of the anchor history written so far
+    int nhis, hisPad[3];
 };
 
 // Geometry of one launch of the head on `U` rois (all device pointers).
@@ -164,3 +166,18 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
              unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep);
 #define AZ_TOPK_MAX 4096
+
+// ---- launchers (az_eval.hip): front-end, recall evaluation, threshold tuner ----------------
+void azk_image_blob(hipStream_t s, const unsigned char *im, int h, int w, const float *means, double inv_sx,
+                    double inv_sy, int oh, int ow, float *out);
+void azk_bbox_overlaps(hipStream_t s, const double *boxes, int N, const double *query, int K, double *out);
+void azk_recall_match(hipStream_t s, int n_img, const double *boxes, const int *box_off, const double *gt,
+                      const int *gt_off, const long long *ov_off, double *ov, double *gt_ovr, int *bad);
+void azk_record_anchors(hipStream_t s, const AzCounts *cnt, int level, int capR, int capHis, const double *B,
+                        const int *inv, const float *zoom_u, double *hisB, float *hisZ, int *nhis, int *err);
+void azk_pool_append(hipStream_t s, const float *src, const int *nptr, int cap_src, float *pool,
+                     unsigned long long *pool_n, long long cap);
+void azk_pool_hist(hipStream_t s, const float *pool, long long n, unsigned int prefix, int shift,
+                   unsigned long long *hist);
+void azk_pool_keep(hipStream_t s, const float *pool, long long n, unsigned int kmin, float *dst,
+                   unsigned long long *ndst);

@@ -7,6 +7,7 @@ feature map and hands over a raw device pointer.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -27,7 +28,9 @@ SYMBOLS = [
     "az_propose_fetch", "az_last_candidates", "az_divide_region", "az_sift_dup", "az_roi_dedup",
     "az_roi_pool", "az_head_forward", "az_decode_filter", "az_topk", "az_nms", "az_set_profiling",
     "az_last_kernel_times", "az_stream", "az_load_det_head", "az_det_forward", "az_detect",
-    "az_set_gemm_mode",
+    "az_set_gemm_mode", "az_last_anchors", "az_tune_begin", "az_tune_end", "az_tune_kth_largest",
+    "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
+    "az_image_blob_host", "az_image_blob_dev",
 ]
 
 
@@ -68,6 +71,14 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise ImportError("libaznet_hip.so not found at %s -- the HIP extension is required "
                           "(no CPU fallback); run make -C az-net_amd/csrc" % p)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and must be the
+    # first to load it -- if this library pulls in /opt/rocm's copy first, torch later finds
+    # "No HIP GPUs".  The host side uses torch for device memory / streams anyway.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(p)
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     fp, dp = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double)
@@ -103,6 +114,19 @@ def load_library(path=None):
     L.az_last_kernel_times.argtypes = [vp, ctypes.c_char_p, fp, ip, ci, cip]
     L.az_stream.restype = vp
     L.az_stream.argtypes = [vp]
+    ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
+    L.az_tune_begin.argtypes = [vp, ll]
+    L.az_tune_end.argtypes = [vp]
+    L.az_tune_kth_largest.argtypes = [vp, ll, fp, llp]
+    L.az_tune_top.argtypes = [vp, ll, fp, ll, llp]
+    L.az_tune_push.argtypes = [vp, fp, ll]
+    L.az_bbox_overlaps.argtypes = [vp, dp, ci, dp, ci, dp]
+    L.az_recall_match.argtypes = [vp, ci, dp, ip, dp, ip, dp]
+    L.az_image_blob_size.argtypes = [ci, ci, cd, cip, cip]
+    L.az_image_blob_host.argtypes = [vp, u8p, ci, ci, fp, cd, fp, ci, ci]
+    L.az_image_blob_dev.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci]
     for name in SYMBOLS:
         if name not in ("az_version", "az_last_error", "az_stream"):
             getattr(L, name).restype = ci
@@ -208,13 +232,16 @@ class AzContext(object):
     # ---- hot path -----------------------------------------------------------------
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
-                    dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True):
+                    dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True,
+                    tune=False):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
         slower); fused=False keeps the geometry of those levels as separate launches.  Both
-        exist for tests and measurements."""
+        exist for tests and measurements.  tune=True selects the tuner's variant of the search
+        (lib/detect/tune.py:256-316) and keeps the anchor history (last_anchors)."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
-                        1 if fixed_num else 0, (0 if speculate else 1) | (0 if fused else 2))
+                        1 if fixed_num else 0,
+                        (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates
@@ -381,6 +408,99 @@ class AzContext(object):
                                    int(batch_size), int(im_h), int(im_w), float(eps), _p(s, ctypes.c_float),
                                    _p(b, ctypes.c_double)))
         return s[:P], b[:P]
+
+    # ---- tuner ------------------------------------------------------------------------
+    def last_anchors(self):
+        """(regions [n,4] f64, zoom [n] f32) of the last tuner-variant search (Bhis, tune.py:303)."""
+        cap = 2 * self.max_regions
+        regions = np.empty((cap, 4), dtype=np.float64)
+        zoom = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_last_anchors(self.h, _p(regions, ctypes.c_double), _p(zoom, ctypes.c_float), cap,
+                                         ctypes.byref(n)))
+        return regions[:n.value].copy(), zoom[:n.value].copy()
+
+    def tune_begin(self, capacity):
+        self._chk(self.L.az_tune_begin(self.h, int(capacity)))
+
+    def tune_end(self):
+        self._chk(self.L.az_tune_end(self.h))
+
+    def tune_kth_largest(self, k):
+        """(k-th largest pooled zoom score as float, number of pooled scores); -inf when <= k."""
+        v = ctypes.c_float(0)
+        n = ctypes.c_longlong(0)
+        self._chk(self.L.az_tune_kth_largest(self.h, int(k), ctypes.byref(v), ctypes.byref(n)))
+        return float(v.value), int(n.value)
+
+    def tune_top(self, k):
+        cap = int(k) + 65536
+        while True:
+            out = np.empty((cap,), dtype=np.float32)
+            n = ctypes.c_longlong(0)
+            rc = self.L.az_tune_top(self.h, int(k), _p(out, ctypes.c_float), cap, ctypes.byref(n))
+            if rc == AZ_ERR_CAPACITY and n.value > cap:
+                cap = int(n.value)
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def tune_push(self, scores):
+        a = _f32(scores).ravel()
+        self._chk(self.L.az_tune_push(self.h, _p(a, ctypes.c_float), a.size))
+
+    # ---- recall evaluation -------------------------------------------------------------
+    def bbox_overlaps(self, boxes, query_boxes):
+        b = _f64(boxes).reshape(-1, 4)
+        q = _f64(query_boxes).reshape(-1, 4)
+        out = np.zeros((b.shape[0], q.shape[0]), dtype=np.float64)
+        self._chk(self.L.az_bbox_overlaps(self.h, _p(b, ctypes.c_double), b.shape[0], _p(q, ctypes.c_double),
+                                          q.shape[0], _p(out, ctypes.c_double)))
+        return out
+
+    def recall_match(self, boxes_list, gt_list):
+        """Per-image greedy matching of imdb.evaluate_recall for lists of [n_i,4] candidate and
+        [k_i,4] ground-truth boxes -> concatenated gt overlaps (image order, then pick order)."""
+        assert len(boxes_list) == len(gt_list)
+        n = len(boxes_list)
+        boff = np.zeros(n + 1, dtype=np.int32)
+        goff = np.zeros(n + 1, dtype=np.int32)
+        for i in range(n):
+            boff[i + 1] = boff[i] + boxes_list[i].shape[0]
+            goff[i + 1] = goff[i] + gt_list[i].shape[0]
+        b = _f64(np.vstack([np.zeros((0, 4))] + [x.reshape(-1, 4) for x in boxes_list]))
+        g = _f64(np.vstack([np.zeros((0, 4))] + [x.reshape(-1, 4) for x in gt_list]))
+        out = np.zeros((int(goff[n]),), dtype=np.float64)
+        self._chk(self.L.az_recall_match(self.h, n, _p(b, ctypes.c_double), _p(boff, ctypes.c_int32),
+                                         _p(g, ctypes.c_double), _p(goff, ctypes.c_int32), _p(out, ctypes.c_double)))
+        return out
+
+    # ---- image front-end ---------------------------------------------------------------
+    def image_blob_size(self, h, w, scale):
+        oh, ow = ctypes.c_int(0), ctypes.c_int(0)
+        rc = self.L.az_image_blob_size(int(h), int(w), float(scale), ctypes.byref(oh), ctypes.byref(ow))
+        if rc != AZ_OK:
+            raise AzError(rc, "az_image_blob_size: bad arguments")
+        return oh.value, ow.value
+
+    def image_blob(self, im, means, scale, out=None):
+        """uint8 BGR HWC image -> [1,3,oh,ow] f32 blob (mean-subtracted, cv2-style bilinear).
+        out: None -> NumPy array; a CUDA torch tensor of the right shape -> filled in place."""
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        assert im.ndim == 3 and im.shape[2] == 3
+        h, w = im.shape[:2]
+        oh, ow = self.image_blob_size(h, w, scale)
+        m = _f32(np.asarray(means).ravel())
+        assert m.size == 3
+        if out is None:
+            blob = np.empty((1, 3, oh, ow), dtype=np.float32)
+            self._chk(self.L.az_image_blob_host(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float),
+                                                float(scale), _p(blob, ctypes.c_float), oh, ow))
+            return blob
+        assert tuple(out.shape[-3:]) == (3, oh, ow) and out.is_contiguous() and out.is_cuda
+        self._chk(self.L.az_image_blob_dev(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float),
+                                           float(scale), ctypes.c_void_p(out.data_ptr()), oh, ow))
+        return out
 
     # ---- measurement -----------------------------------------------------------------
     def set_profiling(self, mode):

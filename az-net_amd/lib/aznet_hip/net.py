@@ -52,6 +52,18 @@ class HipAZNet(object):
         self.ctx.set_feature_map(conv)
         self._conv = conv
 
+    def image_blob(self, im, pixel_means, scale):
+        """_get_image_blob (lib/detect/test.py:27-59) on the GPU for a uint8 BGR image: with a
+        backbone, the blob is written straight into a CUDA tensor the backbone reads (no f32 host
+        copy); without one, a NumPy array comes back."""
+        if self.backbone is None:
+            return self.ctx.image_blob(im, pixel_means, scale)
+        import torch
+        oh, ow = self.ctx.image_blob_size(im.shape[0], im.shape[1], scale)
+        out = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=self.backbone.device)
+        torch.cuda.current_stream(out.device).synchronize()
+        return self.ctx.image_blob(im, pixel_means, scale, out=out)
+
     def compute_conv(self, data_blob):
         """Run the torch backbone on a [1,3,H,W] blob and hand conv5_3 to the HIP context."""
         if self.backbone is None:

@@ -37,28 +37,30 @@ def _im_scale(im_shape):
     return scales
 
 
-def _resize_bilinear(im, scale):
-    """cv2.resize(..., fx=scale, fy=scale, INTER_LINEAR) stand-in (cv2 is not available
-    offline): half-pixel-centre bilinear, output size round(dim * scale)."""
-    if scale == 1.0:
+def _as_uint8(im):
+    """cv2.imread hands the reference uint8 BGR; accept integral-valued arrays of other dtypes."""
+    if im.dtype == np.uint8:
         return im
-    import torch
-    import torch.nn.functional as F
-    h = int(round(im.shape[0] * scale))
-    w = int(round(im.shape[1] * scale))
-    t = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1)))[None]
-    t = F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)
-    return t[0].numpy().transpose(1, 2, 0)
+    q = np.rint(im)
+    if not (np.array_equal(q, im) and q.min() >= 0 and q.max() <= 255):
+        raise TypeError("image must hold uint8 pixel values (as cv2.imread returns)")
+    return q.astype(np.uint8)
 
 
-def _get_image_blob(im):
+def _get_image_blob(im, net=None):
     """BGR uint8 image -> ([1,3,H,W] float32 mean-subtracted blob, scale factors)
-    (test.py:27-59).  Computed once per image; the reference recomputes it at every level."""
-    im_orig = im.astype(np.float32, copy=True)
-    im_orig -= cfg.PIXEL_MEANS.astype(np.float32)
-    scales = _im_scale(im_orig.shape)
-    ims = [_resize_bilinear(im_orig, s) for s in scales]
-    return im_list_to_blob(ims), np.array(scales)
+    (test.py:27-59).  Mean subtraction and the cv2.INTER_LINEAR resize run in one HIP kernel
+    (az_image_blob_*); with `net` (a HipAZNet that owns a backbone) the blob stays on the GPU.
+    Computed once per image; the reference recomputes it at every level."""
+    scales = _im_scale(im.shape)
+    if len(scales) != 1:
+        raise NotImplementedError("one test scale (cfg.TEST.SCALES), as in every config of the reference")
+    src = _as_uint8(im)
+    if net is not None:
+        blob = net.image_blob(src, cfg.PIXEL_MEANS, scales[0])
+    else:
+        blob = ffi.default_context().image_blob(src, cfg.PIXEL_MEANS, scales[0])
+    return blob, np.array(scales)
 
 
 def divide_region(regions):
@@ -101,7 +103,7 @@ def im_propose(net, im, return_conv=False, num_proposals=None, conv=None):
     hnet = net["full"] if isinstance(net, dict) else net
     scales = _im_scale(im.shape)
     if conv is None:
-        blob, _ = _get_image_blob(im)
+        blob, _ = _get_image_blob(im, hnet)
         conv_t = hnet.compute_conv(blob)
         conv = {name: conv_t for name in cfg.SEAR.FRCNN_CONV}
     else:

@@ -7,7 +7,9 @@ output).  Differences forced by what exists offline:
           conv1_1_w/conv1_1_b ...), or `synthetic[:seed]`.
   --def / --def_fc  accepted for command-line compatibility; the layer graph is fixed
           (models/Pascal/VGG16/az-net/test.prototxt, test_fc.prototxt).
-  --imdb  `synthetic_<H>x<W>_<N>` or `npy:<dir>`.
+  --imdb  `voc_<year>_<split>` (needs data/VOCdevkit<year>), `synthetic_<H>x<W>_<N>` or `npy:<dir>`.
+  --recall  (extension) also evaluate recall against the imdb's ground truth
+          (imdb.evaluate_recall, lib/datasets/imdb.py:120-159) and store it in proposals.pkl.
 With several GPUs: python -m torch.distributed.run --nproc-per-node N tools/prop_az.py ...
 shards the images one rank per GPU and gathers the proposals on every rank (RCCL)."""
 import _init_paths  # noqa: F401
@@ -40,6 +42,7 @@ def parse_args():
     parser.add_argument('--tz', dest='tz', help='zoom threshold given directly (instead of --thresh)', default=None,
                         type=float)
     parser.add_argument('--exp', dest='exp_dir', help='experiment path', default=None, type=str)
+    parser.add_argument('--recall', dest='recall', help='evaluate recall against the ground truth', action='store_true')
     if len(sys.argv) == 1:
         parser.print_help()
         sys.exit(1)
@@ -100,10 +103,22 @@ if __name__ == '__main__':
     torch.cuda.set_device(device)
     net = load_net(args.caffemodel, device)
     nets = {'full': net, 'fc': net}
-    from aznet_hip.imdb import get_imdb
+    from datasets.factory import get_imdb
     imdb = get_imdb(args.imdb_name)
+    def report_recall(prop_file):
+        with open(prop_file, 'rb') as f:
+            prop = pickle.load(f)
+        ar, gt_overlaps, recalls, thresholds = imdb.evaluate_recall(prop['boxes'], ctx=net.ctx)
+        prop['recall'] = float(recalls[0])
+        with open(prop_file, 'wb') as f:
+            pickle.dump(prop, f, pickle.HIGHEST_PROTOCOL)
+        print('recall@0.5 = {:.4f}, recall@0.7 = {:.4f}, AR = {:.4f} over {:d} gt boxes'.format(
+            recalls[0], recalls[200], ar, gt_overlaps.size))
+
     if world == 1:
-        test_proposals(nets, imdb)
+        prop_file = test_proposals(nets, imdb)
+        if args.recall:
+            report_recall(prop_file)
     else:
         import torch.distributed as dist
         from aznet_hip import dist as azdist
@@ -130,5 +145,7 @@ if __name__ == '__main__':
             with open(os.path.join(out_dir, 'proposals.pkl'), 'wb') as f:
                 pickle.dump(prop, f, pickle.HIGHEST_PROTOCOL)
             print('wrote', os.path.join(out_dir, 'proposals.pkl'))
+            if args.recall:
+                report_recall(os.path.join(out_dir, 'proposals.pkl'))
         dist.barrier()
         dist.destroy_process_group()

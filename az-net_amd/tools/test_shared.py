@@ -79,7 +79,7 @@ if __name__ == '__main__':
     torch.cuda.set_device(args.gpu_id)
     from prop_az import load_net
     from aznet_hip.net import HipDetNet
-    from aznet_hip.imdb import get_imdb
+    from datasets.factory import get_imdb
     az_net = load_net(args.caffemodel_az, args.gpu_id)
     az_nets = {'full': az_net, 'fc': az_net}
     det_head, det_name = load_det_head(args.caffemodel_frcnn)

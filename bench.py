@@ -113,7 +113,7 @@ def main():
     net = HipAZNet(head, backbone=backbone, device=local_rank, name="vgg16_az_net_hip", max_regions=4096)
     from detect.test import _get_image_blob
     im = synth.make_image(rank, H_IM, W_IM)                  # one image per GPU, seed = rank
-    blob, scales = _get_image_blob(im)
+    blob, scales = _get_image_blob(im, net)                  # HIP front-end kernel -> CUDA tensor
     backbone.normalize_output(blob)                          # random-init weights: unit-RMS conv5_3
     conv = net.compute_conv(blob)                            # resident in HBM from here on
     params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS)

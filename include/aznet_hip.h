@@ -57,7 +57,10 @@ typedef struct {
     int32_t num_proposals;    /* cfg.SEAR.NUM_PROPOSALS (config.py:133, 279)           */
     int32_t fixed_num;        /* cfg.SEAR.FIXED_PROPOSAL_NUM (config.py:172)           */
     int32_t reserved;         /* flags; bit 0: evaluate levels 1-3 one by one (no speculation);
-                                 bit 1: keep their geometry as separate launches (same bits)   */
+                                 bit 1: keep their geometry as separate launches (same bits);
+                                 bit 2: the tuner's variant of the search (lib/detect/tune.py:
+                                 256-316): K levels instead of K-1, Tz applied from the second
+                                 level on, root not forced, anchor history kept (az_last_anchors) */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
@@ -175,6 +178,51 @@ int az_det_forward(az_ctx *ctx, const float *rois, int R, float *cls_prob, float
  * class, un-dedup.  scores_out [P,ncls] f32, boxes_out [P,4*ncls] f64. */
 int az_detect(az_ctx *ctx, const double *boxes, int P, double scale, double dedup, int batch_size,
               int im_h, int im_w, double eps, float *scores_out, double *boxes_out);
+
+/* ---- zoom-threshold tuner (lib/detect/tune.py, tools/set_thresh.py) ------------------- */
+/* `Bhis` of the tuner's im_propose (tune.py:303, returned at :316) for the last az_propose run
+ * with params.reserved bit 2: every region evaluated, level-major, with its zoom score.
+ * regions_out [cap,4] f64, zoom_out [cap] f32; either may be NULL. */
+int az_last_anchors(az_ctx *ctx, double *regions_out, float *zoom_out, int cap, int *n_out);
+/* tune_thresh (tune.py:318-366) keeps the num_images*ANCHORS_PER_IMG largest zoom scores of a
+ * whole image set in a heap and returns the smallest of them.  Here the scores stay in HBM:
+ * between az_tune_begin and az_tune_end every tuner-variant az_propose appends its anchors' zoom
+ * scores to a device pool of `capacity` floats (no host round trip), and az_tune_kth_largest
+ * radix-selects the k-th largest: -inf when the pool holds <= k scores, exactly as the heap
+ * never overflowing leaves `thresh = -np.inf` (tune.py:326,347-350). */
+int az_tune_begin(az_ctx *ctx, long long capacity);
+int az_tune_end(az_ctx *ctx);
+int az_tune_kth_largest(az_ctx *ctx, long long k, float *value_out, long long *n_total);
+/* Multi-GPU merge: every pooled score >= the k-th largest (all of them when the pool holds
+ * <= k), unordered; rank 0 pushes the gathered lists into its own pool and selects again. */
+int az_tune_top(az_ctx *ctx, long long k, float *scores_out, long long cap, long long *n_out);
+int az_tune_push(az_ctx *ctx, const float *scores, long long n);
+
+/* ---- recall evaluation (lib/datasets/imdb.py:120-159) ----------------------------------- */
+/* utils.cython_bbox.bbox_overlaps(boxes f64[N,4], query_boxes f64[K,4]) -> f64[N,K]
+ * (lib/utils/bbox.pyx:132-172). */
+int az_bbox_overlaps(az_ctx *ctx, const double *boxes, int N, const double *query, int K,
+                     double *overlaps_out);
+/* The matching loop of imdb.evaluate_recall (imdb.py:124-147) for n_images images at once:
+ * image i owns boxes[box_off[i]:box_off[i+1]] and gt[gt_off[i]:gt_off[i+1]] (f64 [.,4]); per
+ * image, repeatedly take the best remaining (box, gt) pair, record its overlap, retire both.
+ * gt_overlaps_out [gt_off[n_images]] in image order, then pick order.  Images without boxes
+ * must be left out by the caller (imdb.py:128-129); fewer boxes than gt boxes in an image is
+ * AZ_ERR_INVALID (the reference's `assert(gt_ovr >= 0)` fires there). */
+int az_recall_match(az_ctx *ctx, int n_images, const double *boxes, const int32_t *box_off,
+                    const double *gt, const int32_t *gt_off, double *gt_overlaps_out);
+
+/* ---- image front-end (_get_image_blob, lib/detect/test.py:27-59) ------------------------- */
+/* uint8 BGR HWC image (host) -> float32 [3, oh, ow] blob: subtract cfg.PIXEL_MEANS, then
+ * cv2.resize(fx=fy=scale, INTER_LINEAR) semantics on f32 (half-pixel centres, edge clamp,
+ * horizontal pass then vertical pass).  oh/ow must come from az_image_blob_size
+ * (cv2's dsize = round-half-even(dim * scale)).  _dev writes to a device pointer (e.g. the
+ * torch tensor the backbone reads), _host to a host array. */
+int az_image_blob_size(int h, int w, double scale, int *oh, int *ow);
+int az_image_blob_host(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means,
+                       double scale, float *blob_out, int oh, int ow);
+int az_image_blob_dev(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means,
+                      double scale, float *blob_dev, int oh, int ow);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /

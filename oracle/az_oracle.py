@@ -485,3 +485,130 @@ def im_detect_shared(az_net, frcnn_net, im_shape, scale, num_classes, cfg):
     boxes, tr = im_propose(az_net, im_shape, scale, cfg, return_trace=True)
     scores, pred_boxes = frcnn_forward(frcnn_net, im_shape, scale, boxes, num_classes, tr["conv"], cfg)
     return scores, pred_boxes, boxes
+
+
+# --------------------------------------------------------------------------
+# Callers either side of the path: image front-end, recall
+# evaluation, zoom-threshold tuner.
+# --------------------------------------------------------------------------
+def image_blob_size(h, w, scale):
+    """cv2.resize with fx/fy: dsize = saturate_cast<int>(dim * f), i.e. round half to even."""
+    return int(np.rint(h * scale)), int(np.rint(w * scale))
+
+
+def _linear_taps(n_out, n_in, scale):
+    """Source taps of cv2's INTER_LINEAR for float images (OpenCV 2.4/3.x resize(): the
+    library is not in /root/reference nor in this image -- published algorithm restated, parity
+    unpinned): position (d + 0.5)/scale - 0.5 narrowed to f32; floor and f32 fraction; below
+    0 -> tap 0 weight 1; at/after the last pixel -> last pixel weight 1."""
+    d = np.arange(n_out, dtype=np.float64)
+    f = ((d + 0.5) * (1.0 / scale) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    a = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    s[lo] = 0
+    a[lo] = 0
+    hi = s >= n_in - 1
+    s[hi] = n_in - 1
+    a[hi] = 0
+    s1 = np.minimum(s + 1, n_in - 1)
+    return s, s1, (np.float32(1) - a).astype(np.float32), a
+
+
+def image_blob(im, pixel_means, scale):
+    """_get_image_blob (lib/detect/test.py:27-59) for the single test scale: f32 image minus
+    cfg.PIXEL_MEANS, cv2.resize(fx=fy=scale, INTER_LINEAR), HWC -> [1,3,oh,ow]."""
+    src = im.astype(np.float32, copy=True)
+    src -= np.asarray(pixel_means, dtype=np.float32).reshape(1, 1, 3)
+    h, w = src.shape[:2]
+    oh, ow = image_blob_size(h, w, scale)
+    x0, x1, wx0, wx1 = _linear_taps(ow, w, scale)
+    y0, y1, wy0, wy1 = _linear_taps(oh, h, scale)
+    hor = (src[:, x0, :] * wx0[None, :, None]).astype(np.float32) + \
+          (src[:, x1, :] * wx1[None, :, None]).astype(np.float32)
+    hor = hor.astype(np.float32)
+    out = (hor[y0] * wy0[:, None, None]).astype(np.float32) + (hor[y1] * wy1[:, None, None]).astype(np.float32)
+    return np.ascontiguousarray(out.astype(np.float32).transpose(2, 0, 1)[None])
+
+
+def recall_gt_overlaps(candidate_boxes, gt_boxes):
+    """The matching loop of imdb.evaluate_recall (lib/datasets/imdb.py:123-147): lists of
+    per-image candidate / ground-truth boxes -> concatenated per-gt overlaps."""
+    gt_overlaps = np.zeros(0)
+    for boxes, gts in zip(candidate_boxes, gt_boxes):
+        if boxes.shape[0] == 0:
+            continue
+        overlaps = bbox_overlaps(boxes.astype(np.float64), gts.astype(np.float64))
+        per = np.zeros((gts.shape[0]))
+        for j in range(gts.shape[0]):
+            argmax_overlaps = overlaps.argmax(axis=0)
+            max_overlaps = overlaps.max(axis=0)
+            gt_ind = max_overlaps.argmax()
+            gt_ovr = max_overlaps.max()
+            assert gt_ovr >= 0
+            box_ind = argmax_overlaps[gt_ind]
+            per[j] = overlaps[box_ind, gt_ind]
+            overlaps[box_ind, :] = -1
+            overlaps[:, gt_ind] = -1
+        gt_overlaps = np.hstack((gt_overlaps, per))
+    return gt_overlaps
+
+
+def recall_curve(gt_overlaps):
+    """imdb.py:149-158: (ar, sorted gt_overlaps, recalls, thresholds)."""
+    num_pos = gt_overlaps.size
+    gt_overlaps = np.sort(gt_overlaps)
+    step = 0.001
+    thresholds = np.minimum(np.arange(0.5, 1.0 + step, step), 1.0)
+    recalls = np.zeros_like(thresholds)
+    for i, t in enumerate(thresholds):
+        recalls[i] = (gt_overlaps >= t).sum() / float(num_pos)
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    ar = 2 * trapz(recalls, thresholds)
+    return ar, gt_overlaps, recalls, thresholds
+
+
+def evaluate_recall(candidate_boxes, gt_boxes):
+    return recall_curve(recall_gt_overlaps(candidate_boxes, gt_boxes))
+
+
+def im_propose_tune(net, im_shape, scale, cfg, data_blob=None):
+    """The tuner's search (lib/detect/tune.py:256-316): K levels, Tz = 0 for the first
+    comparison and cfg.Tz afterwards, no forced root; returns ([Y | score], Bhis)."""
+    height, width = int(im_shape[0]), int(im_shape[1])
+    B = np.array([[0, 0, width - 1.0, height - 1.0]])
+    Bhis = np.zeros((0, 5))
+    Y = np.zeros((0, 4))
+    aScores = np.zeros((0,))
+    K = num_levels(height, width, cfg.MIN_SIDE)
+    Tz = 0
+    conv = None
+    for k in range(K):
+        zoom, boxes, c, conv = az_forward(net, (height, width), scale, B, conv, cfg, data_blob, None)
+        Y = np.vstack((Y, boxes))
+        aScores = np.hstack((aScores, c))
+        indZ = np.where(zoom >= Tz)[0]
+        Z = B[indZ, :]
+        Bhis = np.vstack((Bhis, np.hstack((B, zoom[:, np.newaxis]))))
+        if Z.shape[0] == 0:
+            break
+        B = divide_region(Z, cfg.MIN_SIDE)
+        Tz = cfg.Tz
+    Yout, indA = top_k(Y, aScores, cfg.NUM_PROPOSALS)
+    return np.hstack((Yout, aScores[indA][:, np.newaxis])), Bhis
+
+
+def tune_thresh(score_lists, max_per_set):
+    """tune_thresh's heap (lib/detect/tune.py:326-350) over per-image anchor zoom scores."""
+    import heapq
+    top_scores = []
+    thresh = -np.inf
+    for scores in score_lists:
+        inds = np.where(scores > thresh)[0]
+        for val in scores[inds]:
+            heapq.heappush(top_scores, val)
+        if len(top_scores) > max_per_set:
+            while len(top_scores) > max_per_set:
+                heapq.heappop(top_scores)
+            thresh = top_scores[0]
+    return thresh

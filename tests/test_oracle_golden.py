@@ -145,3 +145,65 @@ def test_softmax_matches_definition():
     assert p.dtype == np.float32 and np.allclose(p.sum(1), 1, atol=1e-6)
     ref = np.exp(x.astype(np.float64) - x.max(1, keepdims=True))
     np.testing.assert_allclose(p, ref / ref.sum(1, keepdims=True), rtol=1e-5, atol=1e-7)
+
+
+# ---- rows next to the path: goldens from oracle/gen_golden_next.py -----------
+def _recall_lists(g):
+    cand, gts = [], []
+    for i in range(int(g["n_img"])):
+        cls = g["cls%d" % i]
+        cand.append(g["cand%d" % i])
+        gts.append(g["gt%d" % i][np.where(cls > 0)[0], :])      # imdb.py:125-126
+    return cand, gts
+
+
+def test_evaluate_recall_against_reference():
+    g = load("g10_recall.npz")
+    cand, gts = _recall_lists(g)
+    ar, gt_overlaps, recalls, thresholds = orc.evaluate_recall(cand, gts)
+    assert np.array_equal(gt_overlaps, g["gt_overlaps"])
+    assert np.array_equal(recalls, g["recalls"]) and np.array_equal(thresholds, g["thresholds"])
+    assert ar == float(g["ar"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_tuner_search_against_reference_trace(tag):
+    g = load("g11_tune_%s.npz" % tag)
+    cfg = orc.OracleCfg(Tz=float(g["Tz"]), NUM_PROPOSALS=int(g["num_proposals"]))
+    Y5, Bhis = orc.im_propose_tune(replay_nets(g), (int(g["H"]), int(g["W"])), float(g["scale"]), cfg,
+                                   data_blob=np.zeros((1, 3, 2, 2), np.float32))
+    assert np.array_equal(Bhis, g["Bhis"])
+    assert np.array_equal(Y5[:, 4], g["Y5"][:, 4])
+    assert np.array_equal(Y5, g["Y5"])
+
+
+@pytest.mark.parametrize("per_img", [20, 400])
+def test_tune_thresh_against_reference(per_img):
+    g = load("g12_tune_thresh_%d.npz" % per_img)
+    lists = [g["bhis%d" % i][:, -1] for i in range(3)]
+    assert orc.tune_thresh(lists, 3 * per_img) == float(g["thresh"])
+    # the heap's answer is the k-th largest of all scores (what the GPU path selects)
+    allz = np.sort(np.concatenate(lists))[::-1]
+    assert allz[3 * per_img - 1] == float(g["thresh"])
+    assert orc.tune_thresh(lists, 10 ** 6) == -np.inf
+
+
+def test_image_blob_restatement_properties():
+    """cv2 is absent (parity unpinned): scale 1 is the identity; a x2 upscale of a constant image
+    stays constant; against torch's half-pixel bilinear the f32 results agree to 1e-3."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.RandomState(5)
+    im = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    means = np.array([102.9801, 115.9465, 122.7717])
+    b1 = orc.image_blob(im, means, 1.0)
+    assert np.array_equal(b1[0], (im.astype(np.float32) - means.astype(np.float32)).transpose(2, 0, 1))
+    c = orc.image_blob(np.full((20, 30, 3), 77, np.uint8), means, 2.0)
+    assert c.shape == (1, 3, 40, 60)
+    assert np.allclose(c[0, 0], 77 - np.float32(means[0]), atol=1e-4)
+    for scale in (2.0, 1.6, 0.5):
+        oh, ow = orc.image_blob_size(37, 53, scale)
+        if abs(oh / 37.0 - scale) > 1e-9 or abs(ow / 53.0 - scale) > 1e-9:
+            continue        # torch derives its step from the size ratio, cv2 from fx/fy
+        ref = F.interpolate(torch.from_numpy(b1), size=(oh, ow), mode="bilinear", align_corners=False).numpy()
+        assert np.abs(orc.image_blob(im, means, scale) - ref).max() < 1e-3
