@@ -229,11 +229,9 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
     { Timed t(c, "fc7_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b7, Uptr, c->maxR, d.n7, c->S7, c->h7, d.n7, 1); }
-    { Timed t(c, "tail_gemm", level, 1);
-      azk_fc_gemm(c->stream, c->h7, d.n7, c->Wt, d.n7, Uptr, c->maxR, AZK_TAIL_NOUT, d.n7, AZK_TAIL_SPLIT, c->part); }
-    { Timed t(c, "tail_epilogue", level);
-      azk_tail_epilogue(c->stream, c->part, AZK_TAIL_SPLIT, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom,
-                        score, delta, c->pred_u); }
+    { Timed t(c, "tail", level);
+      azk_tail(c->stream, c->h7, d.n7, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom, score, delta,
+               c->pred_u); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -343,6 +341,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         return fail(c, AZ_ERR_INVALID, "az_load_head: null weight pointer");
     if (C <= 0 || (C & 3) || n6 <= 0 || (n6 & 3) || n71 <= 0 || (n71 & 3) || n72 <= 0 || (n72 & 3))
         return fail(c, AZ_ERR_INVALID, "az_load_head: C, n6, n71, n72 must be positive multiples of 4");
+    if (azk_tail_lds_bytes(n71 + n72) > 64 * 1024)
+        return fail(c, AZ_ERR_INVALID, "az_load_head: n71 + n72 too large for the tail kernel's LDS tile");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_all(c);
@@ -360,12 +360,11 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     int rc;
 #define A(p, n) if ((rc = dalloc(c, &c->p, (n))) != AZ_OK) return rc
     A(W6, (size_t)n6 * d.K6); A(b6, n6); A(W7, (size_t)d.n7 * n6); A(b7, d.n7);
-    A(Wt, (size_t)56 * d.n7); A(bt, 56);
+    A(Wt, 64 * azk_tail_weight_rows(d.n7)); A(bt, 64);
     A(pool5, R * d.K6);
     {
-        const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7, pt = (size_t)AZK_TAIL_SPLIT * R * 56;
-        size_t pm = p6 > p7 ? p6 : p7;
-        pm = pm > pt ? pm : pt;
+        const size_t p6 = (size_t)c->S6 * R * n6, p7 = (size_t)c->S7 * R * d.n7;
+        const size_t pm = p6 > p7 ? p6 : p7;
         const size_t pw = (size_t)n6 * d.K6;          // also stages W6 for the column permutation
         A(part, pm > pw ? pm : pw);
     }
@@ -388,13 +387,18 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipMemcpy(c->W7 + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7, b71, (size_t)n71 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7 + n71, b72, (size_t)n72 * 4, hipMemcpyHostToDevice));
-    // epilogue weights: rows 0..10 adj_score, 11..54 adj_bbox (columns 0..n71), row 55
-    // zoom_score (columns n71..n7); everything else zero
-    HIPCHK(c, hipMemset(c->Wt, 0, (size_t)56 * d.n7 * 4));
-    HIPCHK(c, hipMemcpy2D(c->Wt, (size_t)d.n7 * 4, Was, (size_t)n71 * 4, (size_t)n71 * 4, 11, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy2D(c->Wt + (size_t)11 * d.n7, (size_t)d.n7 * 4, Wab, (size_t)n71 * 4, (size_t)n71 * 4, 44,
-                          hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->Wt + (size_t)55 * d.n7 + n71, Wz, (size_t)n72 * 4, hipMemcpyHostToDevice));
+    // tail weights, k-major [n7][64]: outputs 0..10 adj_score, 11..54 adj_bbox (k < n71), output 55
+    // zoom_score (k >= n71); everything else zero
+    {
+        std::vector<float> wt(64 * azk_tail_weight_rows(d.n7), 0.f);
+        for (int o = 0; o < 11; ++o)
+            for (int k = 0; k < n71; ++k) wt[(size_t)k * 64 + o] = Was[(size_t)o * n71 + k];
+        for (int o = 0; o < 44; ++o)
+            for (int k = 0; k < n71; ++k) wt[(size_t)k * 64 + 11 + o] = Wab[(size_t)o * n71 + k];
+        for (int k = 0; k < n72; ++k) wt[(size_t)(n71 + k) * 64 + 55] = Wz[k];
+        HIPCHK(c, hipMemcpy(c->Wt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemset(c->bt, 0, 64 * 4));
     HIPCHK(c, hipMemcpy(c->bt, bas, 11 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt + 11, bab, 44 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt + 55, bz, 4, hipMemcpyHostToDevice));

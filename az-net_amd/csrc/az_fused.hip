@@ -18,27 +18,26 @@ constexpr int LIM_R = 1024;       // regions per fused level
 
 // first-occurrence flags + rank among distinct keys (np.unique semantics) for N <= limit
 // elements whose keys are in LDS.  slot[i] = position of i's key in ascending unique order.
-template <typename GrpFn>
-__device__ void unique_slots(const long long *skey, GrpFn grp, int N, unsigned char *sfirst, int *slot_out,
-                             int *count_out, int *wsum)
+// (Chunked dedup -- test.py:202-218 -- is expressed by the caller folding the chunk number into
+// the key's top bits: equal only inside a chunk, ordered chunk-major.)
+// O(N^2) LDS-broadcast compares; unrolled so the reads of several j are in flight together.
+__device__ void unique_slots(const long long *skey, int N, unsigned char *sfirst, int *slot_out, int *count_out,
+                             int *wsum)
 {
-    for (int i = threadIdx.x; i < N; i += NT) {
+    for (int i = threadIdx.x; i < N; i += (int)blockDim.x) {
         const long long ki = skey[i];
-        const int gi = grp(i);
-        bool dup = false;
-        for (int j = 0; j < i; ++j) dup |= (skey[j] == ki) & (grp(j) == gi);
+        int dup = 0;
+#pragma unroll 8
+        for (int j = 0; j < i; ++j) dup |= (skey[j] == ki);
         sfirst[i] = dup ? 0 : 1;
     }
     __syncthreads();
     int nf = 0;
-    for (int i = threadIdx.x; i < N; i += NT) {
+    for (int i = threadIdx.x; i < N; i += (int)blockDim.x) {
         const long long ki = skey[i];
-        const int gi = grp(i);
         int slot = 0;
-        for (int j = 0; j < N; ++j) {
-            const int gj = grp(j);
-            slot += (sfirst[j] != 0) & ((gj < gi) | ((gj == gi) & (skey[j] < ki)));
-        }
+#pragma unroll 8
+        for (int j = 0; j < N; ++j) slot += (int)sfirst[j] & (int)(skey[j] < ki);
         slot_out[i] = slot;
         nf += sfirst[i];
     }
@@ -76,7 +75,7 @@ k_spec_prepass(AzCounts *cnt, const double *__restrict__ root, double *B1, doubl
     }
     __syncthreads();
     int P1;
-    unique_slots(skey, [](int) { return 0; }, n1, sfirst, sslot, &P1, wsum);
+    unique_slots(skey, n1, sfirst, sslot, &P1, wsum);
     if (P1 > capR) { if (tid == 0) atomicOr(&cnt->err, 1); return; }
     for (int i = tid; i < n1; i += NT)
         if (sfirst[i]) {
@@ -133,7 +132,14 @@ k_spec_prepass(AzCounts *cnt, const double *__restrict__ root, double *B1, doubl
 constexpr int FL_R = 256;         // regions per fused level (LDS-resident)
 constexpr int FL_C = 2048;        // children per fused level
 
-__global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
+#ifdef AZ_FUSED_TIMING
+#define TSTAMP(i) do { __syncthreads(); if (tid == 0) ts[i] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+constexpr int NTL = 256;         // threads of the fused-levels workgroup: levels 1-3 hold <= a few hundred elements per stage,
+                                 // and every stage boundary costs a barrier across all waves
+__global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 {
     __shared__ double sB[2][FL_R * 4];
     __shared__ int ssrc[2][FL_R];
@@ -146,6 +152,11 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
     AzCounts *cnt = a.cnt;
+#ifdef AZ_FUSED_TIMING
+    __shared__ unsigned long long ts[64];
+    int tsn = 0;
+#endif
+    TSTAMP(tsn++);
 
     if (tid == 0) {                                  // lib/detect/test.py:355
         sB[0][0] = 0.0; sB[0][1] = 0.0; sB[0][2] = a.im_w - 1.0; sB[0][3] = a.im_h - 1.0;
@@ -165,15 +176,16 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         }
 
         // ---- roi projection + feature-space dedup (test.py:61-97, 210-218) -------------------
-        for (int r = tid; r < P; r += NT) {
+        for (int r = tid; r < P; r += NTL) {
             float roi5[5];
-            skey[r] = roi_and_key(B + 4 * r, a.scale, a.dedup, roi5);
+            // roi keys are < 1000^5 < 2^50: the dedup chunk number (test.py:202-205) rides above them
+            skey[r] = roi_and_key(B + 4 * r, a.scale, a.dedup, roi5) + ((long long)(r / a.batch) << 50);
         }
         __syncthreads();
+        TSTAMP(tsn++);
         int U;
-        const int batch = a.batch;
-        unique_slots(skey, [batch](int i) { return i / batch; }, P, sfirst, sslot, &U, wsum);
-        for (int i = tid; i < P; i += NT)
+        unique_slots(skey, P, sfirst, sslot, &U, wsum);
+        for (int i = tid; i < P; i += NTL)
             if (sfirst[i]) sidx[sslot[i]] = i;       // index[]: representative of each unique roi
         __syncthreads();
         // speculative row of region r's representative (level 0: the root; 1: 1 + index; 2: carried)
@@ -182,10 +194,11 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
             return l == 0 ? 0 : (l == 1 ? 1 + rep : ssrc[cur][rep]);
         };
 
+        TSTAMP(tsn++);
         // ---- candidates: decode + clip against the representative's box (test.py:106-151), filter,
         //      ordered append to Y / aScores (test.py:171-187, 380-381) ------------------------------
         int run = 0;
-        for (int base = 0; base < P * AZ_NSUB; base += NT) {
+        for (int base = 0; base < P * AZ_NSUB; base += NTL) {
             const int c = base + tid;
             int fl = 0;
             double bx[4];
@@ -213,9 +226,10 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         }
         int nc = run;
         if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0) atomicOr(&cnt->err, 2); }
+        TSTAMP(tsn++);
         // ---- zoom selection (test.py:383-387) -------------------------------------------------------
         int PZ = 0;
-        for (int base = 0; base < P; base += NT) {
+        for (int base = 0; base < P; base += NTL) {
             const int r = base + tid;
             int zf = 0;
             if (r < P) {
@@ -234,9 +248,10 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         __syncthreads();
         if (l + 1 >= a.nlev) return;
 
+        TSTAMP(tsn++);
         // ---- divide_region + _sift_dup (div.pyx:15-89) ---------------------------------------------
         int CH = 0;
-        for (int base = 0; base < PZ; base += NT) {
+        for (int base = 0; base < PZ; base += NTL) {
             const int z = base + tid;
             const int n = z < PZ ? div_nchildren(div_plan(B + 4 * szr[z])) : 0;
             int tot;
@@ -246,7 +261,7 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         }
         if (CH > FL_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
         __syncthreads();
-        for (int z = tid; z < PZ; z += NT) {
+        for (int z = tid; z < PZ; z += NTL) {
             const double *r = B + 4 * szr[z];
             const DivPlan p = div_plan(r);
             const int nb = div_nchildren(p);
@@ -258,10 +273,12 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
             }
         }
         __syncthreads();
+        TSTAMP(tsn++);
         int Pn;
-        unique_slots(skeyC, [](int) { return 0; }, CH, sfirst, sslot, &Pn, wsum);
+        unique_slots(skeyC, CH, sfirst, sslot, &Pn, wsum);
+        TSTAMP(tsn++);
         if (Pn > FL_R || Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
-        for (int i = tid; i < CH; i += NT)
+        for (int i = tid; i < CH; i += NTL)
             if (sfirst[i]) {
                 const int slot = sslot[i];
                 const int z = sczi[i] >> 16, bi = sczi[i] & 0xFFFF;
@@ -275,9 +292,17 @@ __global__ void __launch_bounds__(NT) k_spec_levels(AzFusedArgs a)
         P = Pn;
         __syncthreads();
     }
+    TSTAMP(tsn++);
+#ifdef AZ_FUSED_TIMING
+    if (tid == 0) {
+        printf("spec_levels stamps (x10ns):");
+        for (int i = 1; i < tsn; ++i) printf(" %llu", ts[i] - ts[i - 1]);
+        printf("\n");
+    }
+#endif
     // hand the next level's regions to the multi-workgroup kernels
     const int nxt = a.n_fused & 1;
-    for (int i = tid; i < P * 4; i += NT) a.B[nxt][i] = sB[nxt][i];
+    for (int i = tid; i < P * 4; i += NTL) a.B[nxt][i] = sB[nxt][i];
     if (tid == 0) cnt->P[a.n_fused] = P;
 }
 
@@ -291,5 +316,5 @@ void azk_spec_prepass(hipStream_t s, AzCounts *cnt, const double *root, double *
 
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a)
 {
-    hipLaunchKernelGGL(k_spec_levels, dim3(1), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(k_spec_levels, dim3(1), dim3(NTL), 0, s, a);
 }

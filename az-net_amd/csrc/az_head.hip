@@ -60,6 +60,14 @@ __global__ void k_permute_k(const float *__restrict__ in, float *__restrict__ ou
     }
 }
 
+// Caffe ROIPooling (test_fc.prototxt:14-25).  One workgroup (4 waves) per (roi, bin): the bin's
+// window cells are dealt round-robin to the waves, a lane reads 4 consecutive channels of a cell
+// (float4; the map is channel-last), four cells per wave are in flight together, and the four
+// partial maxima meet in LDS.  A whole-image roi (window ~70 cells) therefore costs ~5 dependent
+// memory round trips instead of 70; a 2x2 window costs one.  max() is exact, so the split does
+// not change a bit of the result.  Launches with many rois take the wave-per-bin path instead.
+constexpr int ROI_POOL_COOP_MAX = 96;      // rois per launch up to which windows are large (levels 1-3)
+
 __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat, AzHeadDims d,
                                                   float spatial_scale, const float *__restrict__ urois,
                                                   const int *Uptr, float *__restrict__ pool5,
@@ -67,12 +75,72 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                                                   int parts, int min_strips)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
+    __shared__ __attribute__((aligned(16))) float spart[4][512];
     const int U = *Uptr;
     // launches that the split-bf16 GEMM will consume get their bf16 terms written here directly
     const bool to_planes = parts > 0 && ((U + 31) >> 5) >= min_strips;
-    const int lane = threadIdx.x & 63;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < U * PP; item += nwaves) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (U > ROI_POOL_COOP_MAX) {
+        // many rois = small windows (a level deep in the tree): one wave per (roi, bin) with all the
+        // channel chunks of a cell in flight; the cooperative form below would idle three waves
+        const int nwaves = (gridDim.x * blockDim.x) >> 6;
+        for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < U * PP; item += nwaves) {
+            const int u = item / PP, p = item - u * PP;
+            const int ph = p / P, pw = p - ph * P;
+            const float *roi = urois + 5 * (size_t)u;
+            const int rsw = (int)roundf(roi[1] * spatial_scale);
+            const int rsh = (int)roundf(roi[2] * spatial_scale);
+            const int rew = (int)roundf(roi[3] * spatial_scale);
+            const int reh = (int)roundf(roi[4] * spatial_scale);
+            int rh = reh - rsh + 1; rh = rh < 1 ? 1 : rh;
+            int rw = rew - rsw + 1; rw = rw < 1 ? 1 : rw;
+            const float bh = (float)rh / (float)P;
+            const float bw = (float)rw / (float)P;
+            int hs = (int)floorf((float)ph * bh) + rsh;
+            int he = (int)ceilf((float)(ph + 1) * bh) + rsh;
+            int ws = (int)floorf((float)pw * bw) + rsw;
+            int we = (int)ceilf((float)(pw + 1) * bw) + rsw;
+            hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
+            ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
+            const bool empty = (he <= hs) || (we <= ws);
+            float *out = pool5 + (size_t)u * d.K6 + (size_t)p * d.C;
+            // up to 8 channel chunks (512 channels) per pass, so 8 independent loads are in flight
+            for (int cb = 0; cb < d.C; cb += 8 * 64) {
+                float m[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = empty ? 0.0f : -FLT_MAX;
+                for (int h = hs; h < he; ++h) {
+                    const float *row = feat + ((size_t)h * d.W + ws) * d.C + cb + lane;
+                    for (int w = ws; w < we; ++w, row += d.C) {
+                        float v[8];
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = (cb + 64 * j + lane < d.C) ? row[64 * j] : -FLT_MAX;
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                    }
+                }
+    #pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (cb + 64 * j + lane < d.C) {
+                        if (!to_planes) {
+                            out[cb + 64 * j + lane] = m[j];
+                        } else {
+                            float x = m[j];
+                            unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane;
+                            for (int q = 0; q < parts; ++q) {
+                                unsigned b = __float_as_uint(x);
+                                b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
+                                po[q * plane_stride] = (unsigned short)(b >> 16);
+                                x -= __uint_as_float(b & 0xFFFF0000u);
+                            }
+                        }
+                    }
+            }
+        }
+        return;
+    }
+    for (int item = blockIdx.x; item < U * PP; item += gridDim.x) {
         const int u = item / PP, p = item - u * PP;
         const int ph = p / P, pw = p - ph * P;
         const float *roi = urois + 5 * (size_t)u;
@@ -91,30 +159,48 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
         ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
         const bool empty = (he <= hs) || (we <= ws);
+        const int nw = we - ws;
+        const int ncell = empty ? 0 : (he - hs) * nw;
         float *out = pool5 + (size_t)u * d.K6 + (size_t)p * d.C;
-        // up to 8 channel chunks (512 channels) per pass, so 8 independent loads are in flight
-        for (int cb = 0; cb < d.C; cb += 8 * 64) {
-            float m[8];
+        for (int cb = 0; cb < d.C; cb += 512) {
+            // channel quads of this lane in the two 256-channel halves (clamped: C % 4 == 0)
+            const int c0 = min(cb + 4 * lane, d.C - 4), c1 = min(cb + 256 + 4 * lane, d.C - 4);
+            float4 m0 = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX), m1 = m0;
+            for (int i = wave; i < ncell; i += 16) {
+                float4 v0[4], v1[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = empty ? 0.0f : -FLT_MAX;
-            for (int h = hs; h < he; ++h) {
-                const float *row = feat + ((size_t)h * d.W + ws) * d.C + cb + lane;
-                for (int w = ws; w < we; ++w, row += d.C) {
-                    float v[8];
+                for (int q = 0; q < 4; ++q) {
+                    const int ii = min(i + 4 * q, ncell - 1);      // a repeated cell cannot change a max
+                    const int hh = ii / nw;
+                    const float *cell = feat + ((size_t)(hs + hh) * d.W + (ws + ii - hh * nw)) * d.C;
+                    v0[q] = *reinterpret_cast<const float4 *>(cell + c0);
+                    v1[q] = *reinterpret_cast<const float4 *>(cell + c1);
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (cb + 64 * j + lane < d.C) ? row[64 * j] : -FLT_MAX;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                for (int q = 0; q < 4; ++q) {
+                    m0.x = v0[q].x > m0.x ? v0[q].x : m0.x; m0.y = v0[q].y > m0.y ? v0[q].y : m0.y;
+                    m0.z = v0[q].z > m0.z ? v0[q].z : m0.z; m0.w = v0[q].w > m0.w ? v0[q].w : m0.w;
+                    m1.x = v1[q].x > m1.x ? v1[q].x : m1.x; m1.y = v1[q].y > m1.y ? v1[q].y : m1.y;
+                    m1.z = v1[q].z > m1.z ? v1[q].z : m1.z; m1.w = v1[q].w > m1.w ? v1[q].w : m1.w;
                 }
             }
+            *reinterpret_cast<float4 *>(&spart[wave][4 * lane]) = m0;
+            *reinterpret_cast<float4 *>(&spart[wave][256 + 4 * lane]) = m1;
+            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (cb + 64 * j + lane < d.C) {
+            for (int half = 0; half < 2; ++half) {
+                const int cc = tid + 256 * half, c = cb + cc;
+                if (c < d.C) {
+                    float m = spart[0][cc];
+                    m = spart[1][cc] > m ? spart[1][cc] : m;
+                    m = spart[2][cc] > m ? spart[2][cc] : m;
+                    m = spart[3][cc] > m ? spart[3][cc] : m;
+                    if (empty) m = 0.0f;
                     if (!to_planes) {
-                        out[cb + 64 * j + lane] = m[j];
+                        out[c] = m;
                     } else {
-                        float x = m[j];
-                        unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane;
+                        float x = m;
+                        unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + c;
                         for (int q = 0; q < parts; ++q) {
                             unsigned b = __float_as_uint(x);
                             b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
@@ -123,6 +209,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                         }
                     }
                 }
+            }
+            __syncthreads();
         }
     }
 }
@@ -403,7 +491,6 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     if (M <= 0) return;
     const int strips = (M + 31) >> 5;
     if (strips > max_strips) return;            // larger launches of this layer run on the split-bf16 kernel
-    const int mt = (strips + 3) >> 2;
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
     // With at least one group per workgroup, a workgroup owns whole groups and walks their
@@ -412,6 +499,11 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     // which the 64-cycle fp32 MFMA hides).  With fewer groups than workgroups (the narrow
     // layers) the (group, m-tile) pairs are spread over workgroups instead.
     const bool mloop = (G >= (int)gridDim.x);
+    // m-tiles: up to 4 strips each; a narrow layer cuts the rows finer, down to single strips, as
+    // long as all (group, m-tile) items still fit the resident workgroups at once -- e.g. 17 strips
+    // x 80 groups: 6 tiles of <= 3 strips (480 items) instead of 5 of <= 4 (400 items on 512 slots)
+    int mt = (strips + 3) >> 2;
+    if (!mloop) mt = max(mt, min(strips, (int)gridDim.x / G));
     const int nitems = mloop ? G : G * mt;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -466,46 +558,119 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
 }
 
 // ======================================================================================
-// Head epilogue.  adj_score (11) + adj_bbox (44) read int7_1, zoom_score (1) reads int7_2
-// (test_fc.prototxt:146-220): the 56 output rows are stacked into one [56, n71+n72] weight
-// block (zero where a row does not read a column; fmaf(x, 0, acc) == acc exactly), so the
-// three layers are one more call of the split-K GEMM above.  This kernel finishes them:
-// slab sum + bias, Sigmoid on the 12 scores (test_fc.prototxt:221-232), then _bbox_pred +
-// _clip_boxes (lib/detect/test.py:106-151) against the roi's own anchor box.
-// One thread per (roi, sub-region) and one per (roi, zoom).
+// Head tail.  adj_score (11) + adj_bbox (44) read int7_1, zoom_score (1) reads int7_2
+// (test_fc.prototxt:146-220): 56 outputs of a [56, n71+n72] weight block (zero where an output
+// does not read a column; fmaf(x, 0, acc) == acc exactly).  That is 72 kFLOP-pairs per roi -- far
+// too little for a matrix-core launch of its own -- so ONE kernel does the products on the vector
+// ALUs and finishes the head: bias, Sigmoid on the 12 scores (test_fc.prototxt:221-232), then
+// _bbox_pred + _clip_boxes (lib/detect/test.py:106-151) against the roi's own anchor box.
+//   workgroup = 16 waves = TAIL_ROWS rois; the int7 rows are staged in LDS; wave w owns the k
+//   range [w*kq, (w+1)*kq), lane o the output o: acc[r] = fmaf(x[r][k], WtT[k][o], acc[r]) for k
+//   ascending (WtT is k-major, so a wave's weight read is one coalesced 256 B line per k and the
+//   x value is an LDS broadcast); out[r][o] = (((p0 + p1) + p2) + ... + p15) + bias[o].
+//   The weight block (327 KB) comes from L2 at ~0.5 us per dependent load: 16 waves x 16 loads in
+//   flight per lane, double-buffered in registers, keep that latency off the critical path.
+// Rows are independent: a roi's bits do not depend on which other rois share the launch.
 // ======================================================================================
 constexpr int NOUT = AZ_NSUB * 5 + 1;   // 56
+constexpr int TAIL_ROWS = 4;
+constexpr int TAIL_WAVES = 16;
+constexpr int TAIL_KB = 16;             // k values per register batch
 
-__global__ void __launch_bounds__(256)
-k_tail_epilogue(const float *__restrict__ part, int capM, int S, const float *__restrict__ bt,
-                const double *__restrict__ ubox, const int *Uptr, int im_h, int im_w, double eps,
-                float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+// Every wave walks the same number of k (a multiple of two register batches): the weight block
+// and the LDS rows are zero-padded to TAIL_WAVES * kq, so the loop has no conditional loads
+// (a guarded load makes the compiler wait for every earlier one) and fmaf(0, 0, acc) == acc.
+static int tail_kq(int n7)
 {
+    const int per = (n7 + TAIL_WAVES - 1) / TAIL_WAVES;
+    return (per + 2 * TAIL_KB - 1) / (2 * TAIL_KB) * (2 * TAIL_KB);
+}
+
+__global__ void __launch_bounds__(TAIL_WAVES * 64)
+k_tail_fused(const float *__restrict__ h7, int n7, int kq, const float *__restrict__ WtT,
+             const float *__restrict__ bt, const double *__restrict__ ubox, const int *Uptr, int im_h, int im_w,
+             double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+{
+    extern __shared__ __attribute__((aligned(16))) float tail_lds[];
+    const int KP = TAIL_WAVES * kq;
+    float *xs = tail_lds;                                  // [TAIL_ROWS][KP]
+    float *ps = tail_lds + (size_t)TAIL_ROWS * KP;         // [TAIL_WAVES][TAIL_ROWS][64], then outs [TAIL_ROWS][64]
     const int U = *Uptr;
-    const int total = U * (AZ_NSUB + 1);
-    const size_t slab = (size_t)capM * NOUT;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int u = idx / (AZ_NSUB + 1), t = idx - u * (AZ_NSUB + 1);
-        const float *row = part + (size_t)u * NOUT;
-        auto out = [&](int o) {
-            float a = row[o];
-            for (int s = 1; s < S; ++s) a += row[o + s * slab];
-            return a + bt[o];
-        };
-        if (t < AZ_NSUB) {
-            // Caffe Sigmoid: 1. / (1. + exp(-x)) -- f32 exp, double divide, f32 store.
-            const float e = expf(-out(t));
-            score_u[(size_t)u * AZ_NSUB + t] = (float)(1.0 / (1.0 + (double)e));
-            float d4[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = wave * kq;
+    auto wload = [&](int k0, float (&w)[TAIL_KB]) {       // rows up to KP + TAIL_KB exist (zero)
+        const float *p = WtT + (size_t)k0 * 64 + lane;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                d4[q] = out(AZ_NSUB + 4 * t + q);
-                delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
+        for (int j = 0; j < TAIL_KB; ++j) w[j] = p[j * 64];
+    };
+    for (int u0 = blockIdx.x * TAIL_ROWS; u0 < U; u0 += gridDim.x * TAIL_ROWS) {
+        const int nr = min(TAIL_ROWS, U - u0);
+        float w0[TAIL_KB], w1[TAIL_KB];
+        wload(kb, w0);                                     // in flight while the rows are staged
+        __syncthreads();
+        for (int i = tid * 4; i < TAIL_ROWS * KP; i += TAIL_WAVES * 64 * 4) {
+            const int r = i / KP, k = i - r * KP;          // KP % 4 == 0 and n7 % 4 == 0
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nr && k < n7) v = *reinterpret_cast<const float4 *>(h7 + (size_t)(u0 + r) * n7 + k);
+            *reinterpret_cast<float4 *>(xs + i) = v;
+        }
+        __syncthreads();
+        float acc[TAIL_ROWS];
+#pragma unroll
+        for (int r = 0; r < TAIL_ROWS; ++r) acc[r] = 0.f;
+        auto fma_batch = [&](int k0, const float (&w)[TAIL_KB]) {
+#pragma unroll
+            for (int j = 0; j < TAIL_KB; j += 4)
+#pragma unroll
+                for (int r = 0; r < TAIL_ROWS; ++r) {
+                    const float4 x = *reinterpret_cast<const float4 *>(xs + r * KP + k0 + j);
+                    acc[r] = fmaf(x.x, w[j + 0], acc[r]);
+                    acc[r] = fmaf(x.y, w[j + 1], acc[r]);
+                    acc[r] = fmaf(x.z, w[j + 2], acc[r]);
+                    acc[r] = fmaf(x.w, w[j + 3], acc[r]);
+                }
+        };
+        for (int k = kb; k < kb + kq; k += 2 * TAIL_KB) {
+            wload(k + TAIL_KB, w1);
+            fma_batch(k, w0);
+            wload(k + 2 * TAIL_KB, w0);                    // past the range on the last turn: never used
+            fma_batch(k + TAIL_KB, w1);
+        }
+#pragma unroll
+        for (int r = 0; r < TAIL_ROWS; ++r) ps[(wave * TAIL_ROWS + r) * 64 + lane] = acc[r];
+        __syncthreads();
+        float v = 0.f;
+        if (tid < TAIL_ROWS * 64) {
+            const int r = tid >> 6;
+            v = ps[r * 64 + lane];
+            for (int w = 1; w < TAIL_WAVES; ++w) v += ps[(w * TAIL_ROWS + r) * 64 + lane];
+            v += lane < NOUT ? bt[lane] : 0.f;
+        }
+        __syncthreads();
+        if (tid < TAIL_ROWS * 64) ps[tid] = v;              // outs[r][o]
+        __syncthreads();
+        if (tid < TAIL_ROWS * (AZ_NSUB + 1)) {
+            const int r = tid / (AZ_NSUB + 1), t = tid - r * (AZ_NSUB + 1);
+            if (r < nr) {
+                const int u = u0 + r;
+                const float *o = ps + r * 64;
+                if (t < AZ_NSUB) {
+                    // Caffe Sigmoid: 1. / (1. + exp(-x)) -- f32 exp, double divide, f32 store.
+                    const float e = expf(-o[t]);
+                    score_u[(size_t)u * AZ_NSUB + t] = (float)(1.0 / (1.0 + (double)e));
+                    float d4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        d4[q] = o[AZ_NSUB + 4 * t + q];
+                        delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
+                    }
+                    az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+                } else {
+                    const float e = expf(-o[NOUT - 1]);
+                    zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
+                }
             }
-            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * AZ_NSUB + t) * 4);
-        } else {
-            const float e = expf(-out(NOUT - 1));
-            zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
         }
     }
 }
@@ -580,7 +745,7 @@ void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spa
                   int min_strips)
 {
     (void)capU;
-    hipLaunchKernelGGL(k_roi_pool, dim3(1024), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
+    hipLaunchKernelGGL(k_roi_pool, dim3(4096), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
                        planes, plane_stride, parts, min_strips);
 }
 
@@ -626,12 +791,23 @@ void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const in
     hipLaunchKernelGGL(k_fc_reduce, dim3(1024), dim3(256), 0, s, part, bias, Mptr, capM, N, S, y, ldy, relu);
 }
 
-void azk_tail_epilogue(hipStream_t s, const float *part, int S, const float *bt, const double *ubox,
-                       const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
-                       float *delta_u, double *pred_u)
+size_t azk_tail_lds_bytes(int n7)
 {
-    hipLaunchKernelGGL(k_tail_epilogue, dim3(256), dim3(256), 0, s, part, capU, S, bt, ubox, Uptr, im_h, im_w,
-                       eps, zoom_u, score_u, delta_u, pred_u);
+    return ((size_t)TAIL_ROWS * TAIL_WAVES * tail_kq(n7) + TAIL_WAVES * TAIL_ROWS * 64) * sizeof(float);
+}
+
+// rows of the k-major, zero-padded weight block [rows][64] the tail kernel reads
+size_t azk_tail_weight_rows(int n7) { return (size_t)TAIL_WAVES * tail_kq(n7) + 2 * TAIL_KB; }
+
+
+void azk_tail(hipStream_t s, const float *h7, int n7, const float *WtT, const float *bt, const double *ubox,
+              const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
+              float *delta_u, double *pred_u)
+{
+    int grid = (capU + TAIL_ROWS - 1) / TAIL_ROWS;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, h7, n7, tail_kq(n7), WtT, bt, ubox, Uptr,
+                       im_h, im_w, eps, zoom_u, score_u, delta_u, pred_u);
 }
 
 void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,

@@ -72,9 +72,15 @@ k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *
             for (int b = tid; b < 2048; b += blockDim.x) hist[b] = 0;
             __syncthreads();
             const unsigned prefix = s_prefix, mask = s_mask;
-            for (int i = tid; i < N; i += blockDim.x) {
-                const unsigned key = score_key(scores[i]);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+            // eight independent (clamped, unconditional) loads in flight per thread, then the atomics
+            for (int base = 0; base < N; base += 8 * (int)blockDim.x) {
+                unsigned k8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) k8[j] = score_key(scores[min(base + j * (int)blockDim.x + tid, N - 1)]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (base + j * (int)blockDim.x + tid < N && (k8[j] & mask) == prefix)
+                        atomicAdd(&hist[(k8[j] >> sh) & (nb - 1)], 1);
             }
             __syncthreads();
             if (tid < 64) {
@@ -108,30 +114,45 @@ k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *
         T = s_prefix;
         need_eq = s_need;
     }
-    if (tid == 0) { s_ngt = 0; s_neq = 0; }
-    __syncthreads();
-    // ordered gather (index order) of keys > T, and of the first need_eq keys == T
-    for (int base = 0; base < N; base += blockDim.x) {
-        const int i = base + tid;
-        unsigned key = 0;
-        int gt = 0, eq = 0;
-        if (i < N) {
-            key = score_key(scores[i]);
-            if (ksel == N) gt = 1;
-            else { gt = key > T; eq = key == T; }
-        }
-        int tot_gt, tot_eq;
-        const int ogt = block_excl_scan1024(gt, &tot_gt, wsum);
-        const int oeq = block_excl_scan1024(eq, &tot_eq, wsum);
-        const int ngt = s_ngt, neq = s_neq;
-        if (gt && ngt + ogt < TOPK_MAX) { skey[ngt + ogt] = key; sidx[ngt + ogt] = i; }
-        __syncthreads();
-        if (tid == 0) { s_ngt = ngt + tot_gt; s_neq = neq + tot_eq; }
-        __syncthreads();
-        // equal keys go after all greater keys: store them at the tail slots [ksel - need_eq, ksel)
-        if (eq && neq + oeq < need_eq) {
-            const int slot = ksel - need_eq + neq + oeq;
-            skey[slot] = key; sidx[slot] = i;
+    // ordered gather (index order) of keys > T, and of the first need_eq keys == T: thread t owns
+    // the contiguous candidates [t*per, (t+1)*per), so ONE pair of block scans places everything
+    const int per = (N + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int i0 = tid * per, i1 = min(N, i0 + per);
+    int cgt = 0, ceq = 0;
+    for (int b0 = i0; b0 < i1; b0 += 8) {
+        unsigned k8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k8[j] = score_key(scores[min(b0 + j, N - 1)]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (b0 + j < i1) {
+                if (ksel == N) cgt += 1;
+                else { cgt += k8[j] > T; ceq += k8[j] == T; }
+            }
+    }
+    int tot_gt, tot_eq;
+    int ogt = block_excl_scan1024(cgt, &tot_gt, wsum);
+    int oeq = block_excl_scan1024(ceq, &tot_eq, wsum);
+    (void)s_ngt; (void)s_neq;
+    for (int b0 = i0; b0 < i1; b0 += 8) {
+        unsigned k8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k8[j] = score_key(scores[min(b0 + j, N - 1)]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = b0 + j;
+            if (i >= i1) continue;
+            const unsigned key = k8[j];
+            const bool gt = (ksel == N) || key > T;
+            const bool eq = (ksel != N) && key == T;
+            if (gt) {
+                if (ogt < TOPK_MAX) { skey[ogt] = key; sidx[ogt] = i; }
+                ++ogt;
+            } else if (eq) {
+                // equal keys go after all greater keys: tail slots [ksel - need_eq, ksel)
+                if (oeq < need_eq) { skey[ksel - need_eq + oeq] = key; sidx[ksel - need_eq + oeq] = i; }
+                ++oeq;
+            }
         }
     }
     __syncthreads();
