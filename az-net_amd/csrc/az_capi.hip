@@ -14,6 +14,9 @@
 
 struct AzEventRec { std::string name; int level; hipEvent_t a, b; };
 
+constexpr size_t RES_HDR = 512;     // AzCounts, padded, at the head of the result block
+static_assert(sizeof(AzCounts) <= RES_HDR, "AzCounts outgrew its slot");
+
 struct az_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -44,7 +47,7 @@ struct az_ctx {
     double *ubox = nullptr, *pred_u = nullptr, *Yall = nullptr, *Z = nullptr, *child = nullptr, *Yout = nullptr;
     float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr;
     float *zoom_u = nullptr, *score_u = nullptr, *delta_u = nullptr, *Sall = nullptr, *Sout = nullptr;
-    int *sel_idx = nullptr;
+    int *sel_idx = nullptr, *rank_part = nullptr;
     // speculative levels 1-3: provenance of zoomed regions / children / regions, head outputs of the pass
     int *zr = nullptr, *csrc = nullptr, *choff_all = nullptr, *srcB[2] = {nullptr, nullptr};
     float *zoom_s = nullptr, *score_s = nullptr, *delta_s = nullptr;
@@ -144,12 +147,18 @@ int ensure_geom(az_ctx *c)
     const size_t R = (size_t)c->maxR, CAND = (size_t)c->maxCand, CH = (size_t)c->maxCh;
     int rc;
 #define A(p, n) if ((rc = dalloc(c, &c->p, (n), true)) != AZ_OK) return rc
-    A(cnt, 1); A(B[0], R * 4); A(B[1], R * 4); A(rois, R * 5); A(urois, R * 5); A(key, R); A(ckey, CH);
+    {   // result block: the counters, then (fixed proposal count) the selected boxes and scores, so that
+        // az_propose_fetch is ONE device-to-host copy
+        unsigned char *blk = nullptr;
+        if ((rc = dalloc(c, &blk, RES_HDR + (size_t)AZ_TOPK_MAX * 36, true)) != AZ_OK) return rc;
+        c->cnt = (AzCounts *)blk;
+    }
+    A(B[0], R * 4); A(B[1], R * 4); A(rois, R * 5); A(urois, R * 5); A(key, R); A(ckey, CH);
     A(grp, R); A(index, R); A(inv, R); A(choff, R); A(bc_c, (R * AZ_NSUB + 255) / 256 + 1);
     A(bc_z, (R * AZ_NSUB + 255) / 256 + 1);
     A(first, CH > R ? CH : R); A(cflag, R * AZ_NSUB); A(zflag, R);
     A(ubox, R * 4); A(pred_u, R * AZ_NSUB * 4); A(Yall, CAND * 4); A(Z, R * 4); A(child, CH * 4);
-    A(Yout, CAND * 4); A(Sout, CAND); A(sel_idx, CAND);
+    A(Yout, CAND * 4); A(Sout, CAND); A(sel_idx, CAND); A(rank_part, (size_t)azk_topk_scratch_ints((int)CAND));
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
@@ -282,7 +291,7 @@ int az_create(int device, az_ctx **out)
     az_ctx *c = new az_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AZ_ERR_HIP; }
-    if (hipHostMalloc((void **)&c->h_cnt, sizeof(AzCounts)) != hipSuccess) { delete c; return AZ_ERR_HIP; }
+    if (hipHostMalloc((void **)&c->h_cnt, RES_HDR + (size_t)AZ_TOPK_MAX * 36) != hipSuccess) { delete c; return AZ_ERR_HIP; }
     *out = c;
     return AZ_OK;
 }
@@ -472,8 +481,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
-    azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);
+    azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
     // Speculative evaluation of levels 1-3.  The root is always divided (test.py:383-384), so
     // level 2's regions are known up front, and level 3's regions are a subset of the children
     // of ALL level-2 regions.  These few dozen rows cost one pass over the 411 MB int6 weights
@@ -563,7 +571,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     { Timed t(c, "select", nlev);
       if (p->fixed_num)
           azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
-                        c->Sall, c->Yout, c->Sout);
+                        c->Sall, (double *)((unsigned char *)c->cnt + RES_HDR),
+                        (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32),
+                        (p->reserved & 8) ? nullptr : c->rank_part);
       else
           azk_thresh_select_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, p->Tc, c->maxCand, c->sel_idx,
                                  &c->cnt->nsel, c->Yall, c->Sall, c->Yout, c->Sout); }
@@ -588,12 +598,13 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
     // With a fixed proposal count the output size is bounded up front: one batched D2H, one sync.
     const int want = c->last.fixed_num ? c->last.num_proposals : -1;
     int rc;
+    const double *hY = nullptr;
+    const float *hS = nullptr;
     if (want > 0) {
-        if ((rc = ensure_host(c, want)) != AZ_OK) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_Y, c->Yout, (size_t)want * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipMemcpyAsync(c->h_S, c->Sout, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, RES_HDR + (size_t)want * 36, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+        hY = (const double *)((const unsigned char *)c->h_cnt + RES_HDR);
+        hS = (const float *)((const unsigned char *)c->h_cnt + RES_HDR + (size_t)want * 32);
     } else {
         HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
@@ -605,6 +616,8 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
             HIPCHK(c, hipMemcpyAsync(c->h_S, c->Sout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
             HIPCHK(c, hipStreamSynchronize(s));
         }
+        hY = c->h_Y;              // (ensure_host may have moved them)
+        hS = c->h_S;
     }
     c->launched = false;
     const AzCounts &h = *c->h_cnt;
@@ -638,8 +651,8 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
     if (st) st->n_proposals = n;
     *n_out = n;
     if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_propose: output capacity too small");
-    std::memcpy(boxes_out, c->h_Y, (size_t)n * 4 * sizeof(double));
-    if (scores_out) std::memcpy(scores_out, c->h_S, (size_t)n * sizeof(float));
+    std::memcpy(boxes_out, hY, (size_t)n * 4 * sizeof(double));
+    if (scores_out) std::memcpy(scores_out, hS, (size_t)n * sizeof(float));
     return AZ_OK;
 }
 
@@ -835,7 +848,7 @@ int az_topk(az_ctx *c, const float *scores, int n, int k, int32_t *idx_out, int 
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (n) HIPCHK(c, hipMemcpyAsync(c->Sall, scores, (size_t)n * 4, hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->scratch[0], n)) != AZ_OK) return rc;
-    azk_topk(s, c->Sall, &c->cnt->scratch[0], c->maxCand, k, c->sel_idx, &c->cnt->nsel);
+    azk_topk(s, c->Sall, &c->cnt->scratch[0], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->rank_part);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const int m = c->h_cnt->nsel;

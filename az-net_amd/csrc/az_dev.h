@@ -156,10 +156,13 @@ void azk_det_gather(hipStream_t s, const int *Pptr, const int *inv, int ncls, co
 // ---- launchers (az_select.hip) ---------------------------------------------------------
 // Top-k by score (descending, ties: lower index first).  With Yall/Sall/Yout/Sout non-NULL the
 // selected boxes/scores are gathered in the same launch.
+// rank_scratch: azk_topk_scratch_ints(capN) ints -> the chip-wide counting kernels do the work (NULL:
+// the single-workgroup radix select); identical results.
 void azk_topk_full(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
-                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout);
+                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout, int *rank_scratch);
 void azk_topk(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
-              int *nsel);
+              int *nsel, int *rank_scratch);
+int azk_topk_scratch_ints(int capN);
 void azk_thresh_select_full(hipStream_t s, const float *scores, const int *Nptr, int capN, double Tc,
                             int cap_out, int *sel_idx, int *nsel, const double *Yall, const float *Sall,
                             double *Yout, float *Sout);

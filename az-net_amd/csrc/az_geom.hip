@@ -12,9 +12,15 @@ constexpr int TB = 256;
 // ----------------------------------------------------------------------------------------
 __global__ void k_init_root(AzCounts *cnt, double *B0, int im_h, int im_w)
 {
-    // lib/detect/test.py:355: B = [[0, 0, W - 1.0, H - 1.0]]
-    cnt->P[0] = 1;
-    B0[0] = 0.0; B0[1] = 0.0; B0[2] = im_w - 1.0; B0[3] = im_h - 1.0;
+    // clears the counters of the previous search (one launch instead of a memset plus this)
+    int *w = reinterpret_cast<int *>(cnt);
+    for (int i = threadIdx.x; i < (int)(sizeof(AzCounts) / sizeof(int)); i += blockDim.x) w[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // lib/detect/test.py:355: B = [[0, 0, W - 1.0, H - 1.0]]
+        cnt->P[0] = 1;
+        B0[0] = 0.0; B0[1] = 0.0; B0[2] = im_w - 1.0; B0[3] = im_h - 1.0;
+    }
 }
 
 // lib/detect/test.py:61-97 (_get_rois_blob: f64 box * scale -> f32) and :212-214 (hash of
@@ -307,7 +313,7 @@ static inline int grid_for(int cap, int per) { int g = (cap + per - 1) / per; re
 
 void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w)
 {
-    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(1), 0, s, cnt, B0, im_h, im_w);
+    hipLaunchKernelGGL(k_init_root, dim3(1), dim3(64), 0, s, cnt, B0, im_h, im_w);
 }
 
 void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,

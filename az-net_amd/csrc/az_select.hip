@@ -44,7 +44,7 @@ constexpr int TOPK_MAX = 4096;
 // order-preserving key (11 + 11 + 10 bits) find the k-th largest key T; everything above T
 // plus the first (k - count_above) items equal to T is gathered in index order, then ranked.
 __global__ void __launch_bounds__(1024)
-k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *sel_idx, int *nsel,
+k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int min_n, int *sel_idx, int *nsel,
        const double *__restrict__ Yall, const float *__restrict__ Sall, double *Yout, float *Sout)
 {
     __shared__ int hist[2048];
@@ -57,6 +57,7 @@ k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *
 
     int N = *Nptr;
     if (N > capN) N = capN;
+    if (min_n > 0 && N <= min_n) return;          // the counting kernels own this size
     if (k > TOPK_MAX) k = TOPK_MAX;
     const int ksel = k < N ? k : N;
     const int tid = threadIdx.x;
@@ -173,6 +174,82 @@ k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int *
         }
     }
     if (tid == 0) *nsel = ksel;
+}
+
+// ---- top-k by counting, across the whole chip ------------------------------------------------
+// rank(i) = number of candidates that sort before i (higher score, or equal score and lower
+// index): the proposal at output position r is the candidate of rank r, so no sort and no
+// select are needed -- only N^2 compares, which 256 CUs finish in a few microseconds for the
+// N <= ~30k of this path.  Workgroup (ib, jb) counts, for its 256 candidates, the earlier-
+// sorting candidates inside j-range jb (keys staged through LDS, read as broadcasts); the
+// RANK_J partial counts of a candidate are summed by the scatter kernel.  Integer work:
+// identical to the radix-select kernel above, bit for bit.
+constexpr int RANK_J = 16;
+constexpr int RANK_TILE = 1024;
+constexpr int RANK_MAX_N = 65536;      // beyond this the single-workgroup radix select takes over
+
+__device__ __forceinline__ unsigned long long rank_comp(float score, int idx)
+{
+    return ((unsigned long long)score_key(score) << 32) | (unsigned)(~(unsigned)idx);
+}
+
+__global__ void __launch_bounds__(256)
+k_rank_count(const float *__restrict__ scores, const int *Nptr, int capN, int *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long sk[RANK_TILE];
+    int N = *Nptr;
+    if (N > capN) N = capN;
+    if (N > RANK_MAX_N) return;
+    const int i0 = blockIdx.x * 256;
+    if (i0 >= N) return;
+    const int i = i0 + threadIdx.x;
+    const unsigned long long ci = i < N ? rank_comp(scores[i], i) : ~0ull;
+    const int jlen = (N + RANK_J - 1) / RANK_J;
+    const int jb = blockIdx.y * jlen, je = min(N, jb + jlen);
+    int cnt = 0;
+    for (int t0 = jb; t0 < je; t0 += RANK_TILE) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < RANK_TILE; q += 256) {
+            const int j = t0 + q;
+            sk[q] = j < je ? rank_comp(scores[j], j) : 0ull;        // 0 sorts after everything
+        }
+        __syncthreads();
+        const int lim = min(RANK_TILE, je - t0);
+        const int lim4 = (lim + 3) & ~3;                             // padding entries are 0: never counted
+#pragma unroll 4
+        for (int q = 0; q < lim4; q += 2) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&sk[q]);
+            cnt += (v.x > ci) ? 1 : 0;
+            cnt += (v.y > ci) ? 1 : 0;
+        }
+    }
+    if (i < N) part[(size_t)blockIdx.y * capN + i] = cnt;
+}
+
+__global__ void __launch_bounds__(256)
+k_rank_scatter(const float *__restrict__ scores, const int *Nptr, int capN, int k, const int *__restrict__ part,
+               int *sel_idx, int *nsel, const double *__restrict__ Yall, const float *__restrict__ Sall,
+               double *Yout, float *Sout)
+{
+    int N = *Nptr;
+    if (N > capN) N = capN;
+    if (N > RANK_MAX_N) return;
+    if (k > TOPK_MAX) k = TOPK_MAX;
+    const int ksel = k < N ? k : N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *nsel = ksel;
+    if (i >= N) return;
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < RANK_J; ++j) r += part[(size_t)j * capN + i];
+    if (r < ksel) {
+        sel_idx[r] = i;
+        if (Yout) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Yout[(size_t)r * 4 + q] = Yall[(size_t)i * 4 + q];
+            Sout[r] = Sall[i];
+        }
+    }
 }
 
 // aScores >= Tc selection (lib/detect/test.py:393-395), original order, double compare.
@@ -350,16 +427,26 @@ __global__ void k_gather_sel(const int *__restrict__ sel_idx, const int *nsel, i
 }  // namespace
 
 // --------------------------------------------------------------------------------------
+int azk_topk_scratch_ints(int capN) { return RANK_J * capN; }
+
 void azk_topk_full(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx,
-                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout)
+                   int *nsel, const double *Yall, const float *Sall, double *Yout, float *Sout, int *rank_scratch)
 {
-    hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, s, scores, Nptr, capN, k, sel_idx, nsel, Yall, Sall,
-                       Yout, Sout);
+    if (rank_scratch) {
+        const int nb = (min(capN, RANK_MAX_N) + 255) / 256;
+        hipLaunchKernelGGL(k_rank_count, dim3(nb, RANK_J), dim3(256), 0, s, scores, Nptr, capN, rank_scratch);
+        hipLaunchKernelGGL(k_rank_scatter, dim3(nb), dim3(256), 0, s, scores, Nptr, capN, k, rank_scratch, sel_idx,
+                           nsel, Yall, Sall, Yout, Sout);
+        if (capN <= RANK_MAX_N) return;           // N can never exceed what the counting kernels take
+    }
+    hipLaunchKernelGGL(k_topk, dim3(1), dim3(1024), 0, s, scores, Nptr, capN, k, rank_scratch ? RANK_MAX_N : 0,
+                       sel_idx, nsel, Yall, Sall, Yout, Sout);
 }
 
-void azk_topk(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx, int *nsel)
+void azk_topk(hipStream_t s, const float *scores, const int *Nptr, int capN, int k, int *sel_idx, int *nsel,
+              int *rank_scratch)
 {
-    azk_topk_full(s, scores, Nptr, capN, k, sel_idx, nsel, nullptr, nullptr, nullptr, nullptr);
+    azk_topk_full(s, scores, Nptr, capN, k, sel_idx, nsel, nullptr, nullptr, nullptr, nullptr, rank_scratch);
 }
 
 void azk_thresh_select_full(hipStream_t s, const float *scores, const int *Nptr, int capN, double Tc,

@@ -60,7 +60,9 @@ typedef struct {
                                  bit 1: keep their geometry as separate launches (same bits);
                                  bit 2: the tuner's variant of the search (lib/detect/tune.py:
                                  256-316): K levels instead of K-1, Tz applied from the second
-                                 level on, root not forced, anchor history kept (az_last_anchors) */
+                                 level on, root not forced, anchor history kept (az_last_anchors);
+                                 bit 3: final top-k by the single-workgroup radix select instead of
+                                 the chip-wide counting kernels (same result; for tests)          */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */

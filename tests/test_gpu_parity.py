@@ -312,6 +312,24 @@ def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
             assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
 
 
+def test_topk_kernels_agree(small, mods):
+    """Final selection: chip-wide counting kernels vs the single-workgroup radix select."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    net.set_conv(synth.make_feature_map(5, synth.SMALL_DIMS["C"], 38, 63))
+    for k in (1, 300, 2000, 4096):
+        a = net.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k), want_scores=True)
+        b = net.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k, radix_select=True),
+                        want_scores=True)
+        assert a[0].shape == (k, 4) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    rng = np.random.RandomState(2)
+    for n in (1, 255, 256, 257, 5000, 40000):
+        sc = rng.uniform(0, 1, n).astype(np.float32)
+        sc[::5] = sc[0]                                      # ties: lower index first
+        got = net.ctx.topk(sc, 300)
+        assert np.array_equal(got, np.argsort(-sc, kind="stable")[:300])
+
+
 def test_threshold_mode(small, mods):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
