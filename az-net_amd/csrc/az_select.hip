@@ -184,7 +184,7 @@ k_topk(const float *__restrict__ scores, const int *Nptr, int capN, int k, int m
 // sorting candidates inside j-range jb (keys staged through LDS, read as broadcasts); the
 // RANK_J partial counts of a candidate are summed by the scatter kernel.  Integer work:
 // identical to the radix-select kernel above, bit for bit.
-constexpr int RANK_J = 16;
+constexpr int RANK_J = 32;
 constexpr int RANK_TILE = 1024;
 constexpr int RANK_MAX_N = 65536;      // beyond this the single-workgroup radix select takes over
 

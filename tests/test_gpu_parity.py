@@ -209,7 +209,8 @@ def _oracle_loop_on_gpu_head(orc, net, fmap, H, W, scale, cfg):
 
 @pytest.mark.parametrize("H,W,tzq,batch", [(600, 1000, 0.0, 10000), (375, 500, 0.55, 10000),
                                            (480, 640, 0.4, 10000), (640, 853, 0.5, 100),
-                                           (600, 1000, 1.5, 10000)])
+                                           (600, 1000, 1.5, 10000),
+                                           (800, 1200, 0.0, 10000)])        # BASELINE config 4: deep tree, K = 7
 def test_fused_loop_equals_per_level_loop(small, mods, H, W, tzq, batch):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
