@@ -248,6 +248,18 @@ def test_tune_thresh_end_to_end_vs_heap(small, mods, tmp_path):
         for per_img in (3, 50, 10 ** 5):
             cfg.TRAIN.ANCHORS_PER_IMG = per_img
             got = U.tune_thresh({"full": net, "fc": net}, db)
+            # the multi-GPU form: two "ranks" tune disjoint shards, rank 0 merges the per-rank top scores
+            db.shard = [1, 3]
+            ctx = net.ctx
+            ctx.tune_begin(2 * 2 * ctx.max_regions)
+            for i in db.shard:
+                U._search(net, db.image_at(i))
+            other_top = ctx.tune_top(5 * per_img)
+            ctx.tune_end()
+            db.shard = [0, 2, 4]
+            merged = U.tune_thresh({"full": net, "fc": net}, db, gather=lambda top: [top, other_top])
+            db.shard = None
+            assert merged == got
             lists = []
             for i in range(5):
                 _, Bhis = U.im_propose(net, db.image_at(i))

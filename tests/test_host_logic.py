@@ -85,3 +85,74 @@ def test_ffi_struct_layout_matches_header():
     assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, num_proposals=300, batch_size=1000, speculate=False)
     assert (p.im_h, p.im_w, p.Tz, p.batch_size, p.fixed_num, p.reserved) == (600, 1000, 0.3, 1000, 1, 1)
+
+
+def _make_voc_tree(root, year="2007"):
+    """A two-image VOCdevkit<year> tree: ImageSets/Main/test.txt, Annotations/*.xml, JPEGImages/*.jpg."""
+    from PIL import Image
+    base = os.path.join(root, "VOCdevkit" + year, "VOC" + year)
+    for d in ("ImageSets/Main", "Annotations", "JPEGImages"):
+        os.makedirs(os.path.join(base, d))
+    with open(os.path.join(base, "ImageSets", "Main", "test.txt"), "w") as f:
+        f.write("000001\n000002\n\n")
+    objs = {"000001": [("dog", 48, 240, 195, 371), ("person", 8, 12, 352, 498)],
+            "000002": [("Train ", 139, 200, 207, 301)]}
+    rng = np.random.RandomState(0)
+    for idx, lst in objs.items():
+        xml = "<annotation><filename>%s.jpg</filename>" % idx
+        for name, x1, y1, x2, y2 in lst:
+            xml += ("<object><name>%s</name><difficult>0</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin>"
+                    "<xmax>%d</xmax><ymax>%d</ymax></bndbox></object>" % (name, x1, y1, x2, y2))
+        xml += "</annotation>"
+        with open(os.path.join(base, "Annotations", idx + ".xml"), "w") as f:
+            f.write(xml)
+        Image.fromarray(rng.randint(0, 256, (60, 80, 3)).astype(np.uint8)).save(
+            os.path.join(base, "JPEGImages", idx + ".jpg"), quality=95)
+    return os.path.join(root, "VOCdevkit" + year)
+
+
+def test_pascal_voc_reader(tmp_path):
+    """Index file, image paths, 0-based uint16 boxes and class ids as lib/datasets/pascal_voc.py:50-143."""
+    import datasets
+    from datasets.pascal_voc import pascal_voc, VOC_CLASSES
+    devkit = _make_voc_tree(str(tmp_path))
+    db = pascal_voc("test", "2007", devkit_path=devkit)
+    assert db.name == "voc_2007_test" and db.num_classes == 21 and db.image_index == ["000001", "000002"]
+    assert db.image_path_at(1).endswith(os.path.join("JPEGImages", "000002.jpg"))
+    roidb = db.gt_roidb(use_cache=False)
+    assert roidb[0]["boxes"].dtype == np.uint16
+    assert roidb[0]["boxes"].tolist() == [[47, 239, 194, 370], [7, 11, 351, 497]]
+    assert roidb[0]["gt_classes"].tolist() == [VOC_CLASSES.index("dog"), VOC_CLASSES.index("person")]
+    assert roidb[1]["gt_classes"].tolist() == [VOC_CLASSES.index("train")]       # lower().strip()
+    im = db.image_at(0)
+    assert im.shape == (60, 80, 3) and im.dtype == np.uint8
+    from PIL import Image
+    rgb = np.asarray(Image.open(db.image_path_at(0)).convert("RGB"))
+    assert np.array_equal(im, rgb[:, :, ::-1])                                    # BGR, as cv2.imread
+    with pytest.raises(IOError):
+        pascal_voc("val", "2007", devkit_path=devkit)                             # no such image set file
+    assert "voc_2007_test" in datasets.factory.list_imdbs()
+
+
+def test_evaluate_recall_host_math():
+    """imdb.evaluate_recall around the matching: skipped images, ignored classes, curve and AR
+    (lib/datasets/imdb.py:120-159), with the oracle standing in for the GPU matching call."""
+    from datasets.imdb import imdb
+    from oracle import az_oracle as orc
+    from helpers import load
+    g = load("g10_recall.npz")
+    n = int(g["n_img"])
+
+    class Db(imdb):
+        def gt_roidb(self):
+            return [{"boxes": g["gt%d" % i], "gt_classes": g["cls%d" % i]} for i in range(n)]
+
+    class FakeCtx(object):
+        def recall_match(self, cands, gts):
+            return orc.recall_gt_overlaps(cands, gts)
+
+    db = Db("golden")
+    db._image_index = list(range(n))
+    ar, gt_overlaps, recalls, thresholds = db.evaluate_recall([g["cand%d" % i] for i in range(n)], ctx=FakeCtx())
+    assert ar == float(g["ar"]) and np.array_equal(gt_overlaps, g["gt_overlaps"])
+    assert np.array_equal(recalls, g["recalls"]) and np.array_equal(thresholds, g["thresholds"])
