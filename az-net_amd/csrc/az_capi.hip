@@ -1019,6 +1019,57 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
 }
 
 // --------------------------------------------------------------------------------------
+// apply_nms (lib/detect/test.py:467-484) calls nms once per class per image: n_groups independent
+// problems, here in one call.  Groups of up to 256 boxes (all of them, at that call site) share ONE
+// launch, a workgroup each; larger groups go through az_nms one by one.
+int az_nms_batched(az_ctx *c, const float *dets, const int32_t *offsets, int n_groups, double thresh,
+                   int64_t *keep, int32_t *n_keep)
+{
+    if (!c || n_groups < 0 || (n_groups && (!offsets || !n_keep)))
+        return fail(c, AZ_ERR_INVALID, "az_nms_batched: bad arguments");
+    if (n_groups == 0) return AZ_OK;
+    const int total = offsets[n_groups];
+    std::vector<int> small, large;
+    for (int g = 0; g < n_groups; ++g) {
+        const int n = offsets[g + 1] - offsets[g];
+        if (n < 0) return fail(c, AZ_ERR_INVALID, "az_nms_batched: offsets must ascend");
+        n_keep[g] = 0;
+        if (n == 0) continue;
+        (n <= azk_nms_small_max() ? small : large).push_back(g);
+    }
+    if (total > 0 && (!dets || !keep)) return fail(c, AZ_ERR_INVALID, "az_nms_batched: NULL array");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (!small.empty()) {
+        int rc;
+        if ((rc = ev_grow(c, 0, &c->ev_a, (size_t)total * 5 * sizeof(float))) != AZ_OK) return rc;
+        if ((rc = ev_grow(c, 1, &c->ev_b, ((size_t)n_groups + 1) * sizeof(int))) != AZ_OK) return rc;
+        if ((rc = ev_grow(c, 2, &c->ev_c, small.size() * sizeof(int))) != AZ_OK) return rc;
+        if ((rc = ev_grow(c, 3, &c->ev_d, (size_t)total * sizeof(long long))) != AZ_OK) return rc;
+        if ((rc = ev_grow(c, 4, &c->ev_e, (size_t)n_groups * sizeof(int))) != AZ_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->ev_a, dets, (size_t)total * 5 * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->ev_b, offsets, ((size_t)n_groups + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->ev_c, small.data(), small.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemsetAsync(c->ev_e, 0, (size_t)n_groups * sizeof(int), s));
+        azk_nms_small(s, (const float *)c->ev_a, (const int *)c->ev_b, (const int *)c->ev_c, (int)small.size(), thresh,
+                      (long long *)c->ev_d, (int *)c->ev_e);
+        std::vector<long long> hk((size_t)total);
+        HIPCHK(c, hipMemcpyAsync(hk.data(), c->ev_d, (size_t)total * sizeof(long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(n_keep, c->ev_e, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));           // `small`, `hk` live on this frame
+        HIPCHK(c, hipGetLastError());
+        for (int g : small)
+            for (int k = 0; k < n_keep[g]; ++k) keep[offsets[g] + k] = hk[(size_t)offsets[g] + k];
+    }
+    for (int g : large) {
+        int nk = 0;
+        int rc = az_nms(c, dets + 5 * (size_t)offsets[g], offsets[g + 1] - offsets[g], thresh, keep + offsets[g], &nk);
+        if (rc) return rc;
+        n_keep[g] = nk;
+    }
+    return AZ_OK;
+}
+
 // --------------------------------------------------------------------------------------
 // Tuner (lib/detect/tune.py): anchor history and the global k-th largest zoom score.
 int az_last_anchors(az_ctx *c, double *regions_out, float *zoom_out, int cap, int *n_out)

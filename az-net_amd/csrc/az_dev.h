@@ -170,6 +170,11 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
                     const float *Sall, double *Yout, float *Sout);
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
              unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep);
+// many groups of <= azk_nms_small_max() boxes in one launch: group g = dets[goff[g] .. goff[g+1]); gsel lists
+// the groups to process; keep[goff[g] ..] gets the kept group-local indices, nkeep[g] their number
+void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
+                   long long *keep, int *nkeep);
+int azk_nms_small_max();
 #define AZ_TOPK_MAX 4096
 
 // ---- launchers (az_eval.hip): front-end, recall evaluation, threshold tuner ----------------

@@ -410,6 +410,79 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     if (threadIdx.x == 0) *nkeep = s_nk;
 }
 
+// ---- many small NMS problems in one launch (apply_nms: one per class per image) ---------------
+// One workgroup per group of n <= NMS_SMALL boxes; rank sort, suppression bit matrix and greedy scan
+// all in LDS.  Same arithmetic, same order conventions as the three kernels above.
+constexpr int NMS_SMALL = 256;
+
+__global__ void __launch_bounds__(256)
+k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const int *__restrict__ gsel,
+            double thresh, long long *__restrict__ keep, int *__restrict__ nkeep)
+{
+    __shared__ float sd[NMS_SMALL][5];                     // sorted: x1, y1, x2, y2, area
+    __shared__ int sorder[NMS_SMALL];
+    __shared__ float ss[NMS_SMALL];
+    __shared__ unsigned long long smask[NMS_SMALL][NMS_SMALL / 64];
+    const int g = gsel[blockIdx.x];
+    const int o = goff[g], n = goff[g + 1] - o;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *d = dets + 5 * (size_t)o;
+    const int i = tid;
+    const float si = i < n ? d[5 * i + 4] : 0.f;
+    ss[tid] = si;
+    __syncthreads();
+    if (i < n) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float sj = ss[j];
+            rank += (sj > si) | ((sj == si) & (j > i));
+        }
+        const float x1 = d[5 * i], y1 = d[5 * i + 1], x2 = d[5 * i + 2], y2 = d[5 * i + 3];
+        float w = x2 - x1; w = w + 1.0f;
+        float h = y2 - y1; h = h + 1.0f;
+        sorder[rank] = i;
+        sd[rank][0] = x1; sd[rank][1] = y1; sd[rank][2] = x2; sd[rank][3] = y2; sd[rank][4] = w * h;
+    }
+    __syncthreads();
+    const int W = (n + 63) >> 6;
+    // suppression words: wave handles rows wave, wave + 4, ...; lane = column inside the 64-word
+    for (int r = wave; r < n; r += 4) {
+        const float ix1 = sd[r][0], iy1 = sd[r][1], ix2 = sd[r][2], iy2 = sd[r][3], iarea = sd[r][4];
+        for (int cb = 0; cb < W; ++cb) {
+            const int j = cb * 64 + lane;
+            bool sup = false;
+            if (j < n && j > r) {
+                const float jx1 = sd[j][0], jy1 = sd[j][1], jx2 = sd[j][2], jy2 = sd[j][3], jarea = sd[j][4];
+                const float xx1 = ix1 >= jx1 ? ix1 : jx1;
+                const float yy1 = iy1 >= jy1 ? iy1 : jy1;
+                const float xx2 = ix2 <= jx2 ? ix2 : jx2;
+                const float yy2 = iy2 <= jy2 ? iy2 : jy2;
+                float tw = xx2 - xx1; tw = tw + 1.0f;
+                float th = yy2 - yy1; th = th + 1.0f;
+                const float w = 0.0f >= tw ? 0.0f : tw;
+                const float h = 0.0f >= th ? 0.0f : th;
+                const float inter = w * h;
+                float den = iarea + jarea; den = den - inter;
+                const float ovr = inter / den;
+                sup = ((double)ovr >= thresh);
+            }
+            const unsigned long long word = __ballot(sup);
+            if (lane == 0) smask[r][cb] = word;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {                                         // greedy scan over <= 256 sorted boxes
+        unsigned long long removed[NMS_SMALL / 64] = {0ull, 0ull, 0ull, 0ull};
+        int nk = 0;
+        for (int r = 0; r < n; ++r) {
+            if ((removed[r >> 6] >> (r & 63)) & 1ull) continue;
+            keep[o + nk++] = sorder[r];
+            for (int w = r >> 6; w < W; ++w) removed[w] |= smask[r][w];
+        }
+        nkeep[g] = nk;
+    }
+}
+
 __global__ void k_gather_sel(const int *__restrict__ sel_idx, const int *nsel, int cap,
                              const double *__restrict__ Yall, const float *__restrict__ Sall, double *Yout,
                              float *Sout)
@@ -461,6 +534,15 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
                     const float *Sall, double *Yout, float *Sout)
 {
     hipLaunchKernelGGL(k_gather_sel, dim3(64), dim3(256), 0, s, sel_idx, nsel, cap, Yall, Sall, Yout, Sout);
+}
+
+int azk_nms_small_max() { return NMS_SMALL; }
+
+void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
+                   long long *keep, int *nkeep)
+{
+    if (n_sel > 0)
+        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(256), 0, s, dets, goff, gsel, thresh, keep, nkeep);
 }
 
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,

@@ -30,7 +30,7 @@ SYMBOLS = [
     "az_last_kernel_times", "az_stream", "az_load_det_head", "az_det_forward", "az_detect",
     "az_set_gemm_mode", "az_last_anchors", "az_tune_begin", "az_tune_end", "az_tune_kth_largest",
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
-    "az_image_blob_host", "az_image_blob_dev",
+    "az_image_blob_host", "az_image_blob_dev", "az_nms_batched",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library(path=None):
     L.az_decode_filter.argtypes = [vp, dp, fp, fp, ci, ci, ci, cd, cd, dp, fp, ci, cip]
     L.az_topk.argtypes = [vp, fp, ci, ci, ip, cip]
     L.az_nms.argtypes = [vp, fp, ci, cd, i64p, cip]
+    L.az_nms_batched.argtypes = [vp, fp, ip, ci, cd, i64p, ip]
     L.az_load_det_head.argtypes = [vp, ci, ci, ci, ci] + [fp] * 8
     L.az_det_forward.argtypes = [vp, fp, ci, fp, fp]
     L.az_detect.argtypes = [vp, dp, ci, cd, cd, ci, ci, ci, cd, fp, dp]
@@ -376,6 +377,21 @@ class AzContext(object):
         return keep[:n.value].copy()
 
     # ---- Fast R-CNN head on the shared map -----------------------------------------------
+    def nms_batched(self, dets_list, thresh):
+        """NMS of many independent box sets ([n_g,5] float32 each) in one call -> list of keep index
+        arrays (what apply_nms, lib/detect/test.py:467-484, needs per class per image)."""
+        n = len(dets_list)
+        off = np.zeros(n + 1, dtype=np.int32)
+        for g, d in enumerate(dets_list):
+            off[g + 1] = off[g] + d.shape[0]
+        allb = _f32(np.vstack([np.zeros((0, 5), np.float32)] + [np.asarray(d, dtype=np.float32).reshape(-1, 5)
+                                                                   for d in dets_list]))
+        keep = np.zeros(max(int(off[n]), 1), dtype=np.int64)
+        nk = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.L.az_nms_batched(self.h, _p(allb, ctypes.c_float), _p(off, ctypes.c_int32), n, float(thresh),
+                                        _p(keep, ctypes.c_int64), _p(nk, ctypes.c_int32)))
+        return [keep[off[g]:off[g] + nk[g]].copy() for g in range(n)]
+
     def load_det_head(self, head):
         """head: dict of Caffe-layout fp32 arrays W6,b6 (fc6), W7,b7 (fc7), Wc,bc (cls_score),
         Wb,bb (bbox_pred)."""

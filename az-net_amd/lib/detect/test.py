@@ -154,19 +154,25 @@ def im_detect_shared(az_net, frcnn_net, im, num_classes):
 
 
 def apply_nms(all_boxes, thresh):
-    """Per-class, per-image NMS over detections (test.py:467-484)."""
+    """Per-class, per-image NMS over detections (test.py:467-484).  The reference calls nms once per
+    (class, image); here all of them go to the GPU in one az_nms_batched call."""
     num_classes = len(all_boxes)
     num_images = len(all_boxes[0])
     nms_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    where, sets = [], []
     for cls_ind in range(num_classes):
         for im_ind in range(num_images):
             dets = all_boxes[cls_ind][im_ind]
             if isinstance(dets, list) and dets == []:
                 continue
-            keep = nms(np.ascontiguousarray(dets, dtype=np.float32), thresh)
+            where.append((cls_ind, im_ind))
+            sets.append(np.ascontiguousarray(dets, dtype=np.float32))
+    if sets:
+        keeps = ffi.default_context().nms_batched(sets, float(thresh))
+        for (cls_ind, im_ind), keep in zip(where, keeps):
             if len(keep) == 0:
                 continue
-            nms_boxes[cls_ind][im_ind] = dets[keep, :].copy()
+            nms_boxes[cls_ind][im_ind] = all_boxes[cls_ind][im_ind][keep, :].copy()
     return nms_boxes
 
 

@@ -164,6 +164,12 @@ int az_topk(az_ctx *ctx, const float *scores, int n, int k, int32_t *idx_out, in
  * indices in descending-score order.  The reference's call site is apply_nms
  * (lib/detect/test.py:467-484); it is NOT on the proposal path. */
 int az_nms(az_ctx *ctx, const float *dets, int n, double thresh, int64_t *keep, int *n_keep);
+/* The call site itself, apply_nms (lib/detect/test.py:467-484): one nms per class per image, i.e.
+ * many small independent problems.  Group g owns dets[offsets[g] .. offsets[g+1]) (rows of 5 f32);
+ * keep[offsets[g] ..] receives its kept group-local indices (descending score), n_keep[g] their
+ * number.  Groups of <= 256 boxes share one launch (a workgroup each). */
+int az_nms_batched(az_ctx *ctx, const float *dets, const int32_t *offsets, int n_groups, double thresh,
+                   int64_t *keep, int32_t *n_keep);
 
 /* ---- Fast R-CNN head on the shared conv map (BASELINE config 3) ---------------------- */
 /* Replaces caffe.Net(frcnn/test_fc.prototxt, caffemodel) (tools/test_shared.py): the detection

@@ -109,6 +109,31 @@ def test_nms_golden(small):
         assert list(keep) == list(g["keep%d" % i]), "nms case %d" % i
 
 
+def test_nms_batched_equals_single_calls(small, mods):
+    """az_nms_batched (one workgroup per small group, LDS-resident) == az_nms per group == oracle."""
+    ffi, synth, HipAZNet, orc = mods
+    ctx = small[0].ctx
+    rng = np.random.RandomState(17)
+    sets = []
+    for n in [0, 1, 2, 63, 64, 65, 100, 255, 256, 257, 300, 1000] + [int(v) for v in rng.randint(1, 200, 80)]:
+        x1 = rng.uniform(0, 300, n); y1 = rng.uniform(0, 300, n)
+        d = np.stack([x1, y1, x1 + rng.uniform(5, 150, n), y1 + rng.uniform(5, 150, n), rng.uniform(0, 1, n)], 1)
+        d = d.astype(np.float32)
+        if n > 4:
+            d[3] = d[1]                                   # duplicate box, equal score (tie order)
+            d[4, :4] = d[0, :4]
+        sets.append(d)
+    for thresh in (0.3, 0.5):
+        got = ctx.nms_batched(sets, thresh)
+        for d, k in zip(sets, got):
+            assert list(k) == list(ctx.nms(d, thresh))
+            # (equal scores: NumPy's argsort order is unspecified, so the oracle only judges the tie-free sets)
+            u = d.copy()
+            u[:, 4] = (np.argsort(np.argsort(d[:, 4], kind="stable"), kind="stable") + 1) / float(max(len(d), 1))
+            assert list(ctx.nms_batched([u], thresh)[0]) == list(orc.nms(u, thresh))
+    assert ctx.nms_batched([], 0.5) == []
+
+
 def test_topk_vs_numpy(small):
     ctx = small[0].ctx
     rng = np.random.RandomState(5)
