@@ -243,6 +243,7 @@ static int gemm_grid()
 }
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // Operand tiles are fetched with buffer loads: one descriptor per operand tile (wave-uniform,
 // SGPRs), a per-thread byte offset per row that never changes during the K loop (rows past the
@@ -291,16 +292,25 @@ __device__ __forceinline__ void mtile_rows(int strips, int mt, int t, int &strip
 //   * the ds_read_b128 fragment loads of the next 8-wide k group are issued before the current
 //     group's MFMAs (sched_barrier fences keep the compiler from clustering all reads first);
 //   * one barrier per K-step.
-template <int NRT>
+// HALF: the tile ends with a 16-row half strip (rows NRT*32 .. NRT*32+15) for the <= 16 rows a launch
+// has past its last full strip.  It runs on v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of a
+// padded 32-row strip -- fed so that its accumulation chain is the 32x32x2 one: per 8-wide k group two
+// instructions, k slots (0,4,1,5) then (2,6,3,7) (both instructions are bitwise sequential fmaf
+// chains over their k slots: dev/mfma_f32_16x16x4_probe.hip), so a row's bits do not depend on which
+// kind of strip it lands in.
+template <int NRT, bool HALF>
 __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
                                         int ldw, int M, int N, int m0, int n0, int k0, int kend,
                                         float *__restrict__ slab, float (*sA)[BM * LDT], float (*sB)[BN * LDT])
 {
+    static_assert(!HALF || NRT <= 3, "the half strip lives in the tile's fourth strip of LDS rows");
+    constexpr int NLA = NRT + (HALF ? 1 : 0);    // activation float4s per thread per K-step
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lk = (lane >> 5) * 4;
     const int nk = (kend - k0 + BK - 1) / BK;
+    floatx4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
     floatx16 acc[NRT];
 #pragma unroll
@@ -314,26 +324,55 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     // descriptors start at the tile's first row; per-thread row offsets are loop-invariant
     const __amdgpu_buffer_rsrc_t rsA = tile_rsrc(X + (size_t)m0 * ldx, (size_t)(M - m0) * ldx);
     const __amdgpu_buffer_rsrc_t rsB = tile_rsrc(Wt + (size_t)n0 * ldw, (size_t)(N - n0) * ldw);
-    unsigned voA[NRT], voB[4];
+    unsigned voA[NLA], voB[4];
 #pragma unroll
     for (int i = 0; i < NRT; ++i) voA[i] = (unsigned)((min(srow + 32 * i, M - 1 - m0) * ldx + sc4) * 4);
+    // half strip: 16 rows x 8 float4 -- threads t and t + 128 stage the same vector (same value, same place)
+    if constexpr (HALF) voA[NRT] = (unsigned)((min(NRT * 32 + (srow & 15), M - 1 - m0) * ldx + sc4) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) voB[i] = (unsigned)((min(srow + 32 * i, N - 1 - n0) * ldw + sc4) * 4);
-    auto gload = [&](int kt, float4 (&ra)[NRT], float4 (&rb)[4]) {
+    auto gload = [&](int kt, float4 (&ra)[NLA], float4 (&rb)[4]) {
         const unsigned so = (unsigned)(k0 + kt * BK) * 4u;
 #pragma unroll
-        for (int i = 0; i < NRT; ++i) ra[i] = buf_ld(rsA, voA[i], so);
+        for (int i = 0; i < NLA; ++i) ra[i] = buf_ld(rsA, voA[i], so);
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[i] = buf_ld(rsB, voB[i], so);
     };
-    auto lstore = [&](int kt, int buf, const float4 (&ra)[NRT], const float4 (&rb)[4]) {
+    auto lstore = [&](int kt, int buf, const float4 (&ra)[NLA], const float4 (&rb)[4]) {
         const bool ok = (k0 + kt * BK + sc4) < kend;
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
             *reinterpret_cast<float4 *>(&sA[buf][(srow + 32 * i) * LDT + sc4]) = zero_tail(ra[i], ok);
+        if constexpr (HALF)
+            *reinterpret_cast<float4 *>(&sA[buf][(NRT * 32 + (srow & 15)) * LDT + sc4]) = zero_tail(ra[NRT], ok);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<float4 *>(&sB[buf][(srow + 32 * i) * LDT + sc4]) = zero_tail(rb[i], ok);
+    };
+    // half-strip fragments of one 8-wide k group: lane = (row or column lane & 15, k slot lane >> 4);
+    // slot s feeds k = {0,4,1,5}[s] to the first instruction and k + 2 to the second
+    struct HalfFrag { float a1, a2, b1[2], b2[2]; };
+    const int hk = ((lane >> 4) & 1) * 4 + (lane >> 5);
+    const float *ha_base = &sA[0][(NRT * 32 + (lane & 15)) * LDT + hk];
+    const float *hb_base = &sB[0][(wave * 32 + (lane & 15)) * LDT + hk];
+    auto hfrag = [&](int buf, int g8, HalfFrag &f) {
+        if constexpr (HALF) {
+            const float *pa = ha_base + buf * (BM * LDT) + g8 * 8;
+            f.a1 = pa[0]; f.a2 = pa[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *pb = hb_base + buf * (BN * LDT) + h * 16 * LDT + g8 * 8;
+                f.b1[h] = pb[0]; f.b2[h] = pb[2];
+            }
+        }
+    };
+    auto hmfma = [&](const HalfFrag &f) {
+        if constexpr (HALF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acch[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b1[h], acch[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acch[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2, f.b2[h], acch[h], 0, 0, 0);
+        }
     };
     const float *a_base = &sA[0][lrow * LDT + lk];
     const float *b_base = &sB[0][(wave * 32 + lrow) * LDT + lk];
@@ -355,7 +394,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].w, bf.w, acc[r], 0, 0, 0);
     };
     static_assert(BK == 32, "the step bodies below are written for four 8-wide k groups");
-    float4 ra0[NRT], rb0[4], ra1[NRT], rb1[4];
+    float4 ra0[NLA], rb0[4], ra1[NLA], rb1[4];
     gload(0, ra0, rb0);
     gload(nk > 1 ? 1 : 0, ra1, rb1);
     __syncthreads();                 // the previous work item's readers are done with both buffers
@@ -370,18 +409,26 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         // instructions are interleaved one per MFMA issue slot (sched_group_barrier).
         //   a0/a1 hold the fragments of k groups 0/1 of tile kt on entry.
         float4 a0[NRT], a1[NRT], b0, b1;
+        HalfFrag h0, h1;
         frag(0, 0, a0, b0);
         frag(0, 1, a1, b1);
-        auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
+        hfrag(0, 0, h0);
+        hfrag(0, 1, h1);
+        // with a half strip every phase has 4 more (short) MFMAs and up to 6 more 4-byte DS reads
+        constexpr int HM = HALF ? 4 : 0, HD = HALF ? 3 : 0;
+        auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
             __builtin_amdgcn_sched_barrier(0);
             // group 0 MFMAs | request tile kt+2 | fragments of group 2
             gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
             float4 a2[NRT], b2;
+            HalfFrag h2;
             frag(buf, 2, a2, b2);
+            hfrag(buf, 2, h2);
             mfma8(a0, b0);
+            hmfma(h0);
 #pragma unroll
-            for (int i = 0; i < NRT + 4; ++i) {
+            for (int i = 0; i < NLA + 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
             }
@@ -390,15 +437,23 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (2 * NRT + 5), 0);
+#pragma unroll
+            for (int i = 0; i < HD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, 0);
             __builtin_amdgcn_sched_barrier(0);
             // group 1 MFMAs | tile kt+1 -> LDS[buf^1] | fragments of group 3
             lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
             float4 a3[NRT], b3;
+            HalfFrag h3;
             frag(buf, 3, a3, b3);
+            hfrag(buf, 3, h3);
             mfma8(a1, b1);
+            hmfma(h1);
 #pragma unroll
-            for (int i = 0; i < NRT + 4; ++i) {
+            for (int i = 0; i < NLA + 4; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 1);   // 1 DS write
             }
@@ -407,29 +462,48 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (2 * NRT + 5), 1);
+#pragma unroll
+            for (int i = 0; i < HD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, 1);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();         // LDS[buf^1] (tile kt+1) complete; everyone's reads of LDS[buf] issued
             __builtin_amdgcn_sched_barrier(0);
             // group 2 MFMAs | fragments of group 0 of tile kt+1
             frag(buf ^ 1, 0, a0, b0);
+            hfrag(buf ^ 1, 0, h0);
             mfma8(a2, b2);
+            hmfma(h2);
 #pragma unroll
             for (int i = 0; i < NRT + 1; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (NRT + 1), 2);
+#pragma unroll
+            for (int i = 0; i < HD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 2);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NRT + 1) - HD, 2);
             __builtin_amdgcn_sched_barrier(0);
             // group 3 MFMAs | fragments of group 1 of tile kt+1
             frag(buf ^ 1, 1, a1, b1);
+            hfrag(buf ^ 1, 1, h1);
             mfma8(a3, b3);
+            hmfma(h3);
 #pragma unroll
             for (int i = 0; i < NRT + 1; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 3);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT - (NRT + 1), 3);
+#pragma unroll
+            for (int i = 0; i < HD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 3);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NRT + 1) - HD, 3);
             __builtin_amdgcn_sched_barrier(0);
         };
         for (int kt = 0; kt < nk; kt += 2) {
@@ -439,26 +513,35 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     } else {
         // Weight-streaming-bound shape (<= 64 rows): what matters is bytes in flight, not MFMA
         // density.  MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 and write tile kt+1.
-        auto step = [&](int kt, int buf, float4 (&rl_a)[NRT], float4 (&rl_b)[4], const float4 (&rw_a)[NRT],
+        auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
             float4 a0[NRT], a1[NRT], b0, b1;
+            HalfFrag h0, h1;
             frag(buf, 0, a0, b0);
+            hfrag(buf, 0, h0);
             gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
             __builtin_amdgcn_sched_barrier(0);
             frag(buf, 1, a1, b1);
+            hfrag(buf, 1, h1);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(a0, b0);
+            hmfma(h0);
             __builtin_amdgcn_sched_barrier(0);
             frag(buf, 2, a0, b0);
+            hfrag(buf, 2, h0);
             lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
             __builtin_amdgcn_sched_barrier(0);
             mfma8(a1, b1);
+            hmfma(h1);
             __builtin_amdgcn_sched_barrier(0);
             frag(buf, 3, a1, b1);
+            hfrag(buf, 3, h1);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(a0, b0);
+            hmfma(h0);
             __builtin_amdgcn_sched_barrier(0);
             mfma8(a1, b1);
+            hmfma(h1);
             __syncthreads();
         };
         for (int kt = 0; kt < nk; kt += 2) {
@@ -478,19 +561,31 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 if (row < M) slab[(size_t)row * N + col] = acc[r][e];
             }
     }
+    if constexpr (HALF) {
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hcol = n0 + wave * 32 + 16 * h + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + NRT * 32 + 4 * (lane >> 4) + e;
+                if (hcol < N && row < M) slab[(size_t)row * N + hcol] = acch[h][e];
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256, 2)
 k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
-            const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part, int max_strips)
+            const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part, int max_strips,
+            int half_enabled)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
 
     const int M = *Mptr;
     if (M <= 0) return;
-    const int strips = (M + 31) >> 5;
-    if (strips > max_strips) return;            // larger launches of this layer run on the split-bf16 kernel
+    if (((M + 31) >> 5) > max_strips) return;   // larger launches of this layer run on the split-bf16 kernel
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
     // With at least one group per workgroup, a workgroup owns whole groups and walks their
@@ -502,8 +597,30 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     // m-tiles: up to 4 strips each; a narrow layer cuts the rows finer, down to single strips, as
     // long as all (group, m-tile) items still fit the resident workgroups at once -- e.g. 17 strips
     // x 80 groups: 6 tiles of <= 3 strips (480 items) instead of 5 of <= 4 (400 items on 512 slots)
-    int mt = (strips + 3) >> 2;
-    if (!mloop) mt = max(mt, min(strips, (int)gridDim.x / G));
+    auto tiles_for = [&](int st) {
+        int t = (st + 3) >> 2;
+        if (!mloop) t = max(t, min(st, (int)gridDim.x / G));
+        return t;
+    };
+    int strips = (M + 31) >> 5;
+    int mt = tiles_for(strips);
+    // <= 16 rows past the last full strip: the last m-tile takes them as a half strip (16x16x4 MFMA),
+    // which needs that tile to have <= 3 full strips (one more tile if it would have 4)
+    // (group-owned m loops only: for the narrow layers one longer item per group would set the pace.)
+    // If the balanced split would end in a 1- or 2-strip tile (the weight-streaming code path), the
+    // strips are dealt front-loaded instead -- e.g. 4 strips + half as (3, 1+half), not (2, 2+half).
+    bool half_last = false, front = false;
+    if (half_enabled && mloop && (M & 31) && (M & 31) <= 16 && (M >> 5) >= 1) {
+        const int st2 = M >> 5;
+        int mt2 = tiles_for(st2), s0, nrt_last;
+        mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
+        if (nrt_last == 4) {
+            ++mt2;
+            mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
+            front = nrt_last < 3;
+        }
+        strips = st2; mt = mt2; half_last = true;
+    }
     const int nitems = mloop ? G : G * mt;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -516,14 +633,26 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         const int t_lo = mloop ? 0 : item - g * mt, t_hi = mloop ? mt : t_lo + 1;
         for (int mtile = t_lo; mtile < t_hi; ++mtile) {
             int strip0, n_rt;                            // live 32-row strips (workgroup-uniform)
-            mtile_rows(strips, mt, mtile, strip0, n_rt);
+            if (!front) mtile_rows(strips, mt, mtile, strip0, n_rt);
+            else if (mtile < mt - 1) mtile_rows(strips - 1, mt - 1, mtile, strip0, n_rt);
+            else { strip0 = strips - 1; n_rt = 1; }
             const int m0 = strip0 * 32;
-            switch (n_rt) {
-            case 1: fc_tile<1>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
-            case 2: fc_tile<2>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
-            case 3: fc_tile<3>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
-            default: fc_tile<4>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB); break;
+#define FC_TILE(NRT_, HALF_) fc_tile<NRT_, HALF_>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB)
+            if (half_last && mtile == mt - 1) {
+                switch (n_rt) {
+                case 1: FC_TILE(1, true); break;
+                case 2: FC_TILE(2, true); break;
+                default: FC_TILE(3, true); break;
+                }
+            } else {
+                switch (n_rt) {
+                case 1: FC_TILE(1, false); break;
+                case 2: FC_TILE(2, false); break;
+                case 3: FC_TILE(3, false); break;
+                default: FC_TILE(4, false); break;
+                }
             }
+#undef FC_TILE
         }
     }
 }
@@ -778,8 +907,10 @@ static int fc_chunk(int K, int S)
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
                  int N, int K, int S, float *part, int max_strips)
 {
+    static int half = -1;                  // AZ_GEMM_HALF=0: pad the last rows to a full strip instead (measurements)
+    if (half < 0) { const char *e = getenv("AZ_GEMM_HALF"); half = e ? atoi(e) : 1; }
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
-                       fc_chunk(K, S), part, max_strips);
+                       fc_chunk(K, S), part, max_strips, half);
 }
 
 int azk_fc_chunk(int K, int S) { return fc_chunk(K, S); }
