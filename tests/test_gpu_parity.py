@@ -224,6 +224,29 @@ def test_head_rows_independent_of_batch(small, mods):
     assert np.array_equal(z[100:170], z2) and np.array_equal(p[100:170], p2) and np.array_equal(d[100:170], d2)
 
 
+@pytest.mark.parametrize("which", ["small", "full"])
+def test_head_rows_same_bits_in_full_half_and_padded_strips(small, full, mods, which):
+    """A roi's outputs must not depend on where the launch's row count puts it: a full 32-row strip
+    (32x32x2 MFMA), the 16-row half strip at the end (16x16x4 MFMA) or a padded last strip."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small if which == "small" else full
+    C = synth.SMALL_DIMS["C"] if which == "small" else 512
+    net.set_conv(synth.make_feature_map(3, C, 38, 63))
+    rois = _rand_rois(np.random.RandomState(10), 300, 1000, 600)
+    ref = net.ctx.head_forward(rois)                       # 300 rows = 9 strips + 12 rows (half strip)
+    sizes = list(range(1, 70)) + [95, 96, 97, 112, 113, 128, 129, 130, 144, 145, 160, 161, 177, 193, 256, 257, 288, 289]
+    if which == "full":
+        sizes = [1, 31, 33, 40, 48, 49, 64, 65, 80, 81, 96, 100, 130, 145, 161, 257, 289]
+    for n in sizes:
+        got = net.ctx.head_forward(rois[:n])
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b[:n]), n
+        lo = max(0, 300 - n)
+        got = net.ctx.head_forward(rois[lo:])              # the same rois at other row positions
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b[lo:]), n
+
+
 # ---------------------------------------------------------------- whole loop
 def _oracle_loop_on_gpu_head(orc, net, fmap, H, W, scale, cfg):
     """The oracle's level loop with the HIP head injected as the pycaffe-shaped net --
