@@ -236,11 +236,9 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
     { Timed t(c, "fc7_gemm", level, 1);
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
-    { Timed t(c, "fc7_reduce", level);
-      azk_fc_reduce(c->stream, c->part, c->b7, Uptr, c->maxR, d.n7, c->S7, c->h7, d.n7, 1); }
-    { Timed t(c, "tail", level);
-      azk_tail(c->stream, c->h7, d.n7, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom, score, delta,
-               c->pred_u); }
+    { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
+      azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom,
+               score, delta, c->pred_u); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.

@@ -135,13 +135,14 @@ int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xp
                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu);
-// adj_score + adj_bbox + zoom_score (56 outputs) + bias + sigmoid + box decode/clip in one launch
+// int7_1|int7_2's slab sum + bias + ReLU, then adj_score + adj_bbox + zoom_score (56 outputs) + bias +
+// sigmoid + box decode/clip, in one launch
 // (vector-ALU products, see az_head.hip).  WtT is the stacked weight block k-major, zero-padded:
 // [azk_tail_weight_rows(n71+n72)][64].
 #define AZK_TAIL_SPLIT 8      /* k-chunks of the Fast R-CNN head's cls_score|bbox_pred GEMM */
-void azk_tail(hipStream_t s, const float *h7, int n7, const float *WtT, const float *bt, const double *ubox,
-              const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
-              float *delta_u, double *pred_u);
+void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
+              const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
+              float *score_u, float *delta_u, double *pred_u);
 size_t azk_tail_lds_bytes(int n7);
 size_t azk_tail_weight_rows(int n7);
 int azk_fc_split(int K);

@@ -693,7 +693,8 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
 // too little for a matrix-core launch of its own -- so ONE kernel does the products on the vector
 // ALUs and finishes the head: bias, Sigmoid on the 12 scores (test_fc.prototxt:221-232), then
 // _bbox_pred + _clip_boxes (lib/detect/test.py:106-151) against the roi's own anchor box.
-//   workgroup = 16 waves = TAIL_ROWS rois; the int7 rows are staged in LDS; wave w owns the k
+//   workgroup = 16 waves = TAIL_ROWS rois; the int7 rows are staged in LDS (finishing int7_1|int7_2 on the
+//   way: slab sum + bias + ReLU); wave w owns the k
 //   range [w*kq, (w+1)*kq), lane o the output o: acc[r] = fmaf(x[r][k], WtT[k][o], acc[r]) for k
 //   ascending (WtT is k-major, so a wave's weight read is one coalesced 256 B line per k and the
 //   x value is an LDS broadcast); out[r][o] = (((p0 + p1) + p2) + ... + p15) + bias[o].
@@ -716,9 +717,10 @@ static int tail_kq(int n7)
 }
 
 __global__ void __launch_bounds__(TAIL_WAVES * 64)
-k_tail_fused(const float *__restrict__ h7, int n7, int kq, const float *__restrict__ WtT,
-             const float *__restrict__ bt, const double *__restrict__ ubox, const int *Uptr, int im_h, int im_w,
-             double eps, float *zoom_u, float *score_u, float *delta_u, double *pred_u)
+k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float *__restrict__ b7, int n7, int kq,
+             const float *__restrict__ WtT, const float *__restrict__ bt, const double *__restrict__ ubox,
+             const int *Uptr, int im_h, int im_w, double eps, float *zoom_u, float *score_u, float *delta_u,
+             double *pred_u)
 {
     extern __shared__ __attribute__((aligned(16))) float tail_lds[];
     const int KP = TAIL_WAVES * kq;
@@ -740,8 +742,21 @@ k_tail_fused(const float *__restrict__ h7, int n7, int kq, const float *__restri
         __syncthreads();
         for (int i = tid * 4; i < TAIL_ROWS * KP; i += TAIL_WAVES * 64 * 4) {
             const int r = i / KP, k = i - r * KP;          // KP % 4 == 0 and n7 % 4 == 0
+            // int7 = ReLU(sum of the K-chunk slabs in chunk order + bias): k_fc_reduce's arithmetic, done
+            // here while staging (saves a launch; 8 slabs x 5 KB per roi)
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nr && k < n7) v = *reinterpret_cast<const float4 *>(h7 + (size_t)(u0 + r) * n7 + k);
+            if (r < nr && k < n7) {
+                const float *p = part7 + (size_t)(u0 + r) * n7 + k;
+                v = *reinterpret_cast<const float4 *>(p);
+                for (int sl = 1; sl < S7; ++sl) {
+                    const float4 t = *reinterpret_cast<const float4 *>(p + sl * slab7);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                const float4 bb = *reinterpret_cast<const float4 *>(b7 + k);
+                v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
             *reinterpret_cast<float4 *>(xs + i) = v;
         }
         __syncthreads();
@@ -931,14 +946,15 @@ size_t azk_tail_lds_bytes(int n7)
 size_t azk_tail_weight_rows(int n7) { return (size_t)TAIL_WAVES * tail_kq(n7) + 2 * TAIL_KB; }
 
 
-void azk_tail(hipStream_t s, const float *h7, int n7, const float *WtT, const float *bt, const double *ubox,
-              const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u, float *score_u,
-              float *delta_u, double *pred_u)
+void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
+              const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
+              float *score_u, float *delta_u, double *pred_u)
 {
     int grid = (capU + TAIL_ROWS - 1) / TAIL_ROWS;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, h7, n7, tail_kq(n7), WtT, bt, ubox, Uptr,
-                       im_h, im_w, eps, zoom_u, score_u, delta_u, pred_u);
+    hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, part7, S7,
+                       (size_t)capU * n7, b7, n7, tail_kq(n7), WtT, bt, ubox, Uptr, im_h, im_w, eps, zoom_u, score_u,
+                       delta_u, pred_u);
 }
 
 void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,
