@@ -89,6 +89,8 @@ def main():
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 2-images-in-flight measurement")
     ap.add_argument("--no-fast", action="store_true", help="skip the extra split-bf16 (gemm_mode 2) measurement")
+    ap.add_argument("--no-calibrated", action="store_true",
+                    help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
     args = ap.parse_args()
 
@@ -299,6 +301,32 @@ def main():
                          "product, fp32 accumulate)",
                 "note": "opt-in; scores / box deltas stay within 1e-5 of the fp32 path (tolerance 1e-4)"}
         del nf
+    # ---- a data-dependent tree: Tz = the median zoom score over the full tree's regions ----------
+    if not args.no_calibrated:
+        net.propose(ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), 0.0, num_proposals=NUM_PROPOSALS, tune=True))
+        zz = net.ctx.last_anchors()[1].astype(np.float64)
+        n3 = int(sum(regions[:3]))                      # root + its children + their children
+        tz_c = float(np.quantile(zz[1:n3], 0.5))        # (untrained weights: scores drift with region size,
+                                                        #  so the threshold is set where the tree branches)
+        pc = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), tz_c, num_proposals=NUM_PROPOSALS)
+        Yc, stc = net.propose(pc, want_stats=True)
+        for _ in range(5):
+            net.propose(pc)
+        barrier()
+        n_c = max(10, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n_c):
+            net.propose(pc)
+        barrier()
+        dc = time.perf_counter() - t0
+        if rank == 0:
+            out["calibrated_tz"] = {
+                "Tz": tz_c, "value": world * Yc.shape[0] * n_c / dc, "unit": "proposals/s",
+                "ms_per_image": dc / n_c * 1e3,
+                "regions_per_level": [int(stc.level_regions[l]) for l in range(stc.n_levels)],
+                "unique_per_level": [int(stc.level_unique[l]) for l in range(stc.n_levels)],
+                "note": "same image and weights, zoom threshold at the median zoom score of the regions of levels "
+                        "2-3: a partially expanded, data-dependent tree"}
     # ---- backbone + hot path, for context (not `value`) -----------------------------------
     if not args.no_e2e:
         for _ in range(3):
