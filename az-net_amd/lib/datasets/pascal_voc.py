@@ -54,12 +54,12 @@ class pascal_voc(imdb):
         return p
 
     def gt_roidb(self, use_cache=True):
-        cache = os.path.join(self.cache_path, self.name + "_gt_roidb.pkl")
-        if use_cache and os.path.exists(cache):
+        cache = os.path.join(self.cache_path, self.name + "_gt_roidb.pkl") if use_cache else None
+        if cache and os.path.exists(cache):
             with open(cache, "rb") as f:
                 return pickle.load(f)
         roidb = [self._load_annotation(ix) for ix in self._image_index]
-        if use_cache:
+        if cache:
             with open(cache, "wb") as f:
                 pickle.dump(roidb, f, pickle.HIGHEST_PROTOCOL)
         return roidb
