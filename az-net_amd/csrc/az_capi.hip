@@ -479,7 +479,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     hipStream_t s = c->stream;
-    azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
+
     // Speculative evaluation of levels 1-3.  The root is always divided (test.py:383-384), so
     // level 2's regions are known up front, and level 3's regions are a subset of the children
     // of ALL level-2 regions.  These few dozen rows cost one pass over the 411 MB int6 weights
@@ -496,10 +496,11 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
     // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
     const bool fused = n_spec && !(p->reserved & 2) && !(p->im_h == c->nofuse_h && p->im_w == c->nofuse_w);
+    if (!fused) azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
     if (fused) {
         Timed t(c, "spec_prepass", -1);
         azk_spec_prepass(s, c->cnt, c->B[0], c->B[1], c->child, c->choff_all, c->urois, p->scale, p->min_side,
-                         c->maxR, c->maxCh);
+                         c->maxR, c->maxCh, p->im_h, p->im_w);
     } else if (n_spec) {
         Timed t(c, "spec_geometry", -1);
         // children of the root -> B1 (with _sift_dup), exactly what level 1's divide will produce

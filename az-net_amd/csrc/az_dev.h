@@ -106,8 +106,9 @@ struct AzFusedArgs {
     int batch, im_h, im_w, nlev, n_fused, capR, capCh, capCand;
 };
 
-void azk_spec_prepass(hipStream_t s, AzCounts *cnt, const double *root, double *B1, double *child, int *choff_all,
-                      float *urois, double scale, double min_side, int capR, int capCh);
+// (also clears the counters and writes the root region: it is the first kernel of a fused search)
+void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
+                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w);
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
 
 // ---- launchers (az_head.hip) -----------------------------------------------------------

@@ -53,9 +53,19 @@ __device__ void unique_slots(const long long *skey, int N, unsigned char *sfirst
 // (without _sift_dup, offsets in choff_all), and the rois of S = [root ; B1 ; children].
 // ==========================================================================================
 __global__ void __launch_bounds__(NT)
-k_spec_prepass(AzCounts *cnt, const double *__restrict__ root, double *B1, double *child, int *choff_all,
-               float *urois, double scale, double min_side, int capR, int capCh)
+k_spec_prepass(AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
+               float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w)
 {
+    // first kernel of a search: clear the previous search's counters and write the root region
+    // (lib/detect/test.py:355) -- what k_init_root does on the multi-launch path
+    {
+        int *w = reinterpret_cast<int *>(cnt);
+        for (int i = threadIdx.x; i < (int)(sizeof(AzCounts) / sizeof(int)); i += blockDim.x) w[i] = 0;
+        if (threadIdx.x == 0) { root[0] = 0.0; root[1] = 0.0; root[2] = im_w - 1.0; root[3] = im_h - 1.0; }
+        __syncthreads();
+        if (threadIdx.x == 0) cnt->P[0] = 1;
+        __syncthreads();
+    }
     __shared__ long long skey[LIM_R];
     __shared__ unsigned char sfirst[LIM_R];
     __shared__ int sslot[LIM_R];
@@ -307,11 +317,11 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-void azk_spec_prepass(hipStream_t s, AzCounts *cnt, const double *root, double *B1, double *child, int *choff_all,
-                      float *urois, double scale, double min_side, int capR, int capCh)
+void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
+                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w)
 {
     hipLaunchKernelGGL(k_spec_prepass, dim3(1), dim3(NT), 0, s, cnt, root, B1, child, choff_all, urois, scale,
-                       min_side, capR, capCh);
+                       min_side, capR, capCh, im_h, im_w);
 }
 
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a)
