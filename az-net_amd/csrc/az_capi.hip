@@ -533,12 +533,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
-        { Timed t(c, "rois_keys", l);
-          azk_rois_keys(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
-                        c->grp); }
-        { Timed t(c, "dedup_rois", l);
-          azk_dedup_rois(s, c->key, c->grp, Pptr, c->maxR, c->first, c->rois, c->B[cur], c->index, c->inv,
-                         c->urois, c->ubox, Uptr); }
+        { Timed t(c, "rois_dedup", l);
+          azk_rois_dedup(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
+                         c->grp, c->first, c->index, c->inv, c->urois, c->ubox, Uptr); }
         if (l < n_spec) {
             Timed t(c, "spec_lookup", l);
             azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
@@ -747,9 +744,8 @@ int az_roi_dedup(az_ctx *c, const double *boxes, int P, double scale, double ded
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
-    azk_rois_keys(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp);
-    azk_dedup_rois(s, c->key, c->grp, &c->cnt->P[0], c->maxR, c->first, c->rois, c->B[0], c->index, c->inv,
-                   c->urois, c->ubox, &c->cnt->U[0]);
+    azk_rois_dedup(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp,
+                   c->first, c->index, c->inv, c->urois, c->ubox, &c->cnt->U[0]);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const int U = c->h_cnt->U[0];
@@ -1004,9 +1000,8 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
-    azk_rois_keys(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp);
-    azk_dedup_rois(s, c->key, c->grp, &c->cnt->P[0], c->maxR, c->first, c->rois, c->B[0], c->index, c->inv,
-                   c->urois, c->ubox, &c->cnt->U[0]);
+    azk_rois_dedup(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp,
+                   c->first, c->index, c->inv, c->urois, c->ubox, &c->cnt->U[0]);
     launch_det_head(c, &c->cnt->U[0], im_h, im_w, eps);
     azk_det_gather(s, &c->cnt->P[0], c->inv, c->det_ncls, c->dprob_u, c->dpred_u, c->dprob, c->dpred);
     HIPCHK(c, hipStreamSynchronize(s));

@@ -65,6 +65,9 @@ static __device__ __forceinline__ void az_decode_box(const double *anchor, const
 void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w);
 void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
                    int batch, float *rois, long long *key, int *grp);
+void azk_rois_dedup(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup, int batch,
+                    float *rois, long long *key, int *grp, unsigned char *first, int *index, int *inv, float *urois,
+                    double *ubox, int *Uptr);
 void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const int *Nptr, int cap,
                     unsigned char *first, const float *rois, const double *B, int *index, int *inv,
                     float *urois, double *ubox, int *Uptr);

@@ -58,6 +58,35 @@ __global__ void k_first(const long long *__restrict__ key, const int *__restrict
     }
 }
 
+// k_rois_keys and k_first in one launch for the roi dedup: a wave derives the keys it compares against
+// from the regions themselves (a key is four multiplies and roundings), so there is no grid-wide
+// dependency on a key array; it also stores its own element's roi / key / chunk id for k_dedup_rois.
+__global__ void k_first_rois(const double *__restrict__ B, const int *Pptr, double scale, float dedup, int batch,
+                             float *rois, long long *key, int *grp, unsigned char *first)
+{
+    const int P = *Pptr;
+    const int lane = lane_id();
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < P; i += nwaves) {
+        float roi5[5];
+        const long long ki = roi_and_key(B + 4 * (size_t)i, scale, dedup, roi5);
+        const int gi = i / batch;                      // dedup is per BATCH_SIZE chunk (test.py:195-218)
+        if (lane == 0) { key[i] = ki; grp[i] = gi; }
+        if (lane < 5) rois[5 * (size_t)i + lane] = roi5[lane];
+        bool dup = false;
+        for (int j0 = gi * batch; j0 < i; j0 += 64) {  // only the same chunk can hold a duplicate
+            const int j = j0 + lane;
+            if (j < i) {
+                float r5[5];
+                dup |= (roi_and_key(B + 4 * (size_t)j, scale, dedup, r5) == ki);
+            }
+            if (__any(dup)) break;
+        }
+        const bool any_dup = __any(dup);               // vote with all lanes active
+        if (lane == 0) first[i] = any_dup ? 0 : 1;
+    }
+}
+
 // slot[i] = number of distinct (grp, key) pairs ordered before i's pair = position of i's
 // pair in np.unique's ascending output.  Same wave-per-element scheme, ballot + popcount.
 __device__ __forceinline__ int dedup_slot(const long long *__restrict__ key, const int *__restrict__ grp,
@@ -224,9 +253,15 @@ __global__ void k_compact(AzCounts *cnt, int level, int capCand, const double *_
 }
 
 // ----------------------------------------------------------------------------------------
-// Single workgroup: children per parent + exclusive scan -> child offsets, total in *CHptr.
-__global__ void __launch_bounds__(1024) k_divide_scan(const int *PZptr, int *CHptr, int *err, int capCh,
-                                                      const double *__restrict__ Z, int *choff)
+// divide_region of every parent in ONE single-workgroup launch: children per parent + exclusive scan ->
+// child offsets (total in *CHptr), then the children themselves (a few hundred parents at most on this
+// path: a thread emits the <= 11 children of its parents).  With `src_off` the children also get a
+// provenance id *src_base + src_add + src_off[zr ? zr[z] : z] + child index (speculative levels).
+__global__ void __launch_bounds__(1024) k_divide(const int *PZptr, int *CHptr, int *err, int capCh,
+                                                 const double *__restrict__ Z, int *choff, double min_side,
+                                                 double *child, long long *ckey, const int *__restrict__ src_off,
+                                                 const int *__restrict__ zr, const int *src_base, int src_add,
+                                                 int *csrc)
 {
     __shared__ int wsum[17];
     const int PZ = *PZptr;
@@ -243,22 +278,14 @@ __global__ void __launch_bounds__(1024) k_divide_scan(const int *PZptr, int *CHp
         if (z < PZ) choff[z] = running + ex;
         running += tot;
     }
-    if (threadIdx.x == 0) {
-        if (running > capCh) { atomicOr(err, 4); running = 0; }
-        *CHptr = running;
+    if (running > capCh) {
+        if (threadIdx.x == 0) { atomicOr(err, 4); *CHptr = 0; }
+        return;
     }
-}
-
-// Children of every parent.  With `src_off` the children also get a provenance id
-// *src_base + src_off[zr ? zr[z] : z] + child index (used by the speculative levels).
-__global__ void k_divide_emit(const int *PZptr, const int *CHptr, const double *__restrict__ Z,
-                              const int *__restrict__ choff, double min_side, double *child, long long *ckey,
-                              const int *__restrict__ src_off, const int *__restrict__ zr, const int *src_base,
-                              int src_add, int *csrc)
-{
-    const int PZ = *PZptr;
-    if (*CHptr == 0) return;
-    for (int z = blockIdx.x * blockDim.x + threadIdx.x; z < PZ; z += gridDim.x * blockDim.x) {
+    if (threadIdx.x == 0) *CHptr = running;
+    if (running == 0) return;
+    __syncthreads();                                   // choff[] of other threads' parents
+    for (int z = threadIdx.x; z < PZ; z += blockDim.x) {
         const double *r = Z + 4 * (size_t)z;
         const DivPlan p = div_plan(r);
         if (!p.num_long) continue;
@@ -323,6 +350,17 @@ void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, dou
                        rois, key, grp);
 }
 
+// roi projection + feature-space dedup of one level in two launches (keys + first occurrences, then slots)
+void azk_rois_dedup(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup, int batch,
+                    float *rois, long long *key, int *grp, unsigned char *first, int *index, int *inv, float *urois,
+                    double *ubox, int *Uptr)
+{
+    const int g = grid_for(cap, TB / 64);      // one wave per element
+    hipLaunchKernelGGL(k_first_rois, dim3(g), dim3(TB), 0, s, B, Pptr, scale, dedup, batch, rois, key, grp, first);
+    hipLaunchKernelGGL(k_dedup_rois, dim3(g), dim3(TB), 0, s, key, grp, Pptr, first, rois, B, index, inv,
+                       urois, ubox, Uptr);
+}
+
 void azk_dedup_rois(hipStream_t s, const long long *key, const int *grp, const int *Nptr, int cap,
                     unsigned char *first, const float *rois, const double *B, int *index, int *inv,
                     float *urois, double *ubox, int *Uptr)
@@ -349,9 +387,9 @@ void azk_divide(hipStream_t s, const int *PZptr, int *CHptr, int *err, int capR,
                 double min_side, int *choff, double *child, long long *ckey, const int *src_off, const int *zr,
                 const int *src_base, int src_add, int *csrc)
 {
-    hipLaunchKernelGGL(k_divide_scan, dim3(1), dim3(1024), 0, s, PZptr, CHptr, err, capCh, Z, choff);
-    hipLaunchKernelGGL(k_divide_emit, dim3(grid_for(capR, TB)), dim3(TB), 0, s, PZptr, CHptr, Z, choff, min_side,
-                       child, ckey, src_off, zr, src_base, src_add, csrc);
+    (void)capR;
+    hipLaunchKernelGGL(k_divide, dim3(1), dim3(1024), 0, s, PZptr, CHptr, err, capCh, Z, choff, min_side, child, ckey,
+                       src_off, zr, src_base, src_add, csrc);
 }
 
 void azk_dedup_regions(hipStream_t s, const long long *key, const int *Nptr, int cap, int capOut,

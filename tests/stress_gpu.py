@@ -51,6 +51,11 @@ def main():
         ok = (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(Ya, Yb) and
               np.array_equal(Sa, Sb) and a[2].num_eval == b[2].num_eval and a[2].depth == b[2].depth)
         msg = ""
+        why = ""
+        if not ok:
+            why = "fused-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d depth %d/%d" % (
+                np.array_equal(a[0], b[0]), np.array_equal(a[1], b[1]), np.array_equal(Ya, Yb), np.array_equal(Sa, Sb),
+                a[2].num_eval, b[2].num_eval, a[2].depth, b[2].depth)
         if ok and case % 4 == 0:
             class Inj(object):
                 name = "inj"; blobs = net.blobs
@@ -63,11 +68,21 @@ def main():
             Yref, tr = orc.im_propose({"full": inj, "fc": inj}, (H, W), scale, cfg, return_trace=True)
             ok = (a[2].num_eval == tr["num_eval"] and Ya.shape == tr["Y_all"].shape and
                   np.array_equal(Sa.astype(np.float64), tr["aScores"]) and
-                  np.allclose(Ya, tr["Y_all"], rtol=1e-6, atol=1e-4) and a[0].shape == Yref.shape)
+                  np.allclose(Ya, tr["Y_all"], rtol=1e-6, atol=3e-4) and a[0].shape == Yref.shape)   # 1 ulp of the f32 exp
+                  # (NumPy's SIMD expf vs the device's) times half a predicted width of up to ~2500 px
             msg = " (+oracle loop)"
+            if not ok:
+                dS = np.abs(Sa.astype(np.float64) - tr["aScores"]).max() if Ya.shape == tr["Y_all"].shape else -1
+                dY = np.abs(Ya - tr["Y_all"]).max() if Ya.shape == tr["Y_all"].shape else -1
+                why = "vs oracle loop: max|dS| %.3g max|dY| %.3g Yref %s top %s; eval %d/%d shapes %s/%s levels gpu %s oracle %s uniq gpu %s oracle %s" % (
+                    dS, dY, Yref.shape, a[0].shape,
+                    a[2].num_eval, tr["num_eval"], Ya.shape, tr["Y_all"].shape,
+                    [int(a[2].level_regions[l]) for l in range(a[2].n_levels)], [lv["B"].shape[0] for lv in tr["levels"]],
+                    [int(a[2].level_unique[l]) for l in range(a[2].n_levels)],
+                    [sum(f["U"] for f in lv["fwd"]) for lv in tr["levels"]])
         if not ok:
             bad += 1
-            print("MISMATCH case %d: H=%d W=%d scale=%.4f Tz=%r batch=%d nprop=%d fixed=%s" % (case, H, W, scale, Tz, batch, nprop, fixed))
+            print("MISMATCH case %d: H=%d W=%d scale=%.4f Tz=%r batch=%d nprop=%d fixed=%s | %s" % (case, H, W, scale, Tz, batch, nprop, fixed, why))
         elif case % 20 == 0:
             print("case %d ok%s: %dx%d levels %d eval %d cand %d" % (case, msg, H, W, a[2].n_levels, a[2].num_eval, Ya.shape[0]))
     print("stress: %d cases, %d mismatches" % (n_cases, bad))
