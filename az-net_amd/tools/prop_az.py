@@ -13,40 +13,20 @@ output).  Differences forced by what exists offline:
 With several GPUs: python -m torch.distributed.run --nproc-per-node N tools/prop_az.py ...
 shards the images one rank per GPU and gathers the proposals on every rank (RCCL)."""
 import _init_paths  # noqa: F401
-import argparse
 import os
 import pickle
-import pprint
-import sys
-import time
 
 import numpy as np
 
-from detect.test import test_proposals, im_propose
-from detect.config import cfg, cfg_from_file, cfg_set_mode, cfg_load_thresh, cfg_set_path, get_output_dir
+import _cli
 
-
-def parse_args():
-    parser = argparse.ArgumentParser(description='Use AZ-Net to generate proposals')
-    parser.add_argument('--gpu', dest='gpu_id', help='GPU id to use', default=0, type=int)
-    parser.add_argument('--def', dest='prototxt', help='(ignored) prototxt of the full net', default=None, type=str)
-    parser.add_argument('--def_fc', dest='prototxt_fc', help='(ignored) prototxt of the fc layers', default=None,
-                        type=str)
-    parser.add_argument('--net', dest='caffemodel', help='AZ-Net weights (.npz) or synthetic[:seed]',
-                        default='synthetic', type=str)
-    parser.add_argument('--cfg', dest='cfg_file', help='optional config file', default=None, type=str)
-    parser.add_argument('--wait', dest='wait', help='wait until net file exists', default=True, type=bool)
-    parser.add_argument('--imdb', dest='imdb_name', help='dataset to test', default='synthetic_600x1000_8', type=str)
-    parser.add_argument('--thresh', dest='thresh_file', help='file that stores zoom threshold (pickle)', default=None,
-                        type=str)
-    parser.add_argument('--tz', dest='tz', help='zoom threshold given directly (instead of --thresh)', default=None,
-                        type=float)
-    parser.add_argument('--exp', dest='exp_dir', help='experiment path', default=None, type=str)
-    parser.add_argument('--recall', dest='recall', help='evaluate recall against the ground truth', action='store_true')
-    if len(sys.argv) == 1:
-        parser.print_help()
-        sys.exit(1)
-    return parser.parse_args()
+FLAGS = [
+    ("--def", "prototxt", "(ignored) prototxt of the full net", None, str),
+    ("--def_fc", "prototxt_fc", "(ignored) prototxt of the fc layers", None, str),
+    ("--net", "caffemodel", "AZ-Net weights (.caffemodel / .npz) or synthetic[:seed]", "synthetic", str),
+    ("--imdb", "imdb_name", "dataset to test", "synthetic_600x1000_8", str),
+    ("--recall", "recall", "also evaluate recall against the imdb's ground truth", None, None),
+]
 
 
 def load_net(spec, device):
@@ -74,78 +54,67 @@ def load_net(spec, device):
     return HipAZNet(head, backbone=backbone, device=device, name=name)
 
 
-if __name__ == '__main__':
-    args = parse_args()
-    print('Called with args:')
-    print(args)
-    if args.cfg_file is not None:
-        cfg_from_file(args.cfg_file)
-    cfg_set_path(args.exp_dir)
-    if args.tz is not None:
-        thresh = args.tz
-    else:
-        while not os.path.exists(args.thresh_file) and args.wait:
-            print('Waiting for {} to exist...'.format(args.thresh_file))
-            time.sleep(10)
-        thresh = cfg_load_thresh(args.thresh_file)
-    cfg_set_mode('Test', thresh)
-    print('Using config:')
-    pprint.pprint(cfg)
-    if not args.caffemodel.startswith('synthetic'):
-        while not os.path.exists(args.caffemodel) and args.wait:
-            print('Waiting for {} to exist...'.format(args.caffemodel))
-            time.sleep(10)
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    device = int(os.environ.get('LOCAL_RANK', args.gpu_id)) if world > 1 else args.gpu_id
+def main():
+    args = _cli.parse("Use AZ-Net to generate proposals", [_cli.COMMON, _cli.THRESH, FLAGS])
+    cfg = _cli.setup_cfg(args, "Test")
+    if not args.caffemodel.startswith("synthetic"):
+        _cli.wait_for(args.caffemodel, args.wait)
+    world, rank = _cli.ranks()
+    device = int(os.environ.get("LOCAL_RANK", args.gpu_id)) if world > 1 else args.gpu_id
     import torch
     torch.cuda.set_device(device)
-    net = load_net(args.caffemodel, device)
-    nets = {'full': net, 'fc': net}
     from datasets.factory import get_imdb
+    from detect.config import get_output_dir
+    from detect.test import test_proposals, im_propose
+    net = load_net(args.caffemodel, device)
+    nets = {"full": net, "fc": net}
     imdb = get_imdb(args.imdb_name)
+
     def report_recall(prop_file):
-        with open(prop_file, 'rb') as f:
+        with open(prop_file, "rb") as f:
             prop = pickle.load(f)
-        ar, gt_overlaps, recalls, thresholds = imdb.evaluate_recall(prop['boxes'], ctx=net.ctx)
-        prop['recall'] = float(recalls[0])
-        with open(prop_file, 'wb') as f:
+        ar, gt_overlaps, recalls, thresholds = imdb.evaluate_recall(prop["boxes"], ctx=net.ctx)
+        prop["recall"] = float(recalls[0])
+        with open(prop_file, "wb") as f:
             pickle.dump(prop, f, pickle.HIGHEST_PROTOCOL)
-        print('recall@0.5 = {:.4f}, recall@0.7 = {:.4f}, AR = {:.4f} over {:d} gt boxes'.format(
+        print("recall@0.5 = {:.4f}, recall@0.7 = {:.4f}, AR = {:.4f} over {:d} gt boxes".format(
             recalls[0], recalls[200], ar, gt_overlaps.size))
 
     if world == 1:
         prop_file = test_proposals(nets, imdb)
         if args.recall:
             report_recall(prop_file)
-    else:
-        import torch.distributed as dist
-        from aznet_hip import dist as azdist
-        from utils.timer import Timer
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', device))
-        n = len(imdb.image_index)
-        per = (n + world - 1) // world
-        t = Timer()
-        local = []
-        for j in range(per):                      # rank r owns images r, r + world, ...
-            i = min(rank + j * world, n - 1)      # the tail re-runs the last image to keep ranks in step
-            im = imdb.image_at(i)
-            t.tic()
-            Y = im_propose(nets, im)
-            t.toc()
-            local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
-        cap = int(cfg.SEAR.NUM_PROPOSALS)
-        allp = azdist.gather_proposals(local, cap, device=torch.device('cuda', device))[:n]
-        if rank == 0:
-            out_dir = get_output_dir(imdb, net)
-            os.makedirs(out_dir, exist_ok=True)
-            prop = {'boxes': [b for b, _ in allp], 'time': t.average_time, 'recall': 0}
-            with open(os.path.join(out_dir, 'proposals.pkl'), 'wb') as f:
-                pickle.dump(prop, f, pickle.HIGHEST_PROTOCOL)
-            print('wrote', os.path.join(out_dir, 'proposals.pkl'))
-            if args.recall:
-                report_recall(os.path.join(out_dir, 'proposals.pkl'))
-        dist.barrier()
-        dist.destroy_process_group()
+        return
+    # one rank per GPU: rank r owns images r, r + world, ...; proposals are gathered on every rank
+    import torch.distributed as dist
+    from aznet_hip import dist as azdist
+    from utils.timer import Timer
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    n = len(imdb.image_index)
+    per = (n + world - 1) // world
+    t = Timer()
+    local = []
+    for j in range(per):
+        i = min(rank + j * world, n - 1)          # the tail re-runs the last image to keep ranks in step
+        im = imdb.image_at(i)
+        t.tic()
+        Y = im_propose(nets, im)
+        t.toc()
+        local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
+    allp = azdist.gather_proposals(local, int(cfg.SEAR.NUM_PROPOSALS), device=torch.device("cuda", device))[:n]
+    if rank == 0:
+        out_dir = get_output_dir(imdb, net)
+        os.makedirs(out_dir, exist_ok=True)
+        prop_file = os.path.join(out_dir, "proposals.pkl")
+        with open(prop_file, "wb") as f:
+            pickle.dump({"boxes": [b for b, _ in allp], "time": t.average_time, "recall": 0}, f, pickle.HIGHEST_PROTOCOL)
+        print("wrote", prop_file)
+        if args.recall:
+            report_recall(prop_file)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
