@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,8 @@ struct az_ctx {
     // last launch
     az_params last{};
     int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels overflowed
+    std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
+    int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_nlev = 0;
     // profiling
     int profiling = 0;
@@ -300,6 +303,8 @@ int az_destroy(az_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     clear_events(c);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
     free_all(c);
     for (void *p : c->allocs_geom) hipFree(p);
     c->allocs_geom.clear();
@@ -454,30 +459,10 @@ int az_set_feature_map_host(az_ctx *c, const float *host_ptr, int C, int H, int 
 }
 
 // --------------------------------------------------------------------------------------
-int az_propose_launch(az_ctx *c, const az_params *p)
+// Everything az_propose enqueues on the ctx stream (no host synchronisation, no host-dependent sizes:
+// every count is read on the device), so the same sequence can also be captured into a hipGraph.
+static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k, bool tune)
 {
-    int rc = check_ready(c, true);
-    if (rc) return rc;
-    if (!p || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) || p->batch_size <= 0 || !(p->min_side > 0))
-        return fail(c, AZ_ERR_INVALID, "az_propose: bad parameters");
-    const int K = num_levels(p->im_h, p->im_w, p->min_side);
-    // The tuner's variant of the search (lib/detect/tune.py:256-316, params.reserved bit 2) runs
-    // `for k in xrange(K)` -- one level more than test.py:373 --, applies Tz from the second level
-    // on (the first compares against 0), never forces the root, and keeps the anchor history Bhis.
-    const bool tune = (p->reserved & 4) != 0;
-    const int nlev = tune ? K : K - 1;
-    if (nlev < 1)
-        return fail(c, AZ_ERR_INVALID,
-                    "az_propose: image too small for one search level (the reference's loop at "
-                    "lib/detect/test.py:373 would not execute)");
-    if (nlev > AZ_MAX_LEVELS) return fail(c, AZ_ERR_CAPACITY, "az_propose: too many levels");
-    int k = p->num_proposals;
-    if (p->fixed_num) {
-        if (k <= 0) return fail(c, AZ_ERR_INVALID, "az_propose: num_proposals must be positive");
-        if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
-    }
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!(c->profiling & 4)) clear_events(c);
     hipStream_t s = c->stream;
 
     // Speculative evaluation of levels 1-3.  The root is always divided (test.py:383-384), so
@@ -576,6 +561,63 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     if (tune && c->pool) {
         Timed t(c, "pool_append", nlev);
         azk_pool_append(s, c->hisZ, &c->cnt->nhis, c->capHis, c->pool, c->pool_n, c->pool_cap);
+    }
+    return AZ_OK;
+}
+
+int az_propose_launch(az_ctx *c, const az_params *p)
+{
+    int rc = check_ready(c, true);
+    if (rc) return rc;
+    if (!p || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) || p->batch_size <= 0 || !(p->min_side > 0))
+        return fail(c, AZ_ERR_INVALID, "az_propose: bad parameters");
+    const int K = num_levels(p->im_h, p->im_w, p->min_side);
+    // The tuner's variant of the search (lib/detect/tune.py:256-316, params.reserved bit 2) runs
+    // `for k in xrange(K)` -- one level more than test.py:373 --, applies Tz from the second level
+    // on (the first compares against 0), never forces the root, and keeps the anchor history Bhis.
+    const bool tune = (p->reserved & 4) != 0;
+    const int nlev = tune ? K : K - 1;
+    if (nlev < 1)
+        return fail(c, AZ_ERR_INVALID,
+                    "az_propose: image too small for one search level (the reference's loop at "
+                    "lib/detect/test.py:373 would not execute)");
+    if (nlev > AZ_MAX_LEVELS) return fail(c, AZ_ERR_CAPACITY, "az_propose: too many levels");
+    int k = p->num_proposals;
+    if (p->fixed_num) {
+        if (k <= 0) return fail(c, AZ_ERR_INVALID, "az_propose: num_proposals must be positive");
+        if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!(c->profiling & 4)) clear_events(c);
+    hipStream_t s = c->stream;
+    // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
+    // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
+    if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
+    if (c->use_graphs && !c->profiling && !(tune && c->pool)) {
+        std::string key((const char *)p, sizeof(*p));
+        const void *fp = c->feat;
+        key.append((const char *)&fp, sizeof(fp));
+        key.append((const char *)&c->d, sizeof(c->d));
+        key.append((const char *)&c->nofuse_h, sizeof(int));
+        key.append((const char *)&c->nofuse_w, sizeof(int));
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            // (the first search of a shape also runs once un-captured: one-time attribute calls happen there)
+            if ((rc = enqueue_search(c, p, K, nlev, k, tune)) != AZ_OK) return rc;
+            HIPCHK(c, hipStreamSynchronize(s));
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_search(c, p, K, nlev, k, tune);
+            HIPCHK(c, hipStreamEndCapture(s, &g));
+            if (rc) return rc;
+            HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipGraphDestroy(g);
+            it = c->graphs.emplace(key, ge).first;
+        }
+        HIPCHK(c, hipGraphLaunch(it->second, s));
+    } else {
+        if ((rc = enqueue_search(c, p, K, nlev, k, tune)) != AZ_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
     c->last = *p;
@@ -1323,6 +1365,13 @@ int az_image_blob_dev(az_ctx *c, const uint8_t *im, int h, int w, const float *m
     return image_blob_common(c, im, h, w, means, scale, blob_dev, true, oh, ow);
 }
 
+
+int az_set_graphs(az_ctx *c, int on)
+{
+    if (!c) return AZ_ERR_INVALID;
+    c->use_graphs = on ? 1 : 0;
+    return AZ_OK;
+}
 
 int az_set_profiling(az_ctx *c, int on)
 {

@@ -30,7 +30,7 @@ SYMBOLS = [
     "az_last_kernel_times", "az_stream", "az_load_det_head", "az_det_forward", "az_detect",
     "az_set_gemm_mode", "az_last_anchors", "az_tune_begin", "az_tune_end", "az_tune_kth_largest",
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
-    "az_image_blob_host", "az_image_blob_dev", "az_nms_batched",
+    "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library(path=None):
     L.az_det_forward.argtypes = [vp, fp, ci, fp, fp]
     L.az_detect.argtypes = [vp, dp, ci, cd, cd, ci, ci, ci, cd, fp, dp]
     L.az_set_profiling.argtypes = [vp, ci]
+    L.az_set_graphs.argtypes = [vp, ci]
     L.az_last_kernel_times.argtypes = [vp, ctypes.c_char_p, fp, ip, ci, cip]
     L.az_stream.restype = vp
     L.az_stream.argtypes = [vp]
@@ -525,6 +526,10 @@ class AzContext(object):
         """mode bits: 1 = fc GEMM launches only, 2 = every launch group, 4 = accumulate across
         calls until read; 0 = off."""
         self._chk(self.L.az_set_profiling(self.h, int(mode)))
+
+    def set_graphs(self, on):
+        """Replay the search's launch sequence as a hipGraph (same results, less host time)."""
+        self._chk(self.L.az_set_graphs(self.h, 1 if on else 0))
 
     def last_kernel_times(self, cap=65536):
         names = ctypes.create_string_buffer(32 * cap)

@@ -379,6 +379,33 @@ def test_topk_kernels_agree(small, mods):
         assert np.array_equal(got, np.argsort(-sc, kind="stable")[:300])
 
 
+def test_graph_replay_equals_direct_launches(small, mods):
+    """az_set_graphs: the captured launch sequence gives the same proposals, also when parameters and
+    feature maps alternate (one graph per parameter set / map)."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    maps = [synth.make_feature_map(s, synth.SMALL_DIMS["C"], 38, 63) for s in (21, 22)]
+    plist = [ffi.AzContext.make_params(600, 1000, 1.0, 0.0), ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=50),
+             ffi.AzContext.make_params(480, 640, 1.25, 0.0, batch_size=100),
+             ffi.AzContext.make_params(600, 1000, 1.0, 0.0, fixed_num=False, Tc=0.5)]
+    plist[2] = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, batch_size=100)
+    want = {}
+    for mi, m in enumerate(maps):
+        net.set_conv(m)
+        for pi, p in enumerate(plist):
+            want[(mi, pi)] = net.propose(p, want_scores=True)
+    net.ctx.set_graphs(True)
+    try:
+        for rep in range(3):
+            for mi, m in enumerate(maps):
+                net.set_conv(m)
+                for pi, p in enumerate(plist):
+                    got = net.propose(p, want_scores=True)
+                    assert np.array_equal(got[0], want[(mi, pi)][0]) and np.array_equal(got[1], want[(mi, pi)][1])
+    finally:
+        net.ctx.set_graphs(False)
+
+
 def test_threshold_mode(small, mods):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
