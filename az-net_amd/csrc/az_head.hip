@@ -235,6 +235,12 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;          // padded LDS row (floats): 144 B, conflict-free b128 reads
 constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
+// tiles of at least this many strips use the MFMA-dense step schedule (mid-step barrier, one instruction
+// per MFMA issue slot); single-strip tiles keep the simpler weight-streaming one.  (2 vs 3: -5 us on the
+// 49-row speculative pass, neutral elsewhere.)
+#ifndef DENSE_MIN_NRT
+#define DENSE_MIN_NRT 2
+#endif
 static int gemm_grid()
 {
     static int g = -1;
@@ -401,7 +407,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     lstore(0, 0, ra0, rb0);
     __syncthreads();
 
-    if constexpr (NRT >= 3) {
+    if constexpr (NRT >= DENSE_MIN_NRT) {
         // MFMA-bound shape.  The barrier sits in the MIDDLE of the K-step: when a wave reaches it
         // two of its four k groups (32 MFMAs, ~2000 cycles) are still queued with their operands
         // already in registers, so barrier skew and the first fragment reads of the next tile
@@ -416,6 +422,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         hfrag(0, 1, h1);
         // with a half strip every phase has 4 more (short) MFMAs and up to 6 more 4-byte DS reads
         constexpr int HM = HALF ? 4 : 0, HD = HALF ? 3 : 0;
+        constexpr int REM01_ = 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, REM01 = REM01_ > 0 ? REM01_ : 0;
         auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
             __builtin_amdgcn_sched_barrier(0);
@@ -442,7 +449,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, REM01, 0);
             __builtin_amdgcn_sched_barrier(0);
             // group 1 MFMAs | tile kt+1 -> LDS[buf^1] | fragments of group 3
             lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
@@ -467,7 +474,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, 1);
+            __builtin_amdgcn_sched_group_barrier(0x008, REM01, 1);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();         // LDS[buf^1] (tile kt+1) complete; everyone's reads of LDS[buf] issued
             __builtin_amdgcn_sched_barrier(0);
@@ -511,7 +518,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
             if (kt + 1 < nk) step(kt + 1, 1, ra1, rb1, ra0, rb0);
         }
     } else {
-        // Weight-streaming-bound shape (<= 64 rows): what matters is bytes in flight, not MFMA
+        // Weight-streaming-bound shape (one strip): what matters is bytes in flight, not MFMA
         // density.  MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 and write tile kt+1.
         auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
