@@ -37,7 +37,7 @@ def main():
         tf = R * flop6 / (med["fc6_gemm"] * 1e-6) / 1e12
         bw = 411041792 / (med["fc6_gemm"] * 1e-6) / 1e12
         print("R=%5d  " % R + "  ".join("%s %7.1f" % (k, med[k]) for k in
-              ("roi_pool", "fc6_gemm", "fc6_reduce", "fc7_gemm", "fc7_reduce", "tail")) +
+              ("roi_pool", "fc6_gemm", "fc6_reduce", "fc7_gemm", "tail")) +
               "  | fc6 %.1f TF/s  W-stream %.2f TB/s" % (tf, bw))
 
 
