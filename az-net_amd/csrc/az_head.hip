@@ -238,6 +238,12 @@ constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
 // tiles of at least this many strips use the MFMA-dense step schedule (mid-step barrier, one instruction
 // per MFMA issue slot); single-strip tiles keep the simpler weight-streaming one.  (2 vs 3: -5 us on the
 // 49-row speculative pass, neutral elsewhere.)
+#ifndef W_AUX_MAX_NRT
+#define W_AUX_MAX_NRT 1
+#endif
+#ifndef W_AUX_STREAM
+#define W_AUX_STREAM 2      /* cache policy bits of the weight loads of single-strip (weight-streaming) tiles */
+#endif
 #ifndef DENSE_MIN_NRT
 #define DENSE_MIN_NRT 2
 #endif
@@ -268,9 +274,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, s
                                              0x00020000);
 }
 
+template <int AUX = 0>
 __device__ __forceinline__ float4 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 {
-    v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
@@ -342,7 +349,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 #pragma unroll
         for (int i = 0; i < NLA; ++i) ra[i] = buf_ld(rsA, voA[i], so);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = buf_ld(rsB, voB[i], so);
+        for (int i = 0; i < 4; ++i) rb[i] = buf_ld<(NRT <= W_AUX_MAX_NRT) ? W_AUX_STREAM : 0>(rsB, voB[i], so);
     };
     auto lstore = [&](int kt, int buf, const float4 (&ra)[NLA], const float4 (&rb)[4]) {
         const bool ok = (k0 + kt * BK + sc4) < kend;
