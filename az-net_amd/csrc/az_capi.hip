@@ -5,6 +5,7 @@
 #include "az_dev.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -87,8 +88,13 @@ struct az_ctx {
     std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_nlev = 0;
+    void *stage_dst = nullptr;          // az_propose_stage_result_dev target of the search in flight
+    size_t stage_cap = 0;
+    int his_n = 0;                      // rows of the anchor history of the last fetched tuner search
+    int cand_n = -1;                    // candidates of the last fetched search still in Yall/Sall (-1: overwritten)
     // profiling
     int profiling = 0;
+    int event_errors = 0;              // hipEvent* calls that failed while profiling
     std::vector<AzEventRec> events;
     std::vector<void *> allocs;        // head-sized buffers (az_load_head)
     std::vector<void *> allocs_geom;   // geometry buffers (first use)
@@ -178,11 +184,17 @@ struct Timed {
     Timed(az_ctx *c_, const char *n, int l, int cls = 2) : c(c_), name(n), level(l)
     {
         on = (c_->profiling & 2) || ((c_->profiling & 1) && cls == 1);
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+        if (!on) return;
+        // a failed event call drops this measurement (and is reported by az_last_kernel_times), never the search
+        if (hipEventCreate(&a) != hipSuccess) { on = false; ++c->event_errors; return; }
+        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); on = false; ++c->event_errors; return; }
+        if (hipEventRecord(a, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); on = false; ++c->event_errors; }
     }
     ~Timed()
     {
-        if (on) { hipEventRecord(b, c->stream); c->events.push_back({name, level, a, b}); }
+        if (!on) return;
+        if (hipEventRecord(b, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); ++c->event_errors; return; }
+        c->events.push_back({name, level, a, b});
     }
 };
 
@@ -419,7 +431,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     return AZ_OK;
 }
 
-static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W)
+static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W,
+                                  bool wait = true)
 {
     int rc = check_ready(c, false);
     if (rc) return rc;
@@ -442,7 +455,7 @@ static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host,
     }
     // RoIPool reads the map channel-last: one transpose per image, outside the level loop.
     azk_nchw_to_nhwc(c->stream, nchw, c->feat_owned, C, H * W);
-    HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may now reuse / free `src`
+    if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may now reuse / free `src`
     c->feat = c->feat_owned;
     c->d.H = H; c->d.W = W;
     return AZ_OK;
@@ -456,6 +469,11 @@ int az_set_feature_map_dev(az_ctx *c, const float *dev_ptr, int C, int H, int W)
 int az_set_feature_map_host(az_ctx *c, const float *host_ptr, int C, int H, int W)
 {
     return set_feature_map_common(c, host_ptr, true, C, H, W);
+}
+
+int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, int W)
+{
+    return set_feature_map_common(c, dev_ptr, false, C, H, W, false);
 }
 
 // --------------------------------------------------------------------------------------
@@ -589,12 +607,20 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     }
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
+    c->cand_n = -1;
     hipStream_t s = c->stream;
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
     if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
     if (c->use_graphs && !c->profiling && !(tune && c->pool)) {
-        std::string key((const char *)p, sizeof(*p));
+        // key = the fields themselves (never the struct's bytes: padding is the caller's garbage)
+        std::string key;
+        auto put = [&key](const void *v, size_t n) { key.append((const char *)v, n); };
+        put(&p->im_h, sizeof p->im_h); put(&p->im_w, sizeof p->im_w); put(&p->scale, sizeof p->scale);
+        put(&p->Tz, sizeof p->Tz); put(&p->Tc, sizeof p->Tc); put(&p->dedup, sizeof p->dedup);
+        put(&p->eps, sizeof p->eps); put(&p->min_side, sizeof p->min_side); put(&p->batch_size, sizeof p->batch_size);
+        put(&p->num_proposals, sizeof p->num_proposals); put(&p->fixed_num, sizeof p->fixed_num);
+        put(&p->reserved, sizeof p->reserved);
         const void *fp = c->feat;
         key.append((const char *)&fp, sizeof(fp));
         key.append((const char *)&c->d, sizeof(c->d));
@@ -623,6 +649,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     c->last = *p;
     c->last_nlev = nlev;
     c->launched = true;
+    c->stage_dst = nullptr;
     return AZ_OK;
 }
 
@@ -663,6 +690,7 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         std::memset(st, 0, sizeof(*st));
         st->n_levels = nlev;
         st->n_candidates = h.ytot[nlev];
+        st->spec_rows = h.specU;
         for (int l = 0; l < nlev; ++l) {
             st->level_regions[l] = h.P[l];
             st->level_unique[l] = h.U[l];
@@ -677,8 +705,11 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         c->nofuse_h = c->last.im_h; c->nofuse_w = c->last.im_w;
         az_params p2 = c->last;
         p2.reserved |= 2;
+        void *sd = c->stage_dst;
+        const size_t sc = c->stage_cap;
         int rc2 = az_propose_launch(c, &p2);
         if (rc2) return rc2;
+        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;   // the staged record was the failed run's
         return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
     }
     if (h.err)
@@ -686,6 +717,8 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
                     std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
                         "): raise az_set_limits");
     const int n = h.nsel;
+    c->cand_n = h.ytot[nlev];
+    c->his_n = h.nhis;
     if (st) st->n_proposals = n;
     *n_out = n;
     if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_propose: output capacity too small");
@@ -702,6 +735,28 @@ int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_o
     return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
 }
 
+int az_result_record_layout(int k, size_t *bytes, size_t *n_off, size_t *boxes_off, size_t *scores_off)
+{
+    if (k <= 0 || k > AZ_TOPK_MAX) return AZ_ERR_INVALID;
+    if (bytes) *bytes = RES_HDR + (size_t)k * 36;
+    if (n_off) *n_off = offsetof(AzCounts, nsel);
+    if (boxes_off) *boxes_off = RES_HDR;
+    if (scores_off) *scores_off = RES_HDR + (size_t)k * 32;
+    return AZ_OK;
+}
+
+int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
+{
+    if (!c || !c->launched) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev without az_propose_launch");
+    if (!c->last.fixed_num) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev: fixed proposal count only");
+    const size_t bytes = RES_HDR + (size_t)c->last.num_proposals * 36;
+    if (!dst_dev || cap_bytes < bytes) return fail(c, AZ_ERR_INVALID, "az_propose_stage_result_dev: destination too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst_dev, c->cnt, bytes, hipMemcpyDeviceToDevice, c->stream));
+    c->stage_dst = dst_dev; c->stage_cap = cap_bytes;
+    return AZ_OK;
+}
+
 int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out)
 {
     int rc = check_ready(c, false);
@@ -709,7 +764,9 @@ int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap,
     if (!n_out) return AZ_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int n = c->h_cnt->ytot[c->last_nlev];
+    if (c->cand_n < 0)
+        return fail(c, AZ_ERR_STATE, "az_last_candidates: no fetched search, or a later call reused the candidate buffers");
+    const int n = c->cand_n;
     *n_out = n;
     if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_last_candidates: cap too small");
     if (boxes_out) HIPCHK(c, hipMemcpy(boxes_out, c->Yall, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
@@ -723,6 +780,7 @@ static int sift_common(az_ctx *c, int C, double min_side, double *out, int cap, 
 {
     hipStream_t s = c->stream;
     int *Nptr = &c->cnt->scratch[0], *Pn = &c->cnt->scratch[1], *err = &c->cnt->scratch[2];
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     int rc = set_count(c, Nptr, C);
     if (rc) return rc;
@@ -757,6 +815,7 @@ int az_divide_region(az_ctx *c, const double *regions, int P, double min_side, d
     if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: too many regions");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->Z, regions, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->PZ[0], P)) != AZ_OK) return rc;
@@ -783,6 +842,7 @@ int az_roi_dedup(az_ctx *c, const double *boxes, int P, double scale, double ded
     if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_roi_dedup: too many regions");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
@@ -803,6 +863,7 @@ static int stage_rois(az_ctx *c, const float *rois, int R)
     if (R < 0 || (R && !rois)) return fail(c, AZ_ERR_INVALID, "bad rois");
     if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "too many rois");
     HIPCHK(c, hipSetDevice(c->device));
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), c->stream));
     if (R) HIPCHK(c, hipMemcpyAsync(c->urois, rois, (size_t)R * 5 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ubox, 0, (size_t)(R > 0 ? R : 1) * 4 * sizeof(double), c->stream));
@@ -849,6 +910,7 @@ int az_decode_filter(az_ctx *c, const double *anchors, const float *deltas, cons
     if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_decode_filter: too many regions");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     // stage: anchors -> ubox, deltas -> delta_u, scores -> Sout (scratch); inv = identity
     std::vector<int> ident(R);
@@ -882,6 +944,7 @@ int az_topk(az_ctx *c, const float *scores, int n, int k, int32_t *idx_out, int 
     if (n > c->maxCand || k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_topk: n or k too large");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (n) HIPCHK(c, hipMemcpyAsync(c->Sall, scores, (size_t)n * 4, hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->scratch[0], n)) != AZ_OK) return rc;
@@ -1039,6 +1102,7 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!(c->profiling & 4)) clear_events(c);
+    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
@@ -1117,7 +1181,7 @@ int az_last_anchors(az_ctx *c, double *regions_out, float *zoom_out, int cap, in
         return fail(c, AZ_ERR_STATE, "az_last_anchors: the last az_propose was not a tuner search (reserved bit 2)");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int n = c->h_cnt->nhis;
+    const int n = c->his_n;
     *n_out = n;
     if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_last_anchors: cap too small");
     if (regions_out) HIPCHK(c, hipMemcpy(regions_out, c->hisB, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
@@ -1388,9 +1452,15 @@ int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *lev
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n = (int)c->events.size();
     *n_out = n;
+    if (c->event_errors) {
+        const int ne = c->event_errors;
+        c->event_errors = 0;
+        return fail(c, AZ_ERR_HIP, "az_last_kernel_times: " + std::to_string(ne) + " hipEvent call(s) failed while profiling");
+    }
     for (int i = 0; i < n && i < cap; ++i) {
         float ms = 0.f;
-        hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b);
+        if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess)
+            return fail(c, AZ_ERR_HIP, "az_last_kernel_times: hipEventElapsedTime failed");
         if (ms_out) ms_out[i] = ms;
         if (level_out) level_out[i] = c->events[i].level;
         if (names_out) {

@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         for (int r = tid; r < P; r += NTL) {
             float roi5[5];
             // roi keys are < 1000^5 < 2^50: the dedup chunk number (test.py:202-205) rides above them
-            skey[r] = roi_and_key(B + 4 * r, a.scale, a.dedup, roi5) + ((long long)(r / a.batch) << 50);
+            skey[r] = roi_and_key(B + 4 * r, a.scale, a.dedup, roi5, r) + ((long long)(r / a.batch) << 50);
         }
         __syncthreads();
         TSTAMP(tsn++);

@@ -30,7 +30,7 @@ __global__ void k_rois_keys(const double *__restrict__ B, const int *Pptr, doubl
 {
     const int P = *Pptr;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P; r += gridDim.x * blockDim.x) {
-        key[r] = roi_and_key(B + 4 * (size_t)r, scale, dedup, rois + 5 * (size_t)r);
+        key[r] = roi_and_key(B + 4 * (size_t)r, scale, dedup, rois + 5 * (size_t)r, r);
         grp[r] = r / batch;                        // dedup is per BATCH_SIZE chunk (test.py:195-218)
     }
 }
@@ -69,7 +69,7 @@ __global__ void k_first_rois(const double *__restrict__ B, const int *Pptr, doub
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < P; i += nwaves) {
         float roi5[5];
-        const long long ki = roi_and_key(B + 4 * (size_t)i, scale, dedup, roi5);
+        const long long ki = roi_and_key(B + 4 * (size_t)i, scale, dedup, roi5, i);
         const int gi = i / batch;                      // dedup is per BATCH_SIZE chunk (test.py:195-218)
         if (lane == 0) { key[i] = ki; grp[i] = gi; }
         if (lane < 5) rois[5 * (size_t)i + lane] = roi5[lane];
@@ -78,7 +78,7 @@ __global__ void k_first_rois(const double *__restrict__ B, const int *Pptr, doub
             const int j = j0 + lane;
             if (j < i) {
                 float r5[5];
-                dup |= (roi_and_key(B + 4 * (size_t)j, scale, dedup, r5) == ki);
+                dup |= (roi_and_key(B + 4 * (size_t)j, scale, dedup, r5, j) == ki);
             }
             if (__any(dup)) break;
         }

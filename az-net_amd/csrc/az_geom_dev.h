@@ -32,7 +32,10 @@ static __device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints
 
 // lib/detect/test.py:61-97 (_get_rois_blob: f64 box * scale -> f32) and :212-214 (hash of
 // np.round(rois * DEDUP_BOXES) . [1,1e3,1e6,1e9,1e12]; exact integers, so int64 here).
-static __device__ __forceinline__ long long roi_and_key(const double *box, double scale, float dedup, float *roi5)
+// `r` is the region's position in its level: with cfg.DEDUP_BOXES <= 0 the reference skips the
+// dedup (`if cfg.DEDUP_BOXES > 0:`, test.py:211,246 / :281,312), i.e. index = inv_index = identity;
+// the position itself is then the key (all distinct, ascending), which gives exactly that.
+static __device__ __forceinline__ long long roi_and_key(const double *box, double scale, float dedup, float *roi5, int r)
 {
     long long h = 0, mult = 1000;
     roi5[0] = 0.0f;
@@ -44,7 +47,7 @@ static __device__ __forceinline__ long long roi_and_key(const double *box, doubl
         h += (long long)t * mult;
         mult *= 1000;
     }
-    return h;
+    return dedup > 0.0f ? h : (long long)r;
 }
 
 // divide_region, lib/utils/div.pyx:15-76.

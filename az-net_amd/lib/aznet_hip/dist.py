@@ -8,8 +8,17 @@ list equals what test_proposals' serial loop would have produced
 (lib/detect/test.py:492,508-513).  The search itself needs no communication -- images are
 independent -- so there is no collective on the data path.
 
-Record per image: [n, boxes[cap][4], scores[cap]] as float64 (n <= cap = NUM_PROPOSALS):
-300 proposals -> 1501 doubles = 12 KB; latency-bound, so records are batched.
+Two record formats, both one row per image:
+  * device records (`DeviceGather`, the production path): the result block az_propose leaves in
+    HBM (az_result_record_layout: int32 n, boxes f64[k][4], scores f32[k]; 11.3 KB for k = 300)
+    is copied device-to-device into the RCCL send buffer on the ctx stream
+    (az_propose_stage_result_dev) -- the exchanged bytes never visit the host before the gather;
+  * host records (`gather_proposals`): [n, boxes[cap][4], scores[cap]] as float64, for callers
+    that hold NumPy results (variable proposal counts: cfg.SEAR.FIXED_PROPOSAL_NUM = False,
+    cfg.SEAR.APPEND_BOXES).  `cap` is agreed collectively (all-reduce MAX), so a rank with more
+    boxes than another cannot make the collective hang.
+Ranks may own different numbers of images (num_images % world != 0): short ranks send padding
+rows (n = -1) that are dropped after the gather.
 """
 import numpy as np
 
@@ -21,7 +30,8 @@ def record_len(cap):
 def pack_record(boxes, scores, cap):
     """boxes [n,4] f64, scores [n] f32 -> float64 [1 + 5*cap]."""
     n = boxes.shape[0]
-    assert n <= cap
+    if n > cap:
+        raise ValueError("pack_record: %d boxes do not fit a record of capacity %d" % (n, cap))
     rec = np.zeros(record_len(cap), dtype=np.float64)
     rec[0] = n
     rec[1:1 + 4 * n] = boxes.reshape(-1)
@@ -41,26 +51,114 @@ def shard_indices(num_images, rank, world):
     return list(range(rank, num_images, world))
 
 
-def gather_proposals(local, cap, device=None, group=None):
-    """local: list of (boxes, scores) for this rank's images, in local order.  Returns, on
-    every rank, the list for ALL images in global image order (image i = local[i // world]
-    of rank i % world).  Every rank must hold the same number of images."""
+def _world(group=None):
+    import torch.distributed as dist
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def _agree_max(values, device=None, group=None):
+    """Element-wise MAX of a small int vector over the ranks (one tiny all-reduce)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def _interleave(rows_by_rank, n_rows, keep):
+    """rows_by_rank[r][j] = image j * world + r  ->  global image order, padding dropped."""
+    res = []
+    for j in range(n_rows):
+        for r in range(len(rows_by_rank)):
+            item = keep(rows_by_rank[r][j])
+            if item is not None:
+                res.append(item)
+    return res
+
+
+def gather_proposals(local, cap=None, device=None, group=None):
+    """local: list of (boxes [n,4] f64, scores [n] f32) for this rank's images, in local order.
+    Returns, on every rank, the list for ALL images in global image order (image i =
+    local[i // world] of rank i % world).  cap=None (or too small on any rank) is replaced by the
+    largest box count over all ranks; ranks may hold different numbers of images."""
+    import torch
+    import torch.distributed as dist
+    world = _world(group)
     if world == 1:
         return [(b.copy(), s.copy()) for b, s in local]
-    rl = record_len(cap)
-    buf = np.stack([pack_record(b, s, cap) for b, s in local]) if local else np.zeros((0, rl))
+    n_max = max([b.shape[0] for b, _ in local] + [0])
+    cap_all, rows = _agree_max([max(n_max, cap or 0, 1), len(local)], device=device, group=group)
+    rl = record_len(cap_all)
+    buf = np.zeros((rows, rl), dtype=np.float64)
+    buf[:, 0] = -1.0                                       # padding rows of a short rank
+    for j, (b, s) in enumerate(local):
+        buf[j] = pack_record(b, s, cap_all)
     t = torch.from_numpy(buf)
     if device is not None:
         t = t.to(device)
-    # concatenated form (world * n_local rows): the layout both RCCL and gloo accept
-    out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+    # concatenated form (world * rows rows): the layout both RCCL and gloo accept
+    out = torch.empty((world * rows, rl), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    out = out.cpu().numpy().reshape(world, t.shape[0], t.shape[1])
-    res = []
-    for j in range(len(local)):
-        for r in range(world):
-            res.append(unpack_record(out[r, j], cap))
-    return res
+    out = out.cpu().numpy().reshape(world, rows, rl)
+    return _interleave(out, rows, lambda rec: None if rec[0] < 0 else unpack_record(rec, cap_all))
+
+
+def unpack_device_record(raw, layout, k):
+    """raw: uint8 [bytes] of one az_propose result record -> (boxes [n,4] f64, scores [n] f32),
+    or None for a padding row (n < 0)."""
+    nbytes, n_off, b_off, s_off = layout
+    n = int(raw[n_off:n_off + 4].view(np.int32)[0])
+    if n < 0:
+        return None
+    n = min(n, k)
+    boxes = raw[b_off:b_off + 32 * k].view(np.float64).reshape(k, 4)[:n].copy()
+    scores = raw[s_off:s_off + 4 * k].view(np.float32)[:n].copy()
+    return boxes, scores
+
+
+class DeviceGather(object):
+    """Send buffer of `rows` result records in HBM + the all-gather over them.
+
+        g = DeviceGather(ctx, num_proposals, rows, device)
+        for j in range(n_local):
+            ctx.propose_launch(params); g.stage(j); ctx.propose_fetch()
+        everything = g.gather(n_local)       # all ranks' images, global image order
+
+    stage(j) enqueues a device-to-device copy of the search's result record into row j on the ctx
+    stream (complete when propose_fetch returns); gather() marks the rows past n_local as padding,
+    runs ONE all_gather_into_tensor on the device buffers and unpacks on the host."""
+
+    def __init__(self, ctx, num_proposals, rows, device, group=None):
+        import torch
+        from aznet_hip import ffi
+        self.ctx, self.k, self.rows, self.group = ctx, int(num_proposals), int(rows), group
+        self.layout = ffi.AzContext.result_record_layout(self.k)
+        self.rec_bytes = self.layout[0]
+        self.device = device
+        self.send = torch.zeros((self.rows, self.rec_bytes), dtype=torch.uint8, device=device)
+        self.world = _world(group)
+        self.recv = torch.empty((self.world * self.rows, self.rec_bytes), dtype=torch.uint8, device=device)
+        pad = np.zeros(self.rec_bytes, dtype=np.uint8)
+        pad[self.layout[1]:self.layout[1] + 4] = np.array([-1], dtype=np.int32).view(np.uint8)
+        self._pad = torch.from_numpy(pad).to(device)
+
+    def stage(self, j):
+        assert 0 <= j < self.rows
+        self.ctx.stage_result(self.send.data_ptr() + j * self.rec_bytes, self.rec_bytes)
+
+    def gather(self, n_local, to_host=True):
+        """After the last propose_fetch of the batch (the ctx stream is idle then)."""
+        import torch
+        import torch.distributed as dist
+        if n_local < self.rows:
+            self.send[n_local:] = self._pad
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            got = self.recv
+        else:
+            got = self.send
+        if not to_host:
+            torch.cuda.current_stream(self.send.device).synchronize()
+            return None
+        raw = got.cpu().numpy().reshape(self.world, self.rows, self.rec_bytes)
+        return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))

@@ -31,6 +31,7 @@ SYMBOLS = [
     "az_set_gemm_mode", "az_last_anchors", "az_tune_begin", "az_tune_end", "az_tune_kth_largest",
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
+    "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
 ]
 
 
@@ -48,7 +49,8 @@ class AzStats(ctypes.Structure):
                 ("n_candidates", ctypes.c_int32),
                 ("level_regions", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("level_unique", ctypes.c_int32 * AZ_MAX_LEVELS),
-                ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS)]
+                ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS),
+                ("spec_rows", ctypes.c_int32)]
 
 
 class AzError(RuntimeError):
@@ -95,6 +97,10 @@ def load_library(path=None):
     L.az_load_head.argtypes = [vp, ci, ci, ci, ci] + [fp] * 12
     L.az_set_feature_map_dev.argtypes = [vp, vp, ci, ci, ci]
     L.az_set_feature_map_host.argtypes = [vp, fp, ci, ci, ci]
+    L.az_set_feature_map_dev_async.argtypes = [vp, vp, ci, ci, ci]
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    L.az_result_record_layout.argtypes = [ci, szp, szp, szp, szp]
+    L.az_propose_stage_result_dev.argtypes = [vp, vp, ctypes.c_size_t]
     L.az_propose.argtypes = [vp, ctypes.POINTER(AzParams), dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_propose_launch.argtypes = [vp, ctypes.POINTER(AzParams)]
     L.az_propose_fetch.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
@@ -153,9 +159,9 @@ class AzContext(object):
     """One GPU's search context (az_ctx).  Not thread-safe; one per process/GPU."""
 
     def __init__(self, device=0, max_regions=None, max_candidates=None, gemm_mode=None):
-        """gemm_mode: 0 fp32 MFMA (default), 3 / 2 = int6 on the bf16 matrix cores with fp32 operands
-        split into 3 / 2 bf16 terms for launches of > 64 rois (az_set_gemm_mode); None reads the
-        AZ_GEMM_MODE environment variable."""
+        """gemm_mode: 0 fp32 MFMA (default); 2 = int6 on the bf16 matrix cores with fp32 operands
+        split into two bf16 terms for launches of > 64 rois (az_set_gemm_mode); None reads the
+        AZ_GEMM_MODE environment variable.  Anything else raises ValueError."""
         self.L = load_library()
         h = ctypes.c_void_p()
         rc = self.L.az_create(int(device), ctypes.byref(h))
@@ -172,6 +178,9 @@ class AzContext(object):
                                            int(max_candidates or max_regions * AZ_NUM_SUBREG)))
         if gemm_mode is None:
             gemm_mode = int(os.environ.get("AZ_GEMM_MODE", "0"))
+        if int(gemm_mode) not in (0, 2):
+            self.close()
+            raise ValueError("gemm_mode must be 0 (fp32 MFMA) or 2 (split bf16), got %r" % (gemm_mode,))
         self.gemm_mode = int(gemm_mode)
         if self.gemm_mode:
             self._chk(self.L.az_set_gemm_mode(self.h, self.gemm_mode))
@@ -209,9 +218,13 @@ class AzContext(object):
         self._chk(self.L.az_load_head(self.h, C, n6, n71, n72, *[_p(a, ctypes.c_float) for a in arrs]))
         self.dims = dict(C=C, n6=n6, n71=n71, n72=n72, K6=K6)
 
-    def set_feature_map(self, fmap):
+    def set_feature_map(self, fmap, wait=True):
         """fmap: [1,C,H,W] or [C,H,W]; a NumPy array (copied to HBM) or a CUDA torch tensor
-        (borrowed: its data_ptr is handed to the library, the tensor is kept alive here)."""
+        (borrowed: its data_ptr is handed to the library, the tensor is kept alive here).
+        The ctx stream is not torch's: torch's current stream is synchronised first, so a map the
+        backbone is still writing is never read early.  wait=False (torch tensors only) skips the
+        closing synchronisation of the ctx stream (az_set_feature_map_dev_async): the tensor then
+        has to stay untouched until the next propose/propose_fetch returns."""
         if isinstance(fmap, np.ndarray):
             a = _f32(fmap)
             if a.ndim == 4:
@@ -226,8 +239,12 @@ class AzContext(object):
                 assert t.shape[0] == 1
                 t = t[0]
             assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32"
+            assert t.device.index == self.device, "feature map lives on another GPU than this context"
             C, H, W = (int(x) for x in t.shape)
-            self._chk(self.L.az_set_feature_map_dev(self.h, ctypes.c_void_p(t.data_ptr()), C, H, W))
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()     # producer (backbone) done
+            fn = self.L.az_set_feature_map_dev if wait else self.L.az_set_feature_map_dev_async
+            self._chk(fn(self.h, ctypes.c_void_p(t.data_ptr()), C, H, W))
             self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
 
@@ -281,6 +298,22 @@ class AzContext(object):
         if want_stats:
             out.append(st)
         return out[0] if len(out) == 1 else tuple(out)
+
+    @staticmethod
+    def result_record_layout(num_proposals):
+        """(bytes, n_offset, boxes_offset, scores_offset) of the device-resident result record of a
+        fixed-count search (az_result_record_layout)."""
+        L = load_library()
+        v = [ctypes.c_size_t(0) for _ in range(4)]
+        rc = L.az_result_record_layout(int(num_proposals), *[ctypes.byref(x) for x in v])
+        if rc != AZ_OK:
+            raise AzError(rc, "az_result_record_layout(%r)" % (num_proposals,))
+        return tuple(int(x.value) for x in v)
+
+    def stage_result(self, dst_ptr, cap_bytes):
+        """Between propose_launch and propose_fetch: enqueue a device-to-device copy of the result
+        record to `dst_ptr` (a raw device pointer, e.g. a slot of the RCCL send buffer)."""
+        self._chk(self.L.az_propose_stage_result_dev(self.h, ctypes.c_void_p(int(dst_ptr)), int(cap_bytes)))
 
     def last_candidates(self):
         cap = self.max_candidates
@@ -551,9 +584,30 @@ class AzContext(object):
 _default_ctx = None
 
 
-def default_context(device=0):
-    """Process-wide context used by the drop-in modules (utils.cython_div / cython_nms)."""
+def _rank_device():
+    """This process's GPU: torch's current device when torch has one, else LOCAL_RANK, else 0 --
+    one process per GPU, so the drop-in helpers must not all land on GPU 0."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def set_default_context(ctx):
+    """Make `ctx` (the context of this rank's HipAZNet) the one the drop-in modules use."""
     global _default_ctx
-    if _default_ctx is None:
-        _default_ctx = AzContext(device)
+    _default_ctx = ctx
+    return ctx
+
+
+def default_context(device=None):
+    """Process-wide context used by the drop-in modules (utils.cython_div / cython_nms / cython_bbox,
+    apply_nms): the rank's own net's context when one exists (HipAZNet registers itself), otherwise a
+    context created on this rank's GPU."""
+    global _default_ctx
+    if _default_ctx is None or getattr(_default_ctx, "h", None) is None:
+        _default_ctx = AzContext(_rank_device() if device is None else device)
     return _default_ctx

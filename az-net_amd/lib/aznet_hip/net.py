@@ -29,6 +29,8 @@ class HipAZNet(object):
                  max_regions=None, gemm_mode=None):
         self.ctx = ctx or ffi.AzContext(device, max_regions=max_regions, gemm_mode=gemm_mode)
         self.ctx.load_head(head)
+        if ffi._default_ctx is None or getattr(ffi._default_ctx, "h", None) is None:
+            ffi.set_default_context(self.ctx)      # drop-in helpers (nms, divide_region) use this rank's GPU
         self.backbone = backbone
         self.name = name
         self.blobs = {k: _Blob() for k in ("data", "rois", "conv5_3")}
@@ -47,9 +49,11 @@ class HipAZNet(object):
         return k in ("full", "fc")
 
     # ---- feature map -----------------------------------------------------------------
-    def set_conv(self, conv):
-        """conv: NumPy [1,C,H,W] (copied to HBM) or a CUDA torch tensor (borrowed)."""
-        self.ctx.set_feature_map(conv)
+    def set_conv(self, conv, wait=True):
+        """conv: NumPy [1,C,H,W] (copied to HBM) or a CUDA torch tensor (borrowed; torch's current
+        stream is synchronised before the ctx stream reads it).  wait=False: see
+        AzContext.set_feature_map."""
+        self.ctx.set_feature_map(conv, wait=wait)
         self._conv = conv
 
     def image_blob(self, im, pixel_means, scale):
@@ -70,13 +74,18 @@ class HipAZNet(object):
             raise RuntimeError("HipAZNet has no backbone: supply conv5_3 with set_conv()")
         import torch
         conv = self.backbone(data_blob)
-        torch.cuda.current_stream(conv.device).synchronize()   # the ctx stream reads it next
-        self.set_conv(conv)
+        self.set_conv(conv)                                    # (synchronises torch's stream first)
         return conv
 
     # ---- whole search ------------------------------------------------------------------
-    def propose(self, params, want_scores=False, want_stats=False):
-        return self.ctx.propose(params, want_scores=want_scores, want_stats=want_stats)
+    def propose(self, params, want_scores=False, want_stats=False, stage=None):
+        """stage (multi-GPU): a callable run between launch and fetch, e.g. DeviceGather.stage(j), which
+        enqueues the device-to-device copy of the result record into the RCCL send buffer."""
+        if stage is None:
+            return self.ctx.propose(params, want_scores=want_scores, want_stats=want_stats)
+        self.ctx.propose_launch(params)
+        stage()
+        return self.ctx.propose_fetch(want_scores=want_scores, want_stats=want_stats)
 
     # ---- pycaffe-shaped surface ----------------------------------------------------------
     def forward(self, blobs=None, **kw):

@@ -92,12 +92,13 @@ def _append_boxes(boxes):
     return div._sift_dup(subs, 1 / cfg.DEDUP_BOXES)
 
 
-def im_propose(net, im, return_conv=False, num_proposals=None, conv=None):
+def im_propose(net, im, return_conv=False, num_proposals=None, conv=None, stage=None):
     """Generate object proposals with AZ-Net (test.py:346-414).
 
     net: HipAZNet (or the reference-style dict {'full': HipAZNet, 'fc': HipAZNet})
     im:  HxWx3 uint8/float image, BGR
     conv (extension): a precomputed conv5_3 {name: array/tensor} to skip the backbone.
+    stage (extension, multi-GPU): see HipAZNet.propose.
     Returns Y [n,4] float64 (x1,y1,x2,y2 in original pixels), and the conv dict when
     return_conv is set."""
     hnet = net["full"] if isinstance(net, dict) else net
@@ -109,7 +110,7 @@ def im_propose(net, im, return_conv=False, num_proposals=None, conv=None):
     else:
         hnet.set_conv(conv[cfg.SEAR.AZ_CONV[0]])
     params = _params(im.shape, scales[0], num_proposals)
-    Y, st = hnet.propose(params, want_stats=True)
+    Y, st = hnet.propose(params, want_stats=True, stage=stage)
     if cfg.SEAR.APPEND_BOXES:
         Y = _append_boxes(Y)
         Y[:, 0::4] = np.maximum(Y[:, 0::4], 0)

@@ -58,6 +58,9 @@ def setup_cfg(args, mode):
         if getattr(args, "tz", None) is not None:
             thresh = args.tz
         else:
+            if getattr(args, "thresh_file", None) is None:
+                print("error: one of --thresh / --tz is required in Test mode", file=sys.stderr)
+                sys.exit(2)
             wait_for(args.thresh_file, args.wait)
             thresh = cfg_load_thresh(args.thresh_file)
         cfg_set_mode("Test", thresh)

@@ -90,19 +90,25 @@ def main():
     from aznet_hip import dist as azdist
     from utils.timer import Timer
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    dev = torch.device("cuda", device)
+    dist.init_process_group("nccl", device_id=dev)
     n = len(imdb.image_index)
-    per = (n + world - 1) // world
+    mine = azdist.shard_indices(n, rank, world)
+    rows = (n + world - 1) // world                       # short ranks pad (no image is run twice)
+    # fixed proposal count and nothing appended: the result records go device-to-device into the RCCL send
+    # buffer; otherwise (cfg.SEAR.FIXED_PROPOSAL_NUM off / APPEND_BOXES) host records of an agreed capacity
+    fixed = bool(cfg.SEAR.FIXED_PROPOSAL_NUM) and not cfg.SEAR.APPEND_BOXES
+    gat = azdist.DeviceGather(net.ctx, int(cfg.SEAR.NUM_PROPOSALS), rows, dev) if fixed else None
     t = Timer()
     local = []
-    for j in range(per):
-        i = min(rank + j * world, n - 1)          # the tail re-runs the last image to keep ranks in step
+    for j, i in enumerate(mine):
         im = imdb.image_at(i)
         t.tic()
-        Y = im_propose(nets, im)
+        Y = im_propose(nets, im, stage=(lambda j=j: gat.stage(j)) if fixed else None)
         t.toc()
         local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
-    allp = azdist.gather_proposals(local, int(cfg.SEAR.NUM_PROPOSALS), device=torch.device("cuda", device))[:n]
+    allp = gat.gather(len(mine)) if fixed else azdist.gather_proposals(local, device=dev)
+    assert len(allp) == n
     if rank == 0:
         out_dir = get_output_dir(imdb, net)
         os.makedirs(out_dir, exist_ok=True)

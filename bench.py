@@ -75,6 +75,36 @@ def cpu_baseline(head, fmap, Tz, budget_s=20.0):
                       "hot path only (conv5_3 given)" % (len(times), med)}
 
 
+def self_launch(n):
+    """Run this script under torch.distributed.run with n ranks on 127.0.0.1; the parent never
+    initialises HIP (no torch.cuda call, no exec after GPU init) -- it only waits and relays."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    last_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            last_json = line.rstrip("\n")
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and last_json is None:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    if last_json is not None:
+        print(last_json)
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,7 +122,13 @@ def main():
     ap.add_argument("--no-calibrated", action="store_true",
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
+    ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks as fresh processes (one per GPU, RCCL) BEFORE this
+        # process touches the GPU, relay rank 0's JSON line and exit with the launcher's code.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -104,7 +140,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -115,10 +151,15 @@ def main():
     backbone = VGG16Conv5(device=dev, seed=4321)
     net = HipAZNet(head, backbone=backbone, device=local_rank, name="vgg16_az_net_hip", max_regions=4096)
     from detect.test import _get_image_blob
-    im = synth.make_image(rank, H_IM, W_IM)                  # one image per GPU, seed = rank
+    # images owned by this rank: seeds rank, rank + world, ... (BASELINE config 5 is one image per GPU; the
+    # timed loop rotates through args.maps of them so that no step re-reads the previous step's map)
+    ims = [synth.make_image(rank + world * j, H_IM, W_IM) for j in range(max(1, args.maps))]
+    im = ims[0]
     blob, scales = _get_image_blob(im, net)                  # HIP front-end kernel -> CUDA tensor
     backbone.normalize_output(blob)                          # random-init weights: unit-RMS conv5_3
-    conv = net.compute_conv(blob)                            # resident in HBM from here on
+    convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone() for x in ims]   # resident in HBM from here on
+    conv = convs[0]
+    net.set_conv(conv)
     params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS)
 
     def barrier():
@@ -126,41 +167,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pending = []
+    gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev) if world > 1 else None
+    pending = [0]
     # extra contexts for pipelining independent images on one GPU (same weights, same map)
     nets = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
                     for _ in range(args.inflight - 1)]
     for n in nets[1:]:
         n.set_conv(conv)
 
-    def finish(Y, S, i):
+    def finish(last):
+        """One image done; every gather_every images per rank (and at the end): ONE RCCL all-gather of the
+        records staged device-to-device by the searches, then the host copy of all ranks' proposals."""
         if world > 1:
-            pending.append((Y, S))
-            if len(pending) == args.gather_every or i == args.steps - 1:
-                azdist.gather_proposals(pending, NUM_PROPOSALS, device=dev)
-                del pending[:]
+            pending[0] += 1
+            if pending[0] == args.gather_every or last:
+                res = gat.gather(pending[0])
+                assert len(res) == world * pending[0]
+                pending[0] = 0
 
     def run(nsteps, timed):
         if args.inflight == 1:
             for i in range(nsteps):
-                Y, S = net.propose(params, want_scores=True)
-                finish(Y, S, i if timed else -1)
+                net.set_conv(convs[i % len(convs)], wait=False)       # this step's image (one transpose kernel)
+                net.ctx.propose_launch(params)
+                if gat is not None:
+                    gat.stage(pending[0])
+                net.ctx.propose_fetch(want_scores=True)
+                finish(i == nsteps - 1)
             return
+        assert world == 1, "--inflight > 1 is a single-GPU measurement"
         q = []
         for i in range(nsteps):
             n = nets[i % len(nets)]
             if len(q) == len(nets):
-                m, j = q.pop(0)
-                Y, S = m.ctx.propose_fetch(want_scores=True)
-                finish(Y, S, j if timed else -1)
+                q.pop(0).ctx.propose_fetch(want_scores=True)
+            n.set_conv(convs[i % len(convs)], wait=False)
             n.ctx.propose_launch(params)
-            q.append((n, i))
-        for m, j in q:
-            Y, S = m.ctx.propose_fetch(want_scores=True)
-            finish(Y, S, j if timed else -1)
+            q.append(n)
+        for m in q:
+            m.ctx.propose_fetch(want_scores=True)
 
     run(args.warmup, False)
-    del pending[:]
+    pending[0] = 0
     for n in nets:
         n.ctx.set_profiling(0)
         n.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
@@ -180,6 +228,7 @@ def main():
     Y, S, st = net.propose(params, want_scores=True, want_stats=True)
     uniq = [int(st.level_unique[l]) for l in range(st.n_levels)]
     regions = [int(st.level_regions[l]) for l in range(st.n_levels)]
+    spec_rows = int(st.spec_rows)      # root + its children + ALL children of those (one pass serves levels 1-3)
 
     out = None
     if rank == 0:
@@ -192,13 +241,30 @@ def main():
         achieved = flops_per_image * args.steps / (gemm_ms_total * 1e-3) / 1e12 if gemm_ms_total > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate runs); cannot be collected live, so it is read from the committed summary.
-        traffic = None
+        traffic, traffic_source = None, None
         tfile = os.path.join(REPO, "profiles", "roofline_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/roofline_traffic.json (%s): rocprofv3 --pmc passes of this command, "
+                                  "FETCH_SIZE x2 (gfx950) + WRITE_SIZE per launch; NOT measured in this run"
+                                  % tj.get("source", "committed summary"))
             except Exception:
                 traffic = None
+        # the three int6 launch shapes, each against ITS bound: max(weights / 8 TB/s, flops / 157.3 TF)
+        fc6 = {}
+        for n, l, ms in ktimes:
+            if n == "fc6_gemm":
+                fc6.setdefault(l, []).append(ms)
+        fc6_shapes = []
+        for l, v in sorted(fc6.items()):
+            rows = spec_rows if l < 0 else uniq[l]
+            t_us = float(np.mean(v)) * 1e3
+            fl = rows * 2.0 * 25088 * 4096
+            tmin = max(25088 * 4096 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
+            fc6_shapes.append({"level": "speculative 1-3" if l < 0 else l + 1, "rows": int(rows), "avg_us": t_us,
+                               "tflops": fl / t_us / 1e6, "t_min_us": tmin, "frac": tmin / t_us})
         per_level = {}
         for n, l, ms in ktimes:
             per_level.setdefault("%s@L%d" % (n, l + 1), []).append(ms)
@@ -210,8 +276,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "VGG16 AZ proposal hot path, 600x1000 image (scale 1.0), batch=1 per GPU, "
                                    "Tz=%g, regions/level %s, unique RoIs/level %s, top-%d of %d candidates; "
-                                   "conv5_3 [1,512,38,63] resident in HBM" %
-                                   (args.tz, regions, uniq, NUM_PROPOSALS, st.n_candidates),
+                                   "conv5_3 %s resident in HBM, %d distinct images rotated" %
+                                   (args.tz, regions, uniq, NUM_PROPOSALS, st.n_candidates,
+                                    [int(x) for x in conv.shape], len(convs)),
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
                        "gather": ("RCCL all_gather every %d images/rank" % args.gather_every) if world > 1 else "none"},
@@ -220,7 +287,8 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": flops_per_image / (n_launch / max(args.steps, 1)),
                          "avg_launch_ms": gemm_ms_total / n_launch,
-                         "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic},
+                         "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic,
+                         "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes},
             "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
                            "frac": floor_us / (ms_step * 1e3)},
             "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in sorted(per_level.items())},

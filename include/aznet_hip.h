@@ -50,7 +50,8 @@ typedef struct {
     double  scale;            /* im_scale of the single test scale (test.py:45-50)     */
     double  Tz;               /* cfg.SEAR.Tz  (config.py:272-280); compared in double  */
     double  Tc;               /* cfg.SEAR.Tc  (config.py:171), used when !fixed_num    */
-    double  dedup;            /* cfg.DEDUP_BOXES = 1/16 (config.py:206)                */
+    double  dedup;            /* cfg.DEDUP_BOXES = 1/16 (config.py:206); <= 0: no dedup
+                                 (test.py:211 `if cfg.DEDUP_BOXES > 0:`): every region forwarded */
     double  eps;              /* cfg.EPS = 1e-14 (config.py:216)                       */
     double  min_side;         /* cfg.SEAR.MIN_SIDE = 10 (config.py:186)                */
     int32_t batch_size;       /* cfg.SEAR.BATCH_SIZE (config.py:189): dedup chunk size */
@@ -75,6 +76,8 @@ typedef struct {
     int32_t level_regions[AZ_MAX_LEVELS]; /* B.shape[0] per level                        */
     int32_t level_unique[AZ_MAX_LEVELS];  /* rois actually forwarded (after 1/16 dedup)  */
     int32_t level_zoomed[AZ_MAX_LEVELS];  /* len(indZ)                                   */
+    int32_t spec_rows;                    /* rois forwarded by the speculative pass that serves
+                                             levels 1-3 in one launch (0: levels ran one by one) */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
@@ -90,10 +93,11 @@ int az_set_limits(az_ctx *ctx, int max_regions, int max_candidates);
 /* Optional, before az_load_head.  How int6 (95 % of the head's FLOPs) is evaluated for launches of
  * more than 64 rois:
  *   0 (default)  fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain;
- *   3            fp32 operands split into three bf16 round-off terms, six bf16 MFMAs per product
- *                with fp32 accumulation: products good to 2^-24 (fp32-grade), 6/16 of the cost;
- *   2            two terms, three MFMAs: products good to ~2^-16 (outputs still within 1e-4), 3/16.
- * Launches of <= 64 rois are weight-streaming bound and always use the fp32 kernel. */
+ *   2            fp32 operands split into two bf16 round-off terms, three bf16 MFMAs per product with
+ *                fp32 accumulation: products good to ~2^-16 (outputs still within 1e-4), 3/16 of the
+ *                matrix-pipe cost.
+ * Any other value is AZ_ERR_INVALID.  Launches of <= 64 rois are weight-streaming bound and always use
+ * the fp32 kernel. */
 int az_set_gemm_mode(az_ctx *ctx, int parts);
 
 /* Replaces caffe.Net(test_fc.prototxt, caffemodel) (tools/prop_az.py:95-96): the AZ head
@@ -115,6 +119,10 @@ int az_load_head(az_ctx *ctx, int C, int n6, int n71, int n72,
  * _host: host array. */
 int az_set_feature_map_dev(az_ctx *ctx, const float *dev_ptr, int C, int H, int W);
 int az_set_feature_map_host(az_ctx *ctx, const float *host_ptr, int C, int H, int W);
+/* As _dev, without the closing synchronisation: the transpose is only enqueued on the ctx stream,
+ * so handing over the next image's map costs no host round trip.  The source must stay valid (and
+ * unmodified) until the next az_propose_fetch / az_propose on this ctx returns. */
+int az_set_feature_map_dev_async(az_ctx *ctx, const float *dev_ptr, int C, int H, int W);
 
 /* ---- the hot path --------------------------------------------------------------- */
 /* Replaces im_propose (lib/detect/test.py:346-414) given the cached conv5_3: the whole
@@ -128,6 +136,16 @@ int az_propose(az_ctx *ctx, const az_params *p, double *boxes_out, float *scores
 int az_propose_launch(az_ctx *ctx, const az_params *p);
 int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out,
                      az_stats *stats);
+/* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size
+ * records; the reference itself is single-process).  A fixed-count search (params.fixed_num) leaves
+ * its result in HBM as ONE record of az_result_record_layout(k) bytes: int32 n at n_offset,
+ * boxes f64 [k][4] at boxes_offset, scores f32 [k] at scores_offset (rows >= n undefined).
+ * az_propose_stage_result_dev, called between az_propose_launch and az_propose_fetch, enqueues a
+ * device-to-device copy of that record to dst_dev (e.g. a slot of the RCCL send buffer) on the ctx
+ * stream; it is complete when az_propose_fetch returns.  No host hop for the exchanged data. */
+int az_result_record_layout(int num_proposals, size_t *bytes, size_t *n_offset, size_t *boxes_offset,
+                            size_t *scores_offset);
+int az_propose_stage_result_dev(az_ctx *ctx, void *dst_dev, size_t cap_bytes);
 /* All candidates of the last az_propose, before selection (Y / aScores of test.py:380-381). */
 int az_last_candidates(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out);
 

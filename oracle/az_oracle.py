@@ -263,7 +263,14 @@ def get_rois_blob(im_rois, scale):
 
 
 def roi_dedup(rois_blob, dedup=1. / 16.):
-    """test.py:210-218: feature-space dedup.  Returns (index, inv_index)."""
+    """test.py:210-218: feature-space dedup.  Returns (index, inv_index).
+    cfg.DEDUP_BOXES <= 0 skips the dedup (test.py:211 `if cfg.DEDUP_BOXES > 0:`): identity.
+    (The reference's _az_forward then fails at test.py:253, np.hstack of a 1-D and an [R,1] array,
+    because z_tb is only raveled inside the dedup branch; _frcnn_forward, test.py:281-313, works.
+    The restatement ravels in both cases -- the evident intent.)"""
+    if not dedup > 0:
+        ident = np.arange(rois_blob.shape[0], dtype=np.int64)
+        return ident, ident.copy()
     v = np.array([1, 1e3, 1e6, 1e9, 1e12])
     hashes = np.round(rois_blob * dedup).dot(v)
     _, index, inv_index = np.unique(hashes, return_index=True, return_inverse=True)

@@ -25,7 +25,8 @@ def _worker(rank, world, port, num_images, cap, q):
     try:
         mine = azdist.shard_indices(num_images, rank, world)
         local = [_fake(i, cap) for i in mine]
-        allp = azdist.gather_proposals(local, cap)
+        # cap=None / a cap that only some ranks exceed: the capacity is agreed collectively (no hang, no assert)
+        allp = azdist.gather_proposals(local, None if num_images % 2 else cap // 2)
         ok = len(allp) == num_images
         for i, (b, s) in enumerate(allp):
             rb, rs = _fake(i, cap)
@@ -43,7 +44,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("num_images,cap", [(8, 300), (2, 16)])
+@pytest.mark.parametrize("num_images,cap", [(8, 300), (2, 16), (7, 300), (1, 16)])      # 7, 1: ragged shards
 def test_gather_two_ranks(num_images, cap):
     world = 2
     ctx = mp.get_context("spawn")
@@ -69,3 +70,26 @@ def test_record_roundtrip_and_sharding():
     assert azdist.shard_indices(8, 1, 4) == [1, 5] and azdist.shard_indices(3, 2, 4) == [2]
     # single process: gather is the identity
     assert len(azdist.gather_proposals([(b, s)], 300)) == 1
+    with pytest.raises(ValueError):
+        azdist.pack_record(b, s, 10)
+
+
+def test_device_record_layout_and_unpack():
+    """The device-resident result record of az_propose (az_result_record_layout) as DeviceGather unpacks it."""
+    from aznet_hip import ffi
+    k = 300
+    layout = ffi.AzContext.result_record_layout(k)
+    nbytes, n_off, b_off, s_off = layout
+    assert nbytes == 512 + 36 * k and b_off == 512 and s_off == 512 + 32 * k and 0 < n_off < 512 and n_off % 4 == 0
+    b, s = _fake(2, k)
+    n = b.shape[0]
+    raw = np.zeros(nbytes, dtype=np.uint8)
+    raw[n_off:n_off + 4] = np.array([n], dtype=np.int32).view(np.uint8)
+    raw[b_off:b_off + 32 * n] = b.reshape(-1).view(np.uint8)
+    raw[s_off:s_off + 4 * n] = s.view(np.uint8)
+    b2, s2 = azdist.unpack_device_record(raw, layout, k)
+    assert np.array_equal(b, b2) and np.array_equal(s, s2)
+    raw[n_off:n_off + 4] = np.array([-1], dtype=np.int32).view(np.uint8)
+    assert azdist.unpack_device_record(raw, layout, k) is None
+    with pytest.raises(ffi.AzError):
+        ffi.AzContext.result_record_layout(0)

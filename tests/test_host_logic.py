@@ -61,7 +61,7 @@ def test_image_scale_and_blob():
 
 
 def test_synthetic_imdb_and_timer():
-    from aznet_hip.imdb import get_imdb
+    from datasets.factory import get_imdb
     from utils.timer import Timer
     db = get_imdb("synthetic_600x1000_3")
     assert len(db.image_index) == 3 and db.image_at(1).shape == (600, 1000, 3) and db.name == "synthetic_600x1000_3"
