@@ -38,7 +38,7 @@ class VGG16Conv5(object):
                 w = torch.randn(cout, cin, 3, 3, generator=g) * float(np.sqrt(2.0 / (cin * 9)))
                 b = torch.zeros(cout)
             self.layers.append((name, w.to(self.device), b.to(self.device)))
-            cin = cout
+            cin = int(w.shape[0])
         self.out_channels = cin
 
     @torch.no_grad()

@@ -195,7 +195,8 @@ def test_proposals(net, imdb):
         _t['im_prop'].tic()
         prop_boxes[i] = im_propose(net, im)
         _t['im_prop'].toc()
-        num_boxes += prop_boxes[i].shape[0]
+        # (num_boxes stays 0.0: the reference's per-image bookkeeping is commented out, test.py:515-526,
+        #  so its "On average, 0.0 boxes per image are generated" line is reproduced as is)
         print('im_prop: {:d}/{:d} {:.3f}s'.format(i + 1, num_images, _t['im_prop'].average_time))
     recall = 0            # the reference's recall bookkeeping is commented out (test.py:515-531)
     prop = {'boxes': prop_boxes, 'time': _t['im_prop'].average_time, 'recall': recall}

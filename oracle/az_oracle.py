@@ -494,6 +494,55 @@ def im_detect_shared(az_net, frcnn_net, im_shape, scale, num_classes, cfg):
     return scores, pred_boxes, boxes
 
 
+def net_shared_select(per_image, num_classes, max_per_image=100):
+    """The per-class bookkeeping of test_net_shared (test.py:670-760) as a pure function of what
+    im_detect_shared returned per image: per_image = [(scores [R,K] f64, boxes [R,4K] f64), ...].
+    Returns (all_boxes[cls][image] float32 [n,5], thresh [K])."""
+    import heapq
+    num_images = len(per_image)
+    max_per_set = 800 // (num_classes - 1) * num_images        # Python-2 integer division (test.py:676)
+    thresh = -np.inf * np.ones(num_classes)
+    top_scores = [[] for _ in range(num_classes)]
+    all_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    for i, (scores, boxes) in enumerate(per_image):
+        for j in range(1, num_classes):
+            inds = np.where(scores[:, j] > thresh[j])[0]                     # test.py:725
+            cls_scores = scores[inds, j]
+            cls_boxes = boxes[inds, j * 4:(j + 1) * 4]
+            top_inds = np.argsort(-cls_scores)[:max_per_image]               # test.py:728
+            cls_scores = cls_scores[top_inds]
+            cls_boxes = cls_boxes[top_inds, :]
+            for val in cls_scores:                                           # test.py:732-733
+                heapq.heappush(top_scores[j], val)
+            if len(top_scores[j]) > max_per_set:                             # test.py:736-739
+                while len(top_scores[j]) > max_per_set:
+                    heapq.heappop(top_scores[j])
+                thresh[j] = top_scores[j][0]
+            all_boxes[j][i] = np.hstack((cls_boxes, cls_scores[:, np.newaxis])).astype(np.float32, copy=False)
+    for j in range(1, num_classes):                                          # test.py:755-758
+        for i in range(num_images):
+            inds = np.where(all_boxes[j][i][:, -1] > thresh[j])[0]
+            all_boxes[j][i] = all_boxes[j][i][inds, :]
+    return all_boxes, thresh
+
+
+def apply_nms(all_boxes, thresh):
+    """test.py:467-484 (`dets == []` only ever matched the empty-list placeholder)."""
+    num_classes = len(all_boxes)
+    num_images = len(all_boxes[0])
+    nms_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    for cls_ind in range(num_classes):
+        for im_ind in range(num_images):
+            dets = all_boxes[cls_ind][im_ind]
+            if isinstance(dets, list) and dets == []:
+                continue
+            keep = nms(dets, thresh)
+            if len(keep) == 0:
+                continue
+            nms_boxes[cls_ind][im_ind] = dets[keep, :].copy()
+    return nms_boxes
+
+
 # --------------------------------------------------------------------------
 # Callers either side of the path (SURVEY 8f rows 3-4): image front-end, recall
 # evaluation, zoom-threshold tuner.

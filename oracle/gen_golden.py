@@ -16,6 +16,9 @@ Edits applied to the temp copies (NumPy removed the aliases the 2015 code uses):
   lib/detect/{test,config}.py, lib/utils/{blob,timer}.py: `lib2to3`, literal TABs in
   config.py -> spaces, `np.float/np.int/np.bool` aliases installed before import,
   stub modules `caffe`, `cv2` (resize returns zeros of the scaled shape), `easydict`.
+  test.py:477    `if dets == []:` -> `if isinstance(dets, list) and dets == []:`  (NumPy of 2015 answered
+                 `ndarray == []` with a scalar False -- "elementwise comparison failed" -- so the test only
+                 ever fired for the empty-list placeholder; NumPy 2 raises a broadcast error instead)
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/)
 """
@@ -78,6 +81,8 @@ def build_reference(tmp):
              os.path.join(py, "lib", "utils", "blob.py"), os.path.join(py, "lib", "utils", "timer.py")]
     subprocess.check_call([sys.executable, "-m", "lib2to3", "-w", "-n"] + files,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    sub(os.path.join(py, "lib", "detect", "test.py"),
+        [("if dets == []:", "if isinstance(dets, list) and dets == []:")])
     cfgp = os.path.join(py, "lib", "detect", "config.py")
     src = open(cfgp).read().expandtabs(8)
     open(cfgp, "w").write(src)

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Randomised cross-check of the search paths on the GPU (checker script, not collected by pytest):
-for random image shapes / Tz / BATCH_SIZE / MAX_SIZE the default path (speculative levels 1-3, fused
-geometry, counting top-k) must equal, bit for bit, the plain path (level by level, multi-launch
-geometry, radix select), and a subset is also compared with the oracle's loop driven by the HIP head.
-usage: stress_gpu.py [n_cases] [seed]"""
+"""Randomised cross-check of the search paths on the GPU: for random image shapes / Tz / BATCH_SIZE /
+MAX_SIZE / proposal counts the default path (speculative levels 1-3, fused geometry, counting top-k) must
+equal, bit for bit, the plain path (level by level, multi-launch geometry, radix select), and every fourth
+case is also compared with the oracle's loop driven by the HIP head.
+`run_case(net, case)` is what tests/test_gpu_stress.py parametrises (the driver runs it under pytest -m gpu);
+as a script: stress_gpu.py [n_cases] [first_case] for longer soaks."""
 import os
 import sys
 
@@ -12,79 +13,95 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "az-net_amd", "lib"))
 sys.path.insert(0, os.path.join(HERE, ".."))
-from aznet_hip import ffi, synth              # noqa: E402
-from aznet_hip.net import HipAZNet            # noqa: E402
-from oracle import az_oracle as orc           # noqa: E402
+
+
+def make_net():
+    from aznet_hip import synth
+    from aznet_hip.net import HipAZNet
+    return HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="stress")
+
+
+def run_case(net, case):
+    """One random configuration, seeded by `case`.  Returns (ok, description, reason)."""
+    from aznet_hip import ffi, synth
+    from oracle import az_oracle as orc
+    rng = np.random.RandomState(1000003 * (case + 1) % (2 ** 31 - 1))
+    H = int(rng.randint(40, 900)); W = int(rng.randint(40, 1300))
+    max_size = int(rng.choice([1000, 800, 600]))
+    scale = 600.0 / min(H, W)
+    if np.round(scale * max(H, W)) > max_size:
+        scale = float(max_size) / max(H, W)
+    fh = synth.conv_out_size(int(round(H * scale))); fw = synth.conv_out_size(int(round(W * scale)))
+    if orc.num_levels(H, W) - 1 < 1:
+        return True, "case %d skipped (%dx%d: no level)" % (case, H, W), ""
+    fmap = synth.make_feature_map(100 + case, synth.SMALL_DIMS["C"], fh, fw)
+    net.set_conv(fmap)
+    batch = int(rng.choice([10000, 10000, 1000, 100, 37]))
+    nprop = int(rng.choice([300, 300, 2000, 50]))
+    fixed = bool(rng.rand() < 0.85)
+    dedup = 0.0 if rng.rand() < 0.1 else 1. / 16.           # cfg.DEDUP_BOXES <= 0: no feature-space dedup
+    # Tz from the zoom distribution of this image
+    net.propose(ffi.AzContext.make_params(H, W, scale, 0.0, num_proposals=300, batch_size=batch, tune=True))
+    z = net.ctx.last_anchors()[1].astype(np.float64)
+    Tz = float(rng.choice([0.0, np.quantile(z, rng.uniform(0.2, 0.9)), z[rng.randint(z.size)], 1.5]))
+    Tc = float(np.quantile(z, 0.5))
+    kw = dict(num_proposals=nprop, batch_size=batch, fixed_num=fixed, Tc=Tc, dedup=dedup)
+    desc = "case %d: H=%d W=%d scale=%.4f Tz=%r batch=%d nprop=%d fixed=%s dedup=%g" % (
+        case, H, W, scale, Tz, batch, nprop, fixed, dedup)
+    a = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, **kw), want_scores=True, want_stats=True)
+    Ya, Sa = net.ctx.last_candidates()
+    b = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, radix_select=True, **kw),
+                    want_scores=True, want_stats=True)
+    Yb, Sb = net.ctx.last_candidates()
+    ok = (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(Ya, Yb) and
+          np.array_equal(Sa, Sb) and a[2].num_eval == b[2].num_eval and a[2].depth == b[2].depth)
+    if not ok:
+        return False, desc, "fused-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d depth %d/%d" % (
+            np.array_equal(a[0], b[0]), np.array_equal(a[1], b[1]), np.array_equal(Ya, Yb), np.array_equal(Sa, Sb),
+            a[2].num_eval, b[2].num_eval, a[2].depth, b[2].depth)
+    desc += " levels %d eval %d cand %d" % (a[2].n_levels, a[2].num_eval, Ya.shape[0])
+    if case % 4:
+        return True, desc, ""
+
+    class Inj(object):
+        name = "inj"; blobs = net.blobs
+
+        def forward(self, blobs=None, **k2):
+            k2.pop("data", None); k2["conv5_3"] = fmap
+            return net.forward(blobs=blobs, **k2)
+    inj = Inj()
+    cfg = orc.OracleCfg(Tz=Tz, BATCH_SIZE=batch, NUM_PROPOSALS=nprop, FIXED_PROPOSAL_NUM=fixed, Tc=Tc,
+                        DEDUP_BOXES=dedup)
+    Yref, tr = orc.im_propose({"full": inj, "fc": inj}, (H, W), scale, cfg, return_trace=True)
+    # boxes: 1 ulp of the f32 exp (NumPy's SIMD expf vs the device's) times half a predicted width of up to ~2500 px
+    ok = (a[2].num_eval == tr["num_eval"] and Ya.shape == tr["Y_all"].shape and
+          np.array_equal(Sa.astype(np.float64), tr["aScores"]) and
+          np.allclose(Ya, tr["Y_all"], rtol=1e-6, atol=3e-4) and a[0].shape == Yref.shape)
+    if ok:
+        return True, desc + " (+oracle loop)", ""
+    same = Ya.shape == tr["Y_all"].shape
+    dS = np.abs(Sa.astype(np.float64) - tr["aScores"]).max() if same else -1
+    dY = np.abs(Ya - tr["Y_all"]).max() if same else -1
+    why = "vs oracle loop: max|dS| %.3g max|dY| %.3g Yref %s top %s; eval %d/%d shapes %s/%s levels gpu %s oracle %s uniq gpu %s oracle %s" % (
+        dS, dY, Yref.shape, a[0].shape, a[2].num_eval, tr["num_eval"], Ya.shape, tr["Y_all"].shape,
+        [int(a[2].level_regions[l]) for l in range(a[2].n_levels)], [lv["B"].shape[0] for lv in tr["levels"]],
+        [int(a[2].level_unique[l]) for l in range(a[2].n_levels)],
+        [sum(f["U"] for f in lv["fwd"]) for lv in tr["levels"]])
+    return False, desc, why
 
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
-    net = HipAZNet(head, name="stress")
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    net = make_net()
     bad = 0
-    for case in range(n_cases):
-        H = int(rng.randint(40, 900)); W = int(rng.randint(40, 1300))
-        max_size = int(rng.choice([1000, 800, 600]))
-        scale = 600.0 / min(H, W)
-        if np.round(scale * max(H, W)) > max_size:
-            scale = float(max_size) / max(H, W)
-        fh = synth.conv_out_size(int(round(H * scale))); fw = synth.conv_out_size(int(round(W * scale)))
-        if orc.num_levels(H, W) - 1 < 1:
-            continue
-        fmap = synth.make_feature_map(100 + case, synth.SMALL_DIMS["C"], fh, fw)
-        net.set_conv(fmap)
-        batch = int(rng.choice([10000, 10000, 1000, 100, 37]))
-        nprop = int(rng.choice([300, 300, 2000, 50]))
-        fixed = bool(rng.rand() < 0.85)
-        # Tz from the zoom distribution of this image
-        net.propose(ffi.AzContext.make_params(H, W, scale, 0.0, num_proposals=300, batch_size=batch, tune=True))
-        z = net.ctx.last_anchors()[1].astype(np.float64)
-        Tz = float(rng.choice([0.0, np.quantile(z, rng.uniform(0.2, 0.9)), z[rng.randint(z.size)], 1.5]))
-        Tc = float(np.quantile(z, 0.5))
-        kw = dict(num_proposals=nprop, batch_size=batch, fixed_num=fixed, Tc=Tc)
-        a = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, **kw), want_scores=True, want_stats=True)
-        Ya, Sa = net.ctx.last_candidates()
-        b = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, radix_select=True, **kw),
-                        want_scores=True, want_stats=True)
-        Yb, Sb = net.ctx.last_candidates()
-        ok = (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(Ya, Yb) and
-              np.array_equal(Sa, Sb) and a[2].num_eval == b[2].num_eval and a[2].depth == b[2].depth)
-        msg = ""
-        why = ""
-        if not ok:
-            why = "fused-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d depth %d/%d" % (
-                np.array_equal(a[0], b[0]), np.array_equal(a[1], b[1]), np.array_equal(Ya, Yb), np.array_equal(Sa, Sb),
-                a[2].num_eval, b[2].num_eval, a[2].depth, b[2].depth)
-        if ok and case % 4 == 0:
-            class Inj(object):
-                name = "inj"; blobs = net.blobs
-
-                def forward(self, blobs=None, **k2):
-                    k2.pop("data", None); k2["conv5_3"] = fmap
-                    return net.forward(blobs=blobs, **k2)
-            inj = Inj()
-            cfg = orc.OracleCfg(Tz=Tz, BATCH_SIZE=batch, NUM_PROPOSALS=nprop, FIXED_PROPOSAL_NUM=fixed, Tc=Tc)
-            Yref, tr = orc.im_propose({"full": inj, "fc": inj}, (H, W), scale, cfg, return_trace=True)
-            ok = (a[2].num_eval == tr["num_eval"] and Ya.shape == tr["Y_all"].shape and
-                  np.array_equal(Sa.astype(np.float64), tr["aScores"]) and
-                  np.allclose(Ya, tr["Y_all"], rtol=1e-6, atol=3e-4) and a[0].shape == Yref.shape)   # 1 ulp of the f32 exp
-                  # (NumPy's SIMD expf vs the device's) times half a predicted width of up to ~2500 px
-            msg = " (+oracle loop)"
-            if not ok:
-                dS = np.abs(Sa.astype(np.float64) - tr["aScores"]).max() if Ya.shape == tr["Y_all"].shape else -1
-                dY = np.abs(Ya - tr["Y_all"]).max() if Ya.shape == tr["Y_all"].shape else -1
-                why = "vs oracle loop: max|dS| %.3g max|dY| %.3g Yref %s top %s; eval %d/%d shapes %s/%s levels gpu %s oracle %s uniq gpu %s oracle %s" % (
-                    dS, dY, Yref.shape, a[0].shape,
-                    a[2].num_eval, tr["num_eval"], Ya.shape, tr["Y_all"].shape,
-                    [int(a[2].level_regions[l]) for l in range(a[2].n_levels)], [lv["B"].shape[0] for lv in tr["levels"]],
-                    [int(a[2].level_unique[l]) for l in range(a[2].n_levels)],
-                    [sum(f["U"] for f in lv["fwd"]) for lv in tr["levels"]])
+    for case in range(first, first + n_cases):
+        ok, desc, why = run_case(net, case)
         if not ok:
             bad += 1
-            print("MISMATCH case %d: H=%d W=%d scale=%.4f Tz=%r batch=%d nprop=%d fixed=%s | %s" % (case, H, W, scale, Tz, batch, nprop, fixed, why))
+            print("MISMATCH %s | %s" % (desc, why))
         elif case % 20 == 0:
-            print("case %d ok%s: %dx%d levels %d eval %d cand %d" % (case, msg, H, W, a[2].n_levels, a[2].num_eval, Ya.shape[0]))
+            print("ok %s" % desc)
     print("stress: %d cases, %d mismatches" % (n_cases, bad))
     sys.exit(1 if bad else 0)
 

@@ -41,6 +41,38 @@ def _proto_classes():
     return message_factory.GetMessageClass(pool.FindMessageTypeByName("mini.NetParameter"))
 
 
+def write_az_caffemodel(path, head, conv, fmt):
+    """An AZ-Net .caffemodel (InnerProduct head + VGG16 conv layers) serialised by the REAL protobuf encoder:
+    fmt 'v2' = NetParameter.layer (LayerParameter, BlobShape dims), 'v1' = NetParameter.layers
+    (V1LayerParameter, legacy num/channels/height/width).  Also used by tests/test_gpu_harness.py."""
+    Net = _proto_classes()
+    net = Net(name="az_" + fmt)
+    net.input.append("data")
+    named = [("int6", head["W6"], head["b6"]), ("int7_1", head["W71"], head["b71"]), ("int7_2", head["W72"], head["b72"]),
+             ("adj_score", head["Was"], head["bas"]), ("adj_bbox", head["Wab"], head["bab"]),
+             ("zoom_score", head["Wz"], head["bz"])]
+    named = [(k, w, b) for k, (w, b) in conv.items()] + named
+
+    def put(blobs, a):
+        bl = blobs.add()
+        if fmt == "v2":
+            bl.shape.dim.extend(a.shape)
+        else:
+            sh = (1,) * (4 - a.ndim) + tuple(a.shape)
+            bl.num, bl.channels, bl.height, bl.width = [int(x) for x in sh]
+        bl.data.extend(np.asarray(a, dtype=np.float32).ravel().tolist())
+    for name, w, b in named:
+        if fmt == "v2":
+            lay = net.layer.add(name=name, type="Convolution" if name.startswith("conv") else "InnerProduct")
+            net.layer.add(name="relu_" + name, type="ReLU")           # weightless layers in between
+        else:
+            lay = net.layers.add(name=name, type=4 if name.startswith("conv") else 14)
+        put(lay.blobs, w)
+        put(lay.blobs, b)
+    with open(path, "wb") as f:
+        f.write(net.SerializeToString())
+
+
 def test_reader_against_real_protobuf_encoder(tmp_path):
     Net = _proto_classes()
     rng = np.random.RandomState(0)
@@ -93,3 +125,21 @@ def test_heads_roundtrip_through_writer(tmp_path, v1, legacy):
         assert np.array_equal(got[k], det[k]), k
     with pytest.raises(KeyError):
         cm.az_head_from_layers(cm.load_caffemodel(str(f2)))
+
+
+@pytest.mark.parametrize("fmt", ["v1", "v2"])
+def test_full_net_files_from_the_real_encoder(tmp_path, fmt):
+    """Head + conv layers written by the protobuf package in both layer formats -> identical arrays back."""
+    head = synth.make_head(seed=5, **synth.SMALL_DIMS)
+    rng = np.random.RandomState(2)
+    conv = {"conv1_1": (rng.randn(4, 3, 3, 3).astype(np.float32), rng.randn(4).astype(np.float32)),
+            "conv5_3": (rng.randn(16, 4, 3, 3).astype(np.float32), rng.randn(16).astype(np.float32))}
+    f = tmp_path / "net.caffemodel"
+    write_az_caffemodel(str(f), head, conv, fmt)
+    layers = cm.load_caffemodel(str(f))
+    got = cm.az_head_from_layers(layers)
+    for k in head:
+        assert got[k].shape == head[k].shape and np.array_equal(got[k], head[k]), k
+    bb = cm.backbone_from_layers(layers)
+    for k, (w, b) in conv.items():
+        assert np.array_equal(bb[k][0], w) and np.array_equal(bb[k][1], b)

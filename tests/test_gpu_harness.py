@@ -1,0 +1,330 @@
+"""The harness / CLI row: `test_proposals`, `test_net_shared`,
+`tools/prop_az.py`, the `.caffemodel` path and the VGG16 plumbing, on the GPU.
+
+Pinned by tests/golden/g13_harness.npz -- what the REFERENCE's own test_proposals / test_net_shared
+(lib/detect/test.py:486-539, 670-778) printed and pickled for a 2-image stub imdb with the seed-77 / seed-99
+small heads on the CPU (oracle/gen_golden_harness.py)."""
+import io
+import os
+import pickle
+import re
+import shutil
+import subprocess
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from helpers import load
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(REPO, "az-net_amd", "tools")
+
+
+def scrub(text):
+    return re.sub(r"\d+\.\d{3}s", "0.000s", text)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet, HipDetNet
+    from oracle import az_oracle as orc
+    return torch, ffi, synth, HipAZNet, HipDetNet, orc
+
+
+@pytest.fixture()
+def harness_cfg():
+    """cfg as gen_golden_harness.py set it; restored afterwards."""
+    from detect import config as C
+    old = (C.cfg.TEST.NUM_PROPOSALS, C.cfg.SEAR.get("Tz", 0.0), C.cfg.EXP_DIR, C.cfg.TEST.MAX_SIZE,
+           C.cfg.SEAR.BATCH_SIZE)
+    C.cfg.TEST.MAX_SIZE = 1000
+    C.cfg.SEAR.BATCH_SIZE = 10000
+    C.cfg.TEST.NUM_PROPOSALS = 100
+    C.cfg_set_path("harness_test")
+    C.cfg_set_mode("Test", 0.0)
+    yield C
+    C.cfg.TEST.NUM_PROPOSALS = old[0]
+    C.cfg_set_mode("Test", old[1])
+    C.cfg.EXP_DIR = old[2]
+    C.cfg.TEST.MAX_SIZE, C.cfg.SEAR.BATCH_SIZE = old[3], old[4]
+    shutil.rmtree(os.path.join(C.cfg.ROOT_DIR, "output", "harness_test"), ignore_errors=True)
+
+
+class _MapBackbone(object):
+    """Stands where VGG16 would: hands back the seeded conv5_3 of the image the imdb served last (the golden
+    run's 'full' net did the same), as a CUDA tensor."""
+
+    def __init__(self, torch, synth, C, fh, fw):
+        self.torch, self.synth, self.C, self.fh, self.fw = torch, synth, C, fh, fw
+        self.device = torch.device("cuda", 0)
+        self.cur = 0
+
+    def __call__(self, blob):
+        assert tuple(blob.shape[:2]) == (1, 3)
+        m = self.synth.make_feature_map(40 + self.cur, self.C, self.fh, self.fw)
+        return self.torch.from_numpy(m).to(self.device)
+
+
+def _stub_imdb(synth, g, backbone):
+    from datasets.imdb import imdb as imdb_base
+    H, W, n = int(g["H"]), int(g["W"]), int(g["n_img"])
+
+    class Stub(imdb_base):
+        def __init__(self):
+            imdb_base.__init__(self, "stub_2img")
+            self._image_index = list(range(n))
+            self._classes = ["c%d" % i for i in range(21)]
+            self.nms_dets = None
+
+        def image_at(self, i):
+            backbone.cur = i
+            return synth.make_image(i, H, W)
+
+        def image_path_at(self, i):
+            return "synthetic:/%d" % i
+
+        def evaluate_detections(self, nms_dets, output_dir):
+            self.nms_dets, self.eval_dir = nms_dets, output_dir
+    return Stub()
+
+
+@pytest.fixture()
+def rig(mods, harness_cfg):
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    g = load("g13_harness.npz")
+    H, W, scale = int(g["H"]), int(g["W"]), float(g["scale"])
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    bb = _MapBackbone(torch, synth, synth.SMALL_DIMS["C"], fh, fw)
+    net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), backbone=bb, name="az_small")
+    dnet = HipDetNet(synth.make_det_head(seed=99, **synth.SMALL_DET_DIMS), net)
+    return g, net, dnet, _stub_imdb(synth, g, bb), harness_cfg
+
+
+def test_test_proposals_matches_the_reference_run(rig, mods):
+    """proposals.pkl: same dict layout, path rule, printed lines and (within the fp32 head tolerance) boxes
+    as the reference's test_proposals; and equal, bit for bit, to per-image im_propose."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    g, net, dnet, imdb, C = rig
+    from detect import test as T
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        prop_file = T.test_proposals({"full": net, "fc": net}, imdb)
+    assert os.path.relpath(prop_file, C.cfg.ROOT_DIR) == str(g["prop_relpath"]).replace("/harness/", "/harness_test/")
+    assert scrub(buf.getvalue()) == str(g["prop_stdout"])          # per-image line, depth/eval counts, summary
+    with open(prop_file, "rb") as f:
+        prop = pickle.load(f)
+    assert sorted(prop.keys()) == sorted(str(k) for k in g["prop_keys"]) == ["boxes", "recall", "time"]
+    assert isinstance(prop["time"], float) and prop["time"] > 0 and prop["recall"] == int(g["prop_recall"]) == 0
+    assert isinstance(prop["boxes"], list) and len(prop["boxes"]) == int(g["n_img"])
+    for i, b in enumerate(prop["boxes"]):
+        ref = g["prop_boxes%d" % i]
+        assert b.dtype == np.float64 and b.shape == ref.shape == (100, 4)
+        # the reference's head ran on the CPU: same proposals within 1e-4-driven tolerances, except where
+        # two candidates' scores tie within the tolerance at the cut
+        hit = [np.abs(b - r).max(axis=1).min() <= 1e-3 for r in ref]
+        assert np.mean(hit) >= 0.97, (i, np.mean(hit))
+        with redirect_stdout(io.StringIO()):
+            again = T.im_propose(net, imdb.image_at(i))
+        assert np.array_equal(again, b)
+
+
+def test_test_net_shared_matches_the_reference_run(rig, mods):
+    """detections.pkl / evaluate_detections input of test_net_shared (BASELINE config 3)."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    g, net, dnet, imdb, C = rig
+    from detect import test as T
+    n = int(g["n_img"])
+    # per-image results of the path itself, recorded while the harness runs
+    rec = []
+    inner = T.im_detect_shared
+
+    def recording(a, f, im, k):
+        s, b = inner(a, f, im, k)
+        rec.append((s.copy(), b.copy()))
+        return s, b
+    T.im_detect_shared = recording
+    try:
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            nms_dets = T.test_net_shared({"full": net, "fc": net}, {"fc": dnet}, imdb)
+    finally:
+        T.im_detect_shared = inner
+    assert scrub(buf.getvalue()) == str(g["det_stdout"])
+    det_file = os.path.join(C.get_output_dir(imdb, net), "detections.pkl")
+    assert os.path.relpath(det_file, C.cfg.ROOT_DIR) == str(g["det_relpath"]).replace("/harness/", "/harness_test/")
+    assert imdb.eval_dir == os.path.dirname(det_file) and imdb.nms_dets is nms_dets
+    with open(det_file, "rb") as f:
+        all_boxes = pickle.load(f)
+    assert len(all_boxes) == 21 and len(all_boxes[0]) == n and len(rec) == n
+    # (1) the path's per-image outputs vs the reference run's (CPU heads): 1e-4
+    for i in range(n):
+        s, b = rec[i]
+        assert s.dtype == np.float64 and s.shape == g["det_scores%d" % i].shape
+        assert np.abs(s - g["det_scores%d" % i]).max() <= 1e-4
+        # boxes: rows are ordered by proposal rank, which may swap where proposal scores tie within tolerance
+        close = np.abs(b - g["det_boxes%d" % i]).max(axis=1) <= 2e-2
+        assert close.mean() >= 0.95
+    # (2) the harness bookkeeping == the oracle's restatement (pinned to the reference by the golden) applied
+    #     to those per-image outputs: bit-exact lists, thresholds, NMS keep sets
+    want, thresh = orc.net_shared_select(rec, 21)
+    want_nms = orc.apply_nms(want, C.cfg.TEST.NMS)
+    for j in range(1, 21):
+        for i in range(n):
+            assert all_boxes[j][i].dtype == np.float32 and np.array_equal(all_boxes[j][i], want[j][i])
+            a, w = nms_dets[j][i], want_nms[j][i]
+            assert (isinstance(a, list) and isinstance(w, list) and a == w == []) or np.array_equal(a, w)
+            # and the same detections as the reference run, up to the head tolerance
+            ref = g["det_all_%d_%d" % (j, i)]
+            assert abs(all_boxes[j][i].shape[0] - ref.shape[0]) <= 3
+
+
+def _run_tool(args, timeout=900):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([TOOLS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    return subprocess.run([sys.executable, os.path.join(TOOLS, args[0])] + args[1:], env=env, cwd=REPO,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+
+
+def test_prop_az_cli_fresh_process(mods):
+    """tools/prop_az.py as a fresh process (reference flags: tools/prop_az.py:30-54): full-size synthetic net,
+    4 synthetic 600x1000 images, --tz; proposals.pkl layout / path; the same boxes as in-process im_propose."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    from detect import config as C
+    exp = "cli_test_%d" % os.getpid()
+    out_root = os.path.join(C.cfg.ROOT_DIR, "output", exp)
+    try:
+        r = _run_tool(["prop_az.py", "--gpu", "0", "--net", "synthetic", "--imdb", "synthetic_600x1000_4",
+                       "--tz", "0.0", "--exp", exp, "--def", "ignored.prototxt", "--def_fc", "ignored_fc.prototxt"])
+        assert r.returncode == 0, r.stdout[-3000:]
+        out = r.stdout
+        assert "Called with args:" in out and "Using config:" in out
+        assert out.count("300 proposals, evaluate 739 regions, reaches depth 5.") == 4
+        for i in range(1, 5):
+            assert re.search(r"im_prop: %d/4 \d+\.\d{3}s" % i, out)
+        assert "The recall is 0.000" in out and "The average proposal generation time is" in out
+        pf = os.path.join(out_root, "synthetic_600x1000_4", "vgg16_az_net_synthetic_1234", "proposals.pkl")
+        assert os.path.exists(pf), out[-2000:]
+        with open(pf, "rb") as f:
+            prop = pickle.load(f)
+        assert sorted(prop.keys()) == ["boxes", "recall", "time"] and prop["recall"] == 0
+        assert isinstance(prop["time"], float) and len(prop["boxes"]) == 4
+        for b in prop["boxes"]:
+            assert b.dtype == np.float64 and b.shape == (300, 4)
+            assert b[:, 0].min() >= 0 and b[:, 2].max() <= 999 and b[:, 3].max() <= 599
+        # the same net built in this process gives the same proposals (MIOpen may pick another conv algorithm
+        # in another process, which moves conv5_3 by ulps: compare as sets with a pixel tolerance)
+        sys.path.insert(0, TOOLS)
+        import prop_az
+        from detect import test as T
+        old_tz = C.cfg.SEAR.get("Tz", 0.0)
+        C.cfg_set_mode("Test", 0.0)
+        net = prop_az.load_net("synthetic", 0)
+        from datasets.factory import get_imdb
+        imdb = get_imdb("synthetic_600x1000_4")
+        for i in (0, 3):
+            with redirect_stdout(io.StringIO()):
+                Y = T.im_propose(net, imdb.image_at(i))
+            hit = [np.abs(Y - r).max(axis=1).min() <= 5e-2 for r in prop["boxes"][i]]
+            assert np.mean(hit) >= 0.95, (i, np.mean(hit))
+        C.cfg_set_mode("Test", old_tz)
+        # neither --tz nor --thresh: a usable message, not a TypeError
+        r2 = _run_tool(["prop_az.py", "--net", "synthetic", "--imdb", "synthetic_600x1000_1"], timeout=120)
+        assert r2.returncode == 2 and "--thresh / --tz is required" in r2.stdout
+    finally:
+        shutil.rmtree(out_root, ignore_errors=True)
+
+
+# ---------------------------------------------------------------- .caffemodel row (f2)
+def test_caffemodel_files_load_into_the_gpu_head(mods, tmp_path):
+    """V1- and V2-format .caffemodel files (written with tests/test_caffemodel.py's protobuf encoder) read by
+    aznet_hip.caffemodel, loaded through tools/prop_az.py:load_net, give the same head outputs -- bit for
+    bit -- as the head loaded from memory; the conv layers land in the torch backbone unchanged."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    import test_caffemodel as tc
+    sys.path.insert(0, TOOLS)
+    import prop_az
+    head = synth.make_head(seed=5, **synth.SMALL_DIMS)
+    rng = np.random.RandomState(3)
+    from aznet_hip.backbone import VGG16_CONV
+    conv, cin = {}, 3
+    for item in VGG16_CONV:
+        if item == "P":
+            continue
+        name, cout = item
+        cout = max(4, cout // 32)
+        conv[name] = ((rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32),
+                      (0.01 * rng.standard_normal(cout)).astype(np.float32))
+        cin = cout
+    assert cin == synth.SMALL_DIMS["C"]
+    fmap = synth.make_feature_map(9, synth.SMALL_DIMS["C"], 38, 63)
+    rois = np.array([[0, 0, 0, 999, 599], [0, 100, 50, 400, 300], [0, 8, 8, 8, 8], [0, 500, 300, 990, 590]], np.float32)
+    ref_net = HipAZNet(head, name="mem")
+    ref_net.set_conv(fmap)
+    want = ref_net.ctx.head_forward(rois)
+    blob = np.random.RandomState(1).standard_normal((1, 3, 64, 96)).astype(np.float32)
+    for fmt in ("v1", "v2"):
+        path = str(tmp_path / ("az_%s.caffemodel" % fmt))
+        tc.write_az_caffemodel(path, head, conv, fmt)
+        net = prop_az.load_net(path, 0)
+        assert net.name == "az_%s" % fmt
+        net.set_conv(fmap)
+        got = net.ctx.head_forward(rois)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        # backbone weights arrived in Caffe layout [out, in, 3, 3] and are used as such
+        for layer in net.backbone.layers:
+            if layer is not None:
+                assert np.array_equal(layer[1].cpu().numpy(), conv[layer[0]][0])
+                assert np.array_equal(layer[2].cpu().numpy(), conv[layer[0]][1])
+        from aznet_hip.backbone import VGG16Conv5
+        mem = VGG16Conv5(device="cuda:0", weights=conv, width_div=32)
+        assert torch.equal(net.backbone(blob), mem(blob))
+
+
+# ---------------------------------------------------------------- backbone plumbing (g1)
+def test_vgg16_conv5_plumbing(mods):
+    """VGG16Conv5 (models/Pascal/VGG16/az-net/test.prototxt:16-384): 600x1000 -> [1,512,38,63] (four ceil-mode
+    2x2/2 pools, no pool5), Caffe-layout weights used as given, and the GPU forward equals a CPU torch forward
+    of the same stack within 1e-3."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    import torch.nn.functional as F
+    from aznet_hip.backbone import VGG16Conv5, VGG16_CONV
+    bb = VGG16Conv5(device="cuda:0", seed=11)
+    names = [l[0] for l in bb.layers if l is not None]
+    assert names == [x[0] for x in VGG16_CONV if x != "P"] and len(names) == 13 and bb.layers.count(None) == 4
+    assert bb.layers[-1][0] == "conv5_3" and bb.out_channels == 512
+    x = torch.from_numpy(np.random.RandomState(0).uniform(-120, 130, (1, 3, 600, 1000)).astype(np.float32))
+    y = bb(x)
+    assert tuple(y.shape) == (1, 512, 38, 63) and y.is_contiguous() and y.dtype == torch.float32
+    assert (synth.conv_out_size(600), synth.conv_out_size(1000)) == (38, 63)
+    assert tuple(bb(torch.zeros(1, 3, 375, 500)).shape) == (1, 512, 24, 32)       # odd sizes: ceil mode
+    # CPU reference of the same graph
+    h = x
+    with torch.no_grad():
+        for layer in bb.layers:
+            if layer is None:
+                h = F.max_pool2d(h, 2, 2, ceil_mode=True)
+            else:
+                h = F.relu(F.conv2d(h, layer[1].cpu(), layer[2].cpu(), padding=1))
+    ref = h
+    err = (y.cpu() - ref).abs().max().item()
+    assert err <= 1e-3 * max(1.0, ref.abs().max().item()), err
+    # weights round-trip: a dict of Caffe-layout arrays is what the next instance uses
+    w = {l[0]: (l[1].cpu().numpy(), l[2].cpu().numpy()) for l in bb.layers if l is not None}
+    bb2 = VGG16Conv5(device="cuda:0", weights=w)
+    assert torch.equal(bb2(x), y)
+    # and the map feeds the search: set_conv borrows the tensor (after synchronising torch's stream)
+    net = HipAZNet(synth.make_head(seed=1, **synth.SMALL_DIMS), backbone=VGG16Conv5(device="cuda:0", seed=2, width_div=32),
+                   name="plumb")
+    conv = net.compute_conv(x)
+    assert tuple(conv.shape) == (1, 16, 38, 63)
+    Y = net.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0))
+    net2 = HipAZNet(synth.make_head(seed=1, **synth.SMALL_DIMS), name="plumb2")
+    net2.set_conv(conv.cpu().numpy())
+    assert np.array_equal(Y, net2.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0)))

@@ -207,3 +207,25 @@ def test_image_blob_restatement_properties():
             continue        # torch derives its step from the size ratio, cv2 from fx/fy
         ref = F.interpolate(torch.from_numpy(b1), size=(oh, ow), mode="bilinear", align_corners=False).numpy()
         assert np.abs(orc.image_blob(im, means, scale) - ref).max() < 1e-3
+
+
+# ---- harness row (a15 / 8f row 1): goldens from oracle/gen_golden_harness.py -------------------------
+def test_net_shared_bookkeeping_and_apply_nms_golden():
+    """oracle.net_shared_select / apply_nms == what the reference's test_net_shared (lib/detect/test.py:
+    670-778) pickled into detections.pkl and handed to imdb.evaluate_detections, given the per-image
+    (scores, boxes) its own im_detect_shared returned."""
+    g = load("g13_harness.npz")
+    n = int(g["n_img"])
+    per = [(g["det_scores%d" % i], g["det_boxes%d" % i]) for i in range(n)]
+    all_boxes, thresh = orc.net_shared_select(per, 21)
+    nmsd = orc.apply_nms(all_boxes, 0.5)
+    assert np.isfinite(thresh[1:]).all()                  # the adaptive thresholds engaged (max_per_set = 80)
+    for j in range(1, 21):
+        for i in range(n):
+            assert all_boxes[j][i].dtype == np.float32
+            assert np.array_equal(all_boxes[j][i], g["det_all_%d_%d" % (j, i)])
+            got = np.zeros((0, 5), np.float32) if isinstance(nmsd[j][i], list) else nmsd[j][i]
+            assert np.array_equal(got, g["det_nms_%d_%d" % (j, i)])
+    assert sorted(str(k) for k in g["prop_keys"]) == ["boxes", "recall", "time"] and int(g["prop_recall"]) == 0
+    assert str(g["prop_relpath"]) == "output/harness/stub_2img/az_small/proposals.pkl"
+    assert str(g["det_relpath"]) == "output/harness/stub_2img/az_small/detections.pkl"
