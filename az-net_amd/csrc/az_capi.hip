@@ -780,7 +780,6 @@ static int sift_common(az_ctx *c, int C, double min_side, double *out, int cap, 
 {
     hipStream_t s = c->stream;
     int *Nptr = &c->cnt->scratch[0], *Pn = &c->cnt->scratch[1], *err = &c->cnt->scratch[2];
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     int rc = set_count(c, Nptr, C);
     if (rc) return rc;
@@ -815,7 +814,6 @@ int az_divide_region(az_ctx *c, const double *regions, int P, double min_side, d
     if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_divide_region: too many regions");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->Z, regions, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->PZ[0], P)) != AZ_OK) return rc;
@@ -842,7 +840,6 @@ int az_roi_dedup(az_ctx *c, const double *boxes, int P, double scale, double ded
     if (P > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_roi_dedup: too many regions");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (P) HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
@@ -863,7 +860,6 @@ static int stage_rois(az_ctx *c, const float *rois, int R)
     if (R < 0 || (R && !rois)) return fail(c, AZ_ERR_INVALID, "bad rois");
     if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "too many rois");
     HIPCHK(c, hipSetDevice(c->device));
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), c->stream));
     if (R) HIPCHK(c, hipMemcpyAsync(c->urois, rois, (size_t)R * 5 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->ubox, 0, (size_t)(R > 0 ? R : 1) * 4 * sizeof(double), c->stream));
@@ -908,9 +904,9 @@ int az_decode_filter(az_ctx *c, const double *anchors, const float *deltas, cons
     if (rc) return rc;
     if (R < 0 || (R && (!anchors || !deltas || !scores)) || !n_out) return fail(c, AZ_ERR_INVALID, "az_decode_filter: bad arguments");
     if (R > c->maxR) return fail(c, AZ_ERR_CAPACITY, "az_decode_filter: too many regions");
+    c->cand_n = -1;                              // Yall / Sall are reused below
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     // stage: anchors -> ubox, deltas -> delta_u, scores -> Sout (scratch); inv = identity
     std::vector<int> ident(R);
@@ -942,9 +938,9 @@ int az_topk(az_ctx *c, const float *scores, int n, int k, int32_t *idx_out, int 
     if (rc) return rc;
     if (n < 0 || (n && !scores) || k <= 0 || !idx_out || !n_out) return fail(c, AZ_ERR_INVALID, "az_topk: bad arguments");
     if (n > c->maxCand || k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_topk: n or k too large");
+    c->cand_n = -1;                              // Sall is reused below
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     if (n) HIPCHK(c, hipMemcpyAsync(c->Sall, scores, (size_t)n * 4, hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->scratch[0], n)) != AZ_OK) return rc;
@@ -1102,7 +1098,6 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (!(c->profiling & 4)) clear_events(c);
-    c->cand_n = -1;
     HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
     HIPCHK(c, hipMemcpyAsync(c->B[0], boxes, (size_t)P * 4 * sizeof(double), hipMemcpyHostToDevice, s));
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;

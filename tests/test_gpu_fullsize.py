@@ -146,6 +146,7 @@ def test_reference_traces_through_az_propose(small, mods, tag):
     net.set_conv(fmap)
     Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, batch_size=batch), want_scores=True,
                            want_stats=True)
+    Yall, Sall = net.ctx.last_candidates()          # (before the unit calls below reuse the buffers)
     # the oracle loop replaying the reference's recorded head outputs reproduces the reference's Y
     # (tests/test_oracle_golden.py); its trace gives the per-level structure of the reference run
     Yrep, tr = orc.im_propose(replay_nets(g), (H, W), scale, orc.OracleCfg(Tz=Tz, BATCH_SIZE=batch),
@@ -168,7 +169,6 @@ def test_reference_traces_through_az_propose(small, mods, tag):
         assert got.dtype == np.float32 and np.array_equal(got, ref)
     assert ci == ncalls
     # candidates and final proposals vs the reference's run (its head ran on the CPU: 1e-4)
-    Yall, Sall = net.ctx.last_candidates()
     assert Yall.shape == tr["Y_all"].shape
     assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
     np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=1e-3)
@@ -219,14 +219,17 @@ def test_no_dedup_when_dedup_boxes_is_zero(small, mods, H, W, batch):
     assert net.ctx.last_candidates()[0].shape[0] > 0
 
 
-def test_last_candidates_is_invalidated_by_unit_calls(small, mods):
+def test_last_candidates_survives_counter_reuse_but_not_buffer_reuse(small, mods):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
     net.set_conv(synth.make_feature_map(7, synth.SMALL_DIMS["C"], 38, 63))
     net.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0))
     a = net.ctx.last_candidates()
     assert a[0].shape[0] > 300
-    net.ctx.divide_region(np.array([[0, 0, 999.0, 599.0]]), 10.0)        # reuses the counters
+    net.ctx.divide_region(np.array([[0, 0, 999.0, 599.0]]), 10.0)        # reuses the counters, not the candidates
+    b = net.ctx.last_candidates()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    net.ctx.topk(np.arange(10, dtype=np.float32), 3)                     # overwrites the candidate scores
     with pytest.raises(ffi.AzError):
         net.ctx.last_candidates()
 

@@ -156,3 +156,23 @@ def test_evaluate_recall_host_math():
     ar, gt_overlaps, recalls, thresholds = db.evaluate_recall([g["cand%d" % i] for i in range(n)], ctx=FakeCtx())
     assert ar == float(g["ar"]) and np.array_equal(gt_overlaps, g["gt_overlaps"])
     assert np.array_equal(recalls, g["recalls"]) and np.array_equal(thresholds, g["thresholds"])
+
+
+def test_bench_self_launch_relays_rank_failures():
+    """`python bench.py --gpus 2` must start its own ranks (torch.distributed.run on 127.0.0.1) without touching
+    the GPU in the parent, and exit non-zero when a rank fails.  On this CPU-only box every rank fails at
+    device selection, which is exactly the case to relay: no JSON line, non-zero exit code."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-e2e"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+    else:
+        assert r.returncode != 0
+        assert '"metric"' not in r.stdout
+        assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr or "Error" in r.stderr
