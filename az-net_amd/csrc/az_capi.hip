@@ -45,7 +45,7 @@ struct az_ctx {
     float *rois = nullptr, *urois = nullptr;
     long long *key = nullptr, *ckey = nullptr;
     int *grp = nullptr, *index = nullptr, *inv = nullptr, *choff = nullptr, *bc_c = nullptr, *bc_z = nullptr;
-    unsigned char *first = nullptr, *cflag = nullptr, *zflag = nullptr;
+    unsigned char *first = nullptr, *cflag = nullptr, *zflag = nullptr, *keep_u = nullptr;
     double *ubox = nullptr, *pred_u = nullptr, *Yall = nullptr, *Z = nullptr, *child = nullptr, *Yout = nullptr;
     float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr;
     float *zoom_u = nullptr, *score_u = nullptr, *delta_u = nullptr, *Sall = nullptr, *Sout = nullptr;
@@ -84,7 +84,9 @@ struct az_ctx {
     int h_cap = 0;
     // last launch
     az_params last{};
-    int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels overflowed
+    int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels 1-3 overflowed
+    int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which a later level outgrew the fused level kernel
+    int level_fused_env = -1;           // AZ_LEVEL_FUSED=0: keep levels >= 4 as separate launches (measurements)
     std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_nlev = 0;
@@ -165,7 +167,7 @@ int ensure_geom(az_ctx *c)
     A(B[0], R * 4); A(B[1], R * 4); A(rois, R * 5); A(urois, R * 5); A(key, R); A(ckey, CH);
     A(grp, R); A(index, R); A(inv, R); A(choff, R); A(bc_c, (R * AZ_NSUB + 255) / 256 + 1);
     A(bc_z, (R * AZ_NSUB + 255) / 256 + 1);
-    A(first, CH > R ? CH : R); A(cflag, R * AZ_NSUB); A(zflag, R);
+    A(first, CH > R ? CH : R); A(cflag, R * AZ_NSUB); A(zflag, R); A(keep_u, R * AZ_NSUB);
     A(ubox, R * 4); A(pred_u, R * AZ_NSUB * 4); A(Yall, CAND * 4); A(Z, R * 4); A(child, CH * 4);
     A(Yout, CAND * 4); A(Sout, CAND); A(sel_idx, CAND); A(rank_part, (size_t)azk_topk_scratch_ints((int)CAND));
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
@@ -235,7 +237,7 @@ int set_count(az_ctx *c, int *dptr, int v)
 // One forward of the head on the `U` rois in ctx->urois (anchors in ctx->ubox); scores and
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
-                 float *delta)
+                 float *delta, double min_side = 0.0, bool keep_flags = false)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
@@ -253,7 +255,7 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
       azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom,
-               score, delta, c->pred_u); }
+               score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -499,6 +501,12 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
     // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
     const bool fused = n_spec && !(p->reserved & 2) && !(p->im_h == c->nofuse_h && p->im_w == c->nofuse_w);
+    // Levels after the speculative ones: one single-workgroup kernel per level (az_level.hip) instead of ten
+    // launches, the final selection folded into the last one (params.reserved bit 4 / AZ_LEVEL_FUSED=0 keep
+    // the multi-launch form; same bits).  Needs one dedup chunk per level (cfg.SEAR.BATCH_SIZE >= regions).
+    if (c->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); c->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
+    const bool fused_lv = fused && nlev > n_spec && !(p->reserved & 16) && c->level_fused_env &&
+                          !(p->im_h == c->nofuse_lv_h && p->im_w == c->nofuse_lv_w);
     if (!fused) azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
     if (fused) {
         Timed t(c, "spec_prepass", -1);
@@ -530,13 +538,32 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
         a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
         a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
+        a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0;
         azk_spec_levels(s, a);
     }
     for (int l = fused ? n_spec : 0; l < nlev; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
-        { Timed t(c, "rois_dedup", l);
+        const bool lv_here = fused_lv && l + 1 < nlev;           // (the last level's copy + top-k stay chip-wide)
+        if (lv_here) {
+            // this level's rois were projected and deduplicated by the previous geometry kernel
+            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true);
+            Timed t(c, "level_geom", l);
+            AzLevelArgs a;
+            a.cnt = c->cnt; a.level = l; a.nlev = nlev;
+            a.B = c->B[cur]; a.Bnext = c->B[cur ^ 1];
+            a.pred_u = c->pred_u; a.score_u = c->score_u; a.zoom_u = c->zoom_u; a.keep_u = c->keep_u; a.Uptr = Uptr;
+            a.urois = c->urois; a.index = c->index; a.inv = c->inv; a.ubox = c->ubox;
+            a.Yall = c->Yall; a.Sall = c->Sall;
+            a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
+            a.batch = p->batch_size; a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
+            a.force_root = 1;
+            azk_level_geom(s, a);
+            continue;
+        }
+        if (!fused_lv) {          // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
+          Timed t(c, "rois_dedup", l);
           azk_rois_dedup(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
                          c->grp, c->first, c->index, c->inv, c->urois, c->ubox, Uptr); }
         if (l < n_spec) {
@@ -567,7 +594,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                                 c->srcB[cur ^ 1]); }
         }
     }
-    { Timed t(c, "select", nlev);
+    {
+      Timed t(c, "select", nlev);
       if (p->fixed_num)
           azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
                         c->Sall, (double *)((unsigned char *)c->cnt + RES_HDR),
@@ -626,6 +654,8 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->d, sizeof(c->d));
         key.append((const char *)&c->nofuse_h, sizeof(int));
         key.append((const char *)&c->nofuse_w, sizeof(int));
+        key.append((const char *)&c->nofuse_lv_h, sizeof(int));
+        key.append((const char *)&c->nofuse_lv_w, sizeof(int));
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             // (the first search of a shape also runs once un-captured: one-time attribute calls happen there)
@@ -701,10 +731,13 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
     }
     if ((h.err & 8) && !(c->last.reserved & 2)) {
         // a fused level outgrew its LDS tables: rerun with the multi-launch kernels and remember
-        // the image shape so that later calls skip the fused attempt
-        c->nofuse_h = c->last.im_h; c->nofuse_w = c->last.im_w;
+        // the image shape so that later calls skip the fused attempt -- first only for the levels after the
+        // speculative ones (az_level.hip), then, if levels 1-3 themselves overflow, for everything
+        const bool lv_was_on = !(c->last.reserved & 16) && c->level_fused_env != 0 &&
+                               !(c->last.im_h == c->nofuse_lv_h && c->last.im_w == c->nofuse_lv_w);
         az_params p2 = c->last;
-        p2.reserved |= 2;
+        if (lv_was_on) { c->nofuse_lv_h = c->last.im_h; c->nofuse_lv_w = c->last.im_w; p2.reserved |= 16; }
+        else { c->nofuse_h = c->last.im_h; c->nofuse_w = c->last.im_w; p2.reserved |= 2; }
         void *sd = c->stage_dst;
         const size_t sc = c->stage_cap;
         int rc2 = az_propose_launch(c, &p2);

@@ -61,6 +61,15 @@ static __device__ __forceinline__ void az_decode_box(const double *anchor, const
 }
 
 
+// Candidate filter of _unwrap_adj_pred (lib/detect/test.py:181-185).
+static __device__ __forceinline__ bool cand_keep(const double *bx, double min_side)
+{
+    const double h = bx[3] - bx[1] + 1;
+    const double w = bx[2] - bx[0] + 1;
+    const double side = (h < w) ? h : w;          // np.minimum(heights, widths)
+    return side >= min_side;
+}
+
 // ---- launchers (az_geom.hip) -----------------------------------------------------------
 void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w);
 void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
@@ -100,6 +109,8 @@ struct AzFusedArgs {
     double *B[2];
     int *srcB[2];
     int *index, *inv, *zr, *choff, *csrc;
+    float *rois, *urois;          // (next_dedup) roi projection + dedup of the first level after the fused ones
+    int next_dedup;
     const int *choff_all;
     double *ubox, *pred_u, *Yall, *Z, *child;
     float *zoom_u, *score_u, *delta_u, *Sall;
@@ -113,6 +124,26 @@ struct AzFusedArgs {
 void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
                       float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w);
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
+
+// ---- launcher (az_level.hip): one level's geometry (and the final selection) in one workgroup ------
+struct AzLevelArgs {
+    AzCounts *cnt;
+    int level, nlev;
+    const double *B;               // regions of this level
+    double *Bnext;                 // regions of the next level
+    const double *pred_u;          // head outputs of this level's unique rois
+    const float *score_u, *zoom_u;
+    float *urois;                  // next level: unique rois
+    int *index, *inv;              // this level's inv_index on entry; the next level's index / inv_index on exit
+    const unsigned char *keep_u;   // MIN_SIDE filter of this level's decoded boxes (tail kernel)
+    const int *Uptr;               // unique rois of this level
+    double *ubox;                  // next level: anchor boxes of the unique rois
+    double *Yall; float *Sall;     // candidates of the whole search
+    double scale, Tz, min_side;
+    float dedup;
+    int batch, capR, capCh, capCand, force_root;
+};
+void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
 
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 // feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
@@ -144,9 +175,10 @@ void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const in
 // (vector-ALU products, see az_head.hip).  WtT is the stacked weight block k-major, zero-padded:
 // [azk_tail_weight_rows(n71+n72)][64].
 #define AZK_TAIL_SPLIT 8      /* k-chunks of the Fast R-CNN head's cls_score|bbox_pred GEMM */
+// keep_u (may be NULL): per decoded box, the MIN_SIDE filter of _unwrap_adj_pred (test.py:181-185)
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
-              float *score_u, float *delta_u, double *pred_u);
+              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u = nullptr, double min_side = 0.0);
 size_t azk_tail_lds_bytes(int n7);
 size_t azk_tail_weight_rows(int n7);
 int azk_fc_split(int K);

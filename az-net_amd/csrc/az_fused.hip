@@ -159,6 +159,9 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     __shared__ int sslot[FL_C];
     __shared__ int sczi[FL_C];
     __shared__ int sidx[FL_R], szr[FL_R], schoff[FL_R];
+    __shared__ unsigned long long ssort[2 * FL_R];
+    __shared__ unsigned sbins[SORT_NB + 1];
+    __shared__ unsigned smm[2];
     __shared__ int wsum[17];
     const int tid = threadIdx.x;
     AzCounts *cnt = a.cnt;
@@ -314,6 +317,14 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     const int nxt = a.n_fused & 1;
     for (int i = tid; i < P * 4; i += NTL) a.B[nxt][i] = sB[nxt][i];
     if (tid == 0) cnt->P[a.n_fused] = P;
+    if (a.next_dedup && a.n_fused < a.nlev) {
+        // the next level runs on the fused level kernel (az_level.hip), which expects its rois deduplicated
+        if (P > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
+        __syncthreads();
+        const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, a.rois,
+                                       a.index, a.inv, a.urois, a.ubox);
+        if (tid == 0) cnt->U[a.n_fused] = U;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

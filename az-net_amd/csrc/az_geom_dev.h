@@ -98,11 +98,128 @@ static __device__ __forceinline__ long long div_child(const double *r, const Div
     return h;
 }
 
-// Candidate filter of _unwrap_adj_pred (lib/detect/test.py:181-185).
-static __device__ __forceinline__ bool cand_keep(const double *bx, double min_side)
+
+// ----------------------------------------------------------------------------------------
+// Single-workgroup building blocks of the fused level kernels (az_fused.hip, az_level.hip).
+
+// Sort (ascending) of N DISTINCT 64-bit words in LDS by the whole workgroup, as a bucket sort: the words'
+// high parts (w >> S, which must fit 32 bits) are mapped linearly from [min, max] onto SORT_NB buckets
+// (monotone, so bucket order is sort order), a histogram + scan gives every bucket its segment, and inside a
+// segment -- a handful of words for the region hashes and scores of this path -- a word's place is the number
+// of smaller words.  Seven barriers and no dependent compare-exchange chain (a bitonic network of 1024 words
+// took 9 us on one CU, this takes ~2); correct for any input, O(N^2 / threads) only if all words share a
+// bucket.  `tmp`: N words, `bins`: SORT_NB + 1 counters, `mm`: 2 words of LDS.
+constexpr int SORT_NB = 4096;
+
+static __device__ void block_bucket_sort(unsigned long long *w, int N, unsigned long long *tmp, unsigned *bins,
+                                         int S, int *wsum, unsigned *mm)
 {
-    const double h = bx[3] - bx[1] + 1;
-    const double w = bx[2] - bx[0] + 1;
-    const double side = (h < w) ? h : w;          // np.minimum(heights, widths)
-    return side >= min_side;
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
+    __syncthreads();
+    if (tid == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
+    for (int b = tid; b <= SORT_NB; b += nt) bins[b] = 0u;
+    __syncthreads();
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = tid; i < N; i += nt) {
+        const unsigned h = (unsigned)(w[i] >> S);
+        lo = h < lo ? h : lo;
+        hi = h > hi ? h : hi;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & 63) == 0 && N > 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+    __syncthreads();
+    const unsigned base_h = mm[0];
+    const unsigned long long range = (unsigned long long)(mm[1] - mm[0]) + 1ull;
+    auto bucket = [&](unsigned long long x) {
+        return (int)(((unsigned long long)((unsigned)(x >> S) - base_h) * (unsigned long long)SORT_NB) / range);
+    };
+    for (int i = tid; i < N; i += nt) atomicAdd(&bins[bucket(w[i])], 1u);
+    __syncthreads();
+    {   // exclusive scan of the bucket counts, in place
+        const int per = (SORT_NB + nt - 1) / nt;
+        const int b0 = tid * per, b1 = min(SORT_NB, b0 + per);
+        int sum = 0;
+        for (int b = b0; b < b1; ++b) sum += (int)bins[b];
+        int tot;
+        int run = block_excl_scan(sum, &tot, wsum);
+        for (int b = b0; b < b1; ++b) { const int c = (int)bins[b]; bins[b] = (unsigned)run; run += c; }
+    }
+    __syncthreads();
+    // scatter into the bucket segments (arrival order inside a segment); bins[b] ends up as the END of segment b
+    for (int i = tid; i < N; i += nt) {
+        const unsigned long long x = w[i];
+        tmp[atomicAdd(&bins[bucket(x)], 1u)] = x;
+    }
+    __syncthreads();
+    for (int p = tid; p < N; p += nt) {
+        const unsigned long long x = tmp[p];
+        const int b = bucket(x);
+        const int s0 = b ? (int)bins[b - 1] : 0, s1 = (int)bins[b];
+        int r = 0;
+        for (int q = s0; q < s1; ++q) r += tmp[q] < x;
+        w[s0 + r] = x;
+    }
+    __syncthreads();
+}
+
+static __device__ __forceinline__ int next_pow2(int v)
+{
+    int n = 2;
+    while (n < v) n <<= 1;
+    return n;
+}
+
+// Roi projection + feature-space dedup of the Pn regions `Bn` (LDS or global; lib/detect/test.py:61-97,
+// 210-218) by one workgroup: rois [Pn,5] (written only if `rois` is not NULL), and np.unique(hashes, return_index, return_inverse) as a sort of
+// (key << 14 | position): run heads in ascending key order are the unique rois, the head of a run is its first
+// occurrence.  Writes index / inv / the unique rois and their anchor boxes, returns U.  The caller guarantees
+// Pn <= 16384 and Pn <= batch (one dedup chunk: keys < 1000^5 < 2^50); `ssort` / `stmp` hold Pn words each.
+static __device__ int roi_dedup_sorted(const double *Bn, int Pn, double scale, float dedup, unsigned long long *ssort,
+                                       unsigned long long *stmp, unsigned *bins, unsigned *mm, int *wsum, float *rois,
+                                       int *index, int *inv, float *urois, double *ubox)
+{
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
+    for (int r = tid; r < Pn; r += nt) {
+        float roi5[5];
+        const long long key = roi_and_key(Bn + 4 * r, scale, dedup, roi5, r);
+        if (rois) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rois[5 * (size_t)r + q] = roi5[q];
+        }
+        ssort[r] = ((unsigned long long)key << 14) | (unsigned)r;
+    }
+    block_bucket_sort(ssort, Pn, stmp, bins, 34, wsum, mm);            // high part = key >> 20
+    int U = 0;
+    for (int base = 0; base < Pn; base += nt) {
+        const int i = base + tid;
+        int head = 0;
+        unsigned long long w = 0;
+        if (i < Pn) {
+            w = ssort[i];
+            head = (i == 0) || ((ssort[i - 1] >> 14) != (w >> 14));
+        }
+        int tot;
+        const int ex = block_excl_scan(head, &tot, wsum);
+        if (i < Pn) {
+            const int slot = U + ex + head - 1;            // run number of position i
+            const int r = (int)(w & 0x3FFFu);
+            inv[r] = slot;
+            if (head) {
+                index[slot] = r;
+                float roi5[5];
+                roi_and_key(Bn + 4 * r, scale, dedup, roi5, r);          // (recomputed: cheaper than a memory round trip)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) urois[5 * (size_t)slot + q] = roi5[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ubox[4 * (size_t)slot + q] = Bn[4 * r + q];
+            }
+        }
+        U += tot;
+    }
+    return U;
 }

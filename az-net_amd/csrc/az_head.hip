@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(TAIL_WAVES * 64)
 k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float *__restrict__ b7, int n7, int kq,
              const float *__restrict__ WtT, const float *__restrict__ bt, const double *__restrict__ ubox,
              const int *Uptr, int im_h, int im_w, double eps, float *zoom_u, float *score_u, float *delta_u,
-             double *pred_u)
+             double *pred_u, unsigned char *keep_u, double min_side)
 {
     extern __shared__ __attribute__((aligned(16))) float tail_lds[];
     const int KP = TAIL_WAVES * kq;
@@ -823,7 +823,9 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
                         d4[q] = o[AZ_NSUB + 4 * t + q];
                         delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
                     }
-                    az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * AZ_NSUB + t) * 4);
+                    double *pb = pred_u + ((size_t)u * AZ_NSUB + t) * 4;
+                    az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pb);
+                    if (keep_u) keep_u[(size_t)u * AZ_NSUB + t] = cand_keep(pb, min_side) ? 1 : 0;
                 } else {
                     const float e = expf(-o[NOUT - 1]);
                     zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
@@ -962,13 +964,13 @@ size_t azk_tail_weight_rows(int n7) { return (size_t)TAIL_WAVES * tail_kq(n7) + 
 
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
-              float *score_u, float *delta_u, double *pred_u)
+              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u, double min_side)
 {
     int grid = (capU + TAIL_ROWS - 1) / TAIL_ROWS;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, part7, S7,
                        (size_t)capU * n7, b7, n7, tail_kq(n7), WtT, bt, ubox, Uptr, im_h, im_w, eps, zoom_u, score_u,
-                       delta_u, pred_u);
+                       delta_u, pred_u, keep_u, min_side);
 }
 
 void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,

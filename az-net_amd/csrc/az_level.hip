@@ -1,0 +1,219 @@
+// az_level.hip -- everything between the head evaluations of two consecutive levels of the search loop, as
+// ONE single-workgroup kernel (lib/detect/test.py:373-391 with 189-257 and lib/utils/div.pyx:15-89 inlined):
+//
+//   candidates of level l   _unwrap_adj_pred: MIN_SIDE filter, ordered append to Y / aScores
+//   zoom selection          zoom[0] = 1 at level 1; indZ = where(zoom >= Tz); Z = B[indZ]
+//   divide_region(Z)        children, then _sift_dup = np.unique over the 10-px hash (first occurrence,
+//                           ascending hash order) -> B of level l+1
+//   level l+1's rois        _get_rois_blob + the feature-space dedup np.unique(return_index, return_inverse)
+//
+// The multi-launch form of the same steps (az_geom.hip: ten launches per level, each a wave per element
+// over the whole chip) stays as the path for levels that outgrow this kernel's LDS tables, for the last level
+// (whose candidate copy and top-k are data-heavy: one CU moves ~25 GB/s) and as the bit-for-bit cross-check in
+// the tests.  A level in the middle of the tree is a few hundred regions and a few KB of state: every stage
+// boundary of the multi-launch form costs a kernel boundary plus a first-touch round trip to memory another
+// XCD has just written (~4-5 us), ten times per level.  Here the level's inputs (inv_index, zoom scores, keep
+// flags) come in with ONE round trip, everything else runs out of LDS with a barrier between stages, and both
+// np.unique calls are an LDS bucket sort of (hash << bits | position) words: run heads are the unique values
+// in ascending order and, positions being the low bits, the head of a run is its first occurrence -- the same
+// integers as the O(N^2) rank kernels.  Same device helpers (az_geom_dev.h) for the f64 arithmetic, built with
+// -ffp-contract=off.
+#include "az_geom_dev.h"
+
+namespace {
+
+constexpr int NT = 1024;
+constexpr int LV_R = 1024;         // regions per level handled here
+constexpr int LV_C = 4096;         // children per level (before _sift_dup)
+
+// LDS carve-up in 8-byte words (one buffer; stages that share a region never overlap in time):
+//   [0, 4096) sort words   [4096, 6144) sczi   [6144, 7168) szr, schoff
+//   [7168, 11264) sort scratch, then the next level's regions (f64 x 4 x 1024)
+//   [11264, 11776) inv   [11776, 12288) zoom scores   [12288, 13696) keep flags   [13696, 15745) sort buckets
+constexpr int W_SORT = 0, W_SCZI = 4096, W_SZR = 6144, W_BN = 7168, W_INV = 11264, W_ZOOM = 11776, W_KEEP = 12288,
+              W_BINS = 13696;
+constexpr int LDS_WORDS = W_BINS + (SORT_NB + 2) / 2 + 1;
+
+#ifdef AZ_LEVEL_TIMING
+#define TSTAMP() do { __syncthreads(); if (tid == 0 && tsn < 32) ts[tsn++] = wall_clock64(); } while (0)
+#define TREPORT() do { if (tid == 0) { printf("level %d stamps (x10ns):", l); for (int i = 1; i < tsn; ++i) printf(" %llu", ts[i] - ts[i - 1]); printf("\n"); } } while (0)
+#else
+#define TSTAMP() do { } while (0)
+#define TREPORT() do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
+{
+#ifdef AZ_LEVEL_TIMING
+    __shared__ unsigned long long ts[32];
+    int tsn = 0;
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned long long sbuf[LDS_WORDS];
+    __shared__ int wsum[17];
+    __shared__ unsigned s_mm[2];
+    const int tid = threadIdx.x;
+    AzCounts *cnt = a.cnt;
+    const int l = a.level;
+    const int P = cnt->P[l];
+    const int U = *a.Uptr;
+    const int ybase = cnt->ytot[l];
+    if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
+    if (P > LV_R || U > LV_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    TSTAMP();
+
+    // ---- one round trip: this level's inv_index, zoom scores and keep flags -> LDS; its regions -> cache ----
+    int *sinv = reinterpret_cast<int *>(sbuf + W_INV);
+    float *szoom = reinterpret_cast<float *>(sbuf + W_ZOOM);
+    unsigned char *skeep = reinterpret_cast<unsigned char *>(sbuf + W_KEEP);
+    const double *B = a.B;
+    {
+        double warm = 0.0;
+        for (int r = tid; r < P; r += NT) { sinv[r] = a.inv[r]; warm += B[4 * (size_t)r]; }
+        for (int u = tid; u < U; u += NT) szoom[u] = a.zoom_u[u];
+        for (int i = tid; i < U * AZ_NSUB; i += NT) skeep[i] = a.keep_u[i];
+        if (warm == -1.2345e300) szoom[0] = 0.f;           // (never true; keeps the region loads alive: they warm this CU's caches)
+    }
+    __syncthreads();
+    TSTAMP();
+
+    // ---- candidates (test.py:171-187, 380-381): pred_u holds the boxes decoded against the unique roi's own
+    //      anchor and keep_u their MIN_SIDE filter (tail kernel); region r reads the row of its unique roi
+    //      inv[r].  Thread t owns the contiguous candidates [t*per, (t+1)*per): ONE block scan orders them. ----
+    int nc;
+    {
+        const int NC = P * AZ_NSUB;
+        const int per = (NC + NT - 1) / NT;                 // <= 11 (P <= LV_R)
+        const int c0 = tid * per, c1 = min(NC, c0 + per);
+        unsigned keep = 0;
+        for (int c = c0; c < c1; ++c) {
+            const int r = c / AZ_NSUB, sub = c - r * AZ_NSUB;
+            if (skeep[sinv[r] * AZ_NSUB + sub]) keep |= 1u << (c - c0);
+        }
+        int tot;
+        int dst = ybase + block_excl_scan(__popc(keep), &tot, wsum);
+        // the copy, in two batches of independent loads (the boxes of 12 candidates do not fit the registers
+        // of a 1024-thread workgroup)
+#pragma unroll
+        for (int h = 0; h < 2 && 6 * h < per; ++h) {
+            double bx[6][4];
+            float sc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int c = min(c0 + 6 * h + j, NC - 1);
+                const int r = c / AZ_NSUB, sub = c - r * AZ_NSUB;
+                const size_t src = (size_t)sinv[r] * AZ_NSUB + sub;
+                const double *pb = a.pred_u + src * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bx[j][q] = pb[q];
+                sc[j] = a.score_u[src];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (keep & (1u << (6 * h + j))) {
+                    if (dst < a.capCand) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = bx[j][q];
+                        a.Sall[dst] = sc[j];
+                    }
+                    ++dst;
+                }
+        }
+        nc = tot;
+    }
+    if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0) atomicOr(&cnt->err, 2); }
+    TSTAMP();
+
+    // ---- zoom selection (test.py:383-387) -----------------------------------------------------------
+    int *szr = reinterpret_cast<int *>(sbuf + W_SZR), *schoff = szr + LV_R;
+    int PZ = 0;
+    for (int base = 0; base < P; base += NT) {
+        const int r = base + tid;
+        int zf = 0;
+        if (r < P) {
+            float z = szoom[sinv[r]];
+            if (a.force_root && l == 0 && r == 0) z = 1.0f;
+            zf = ((double)z >= a.Tz);
+        }
+        int tot;
+        const int off = block_excl_scan(zf, &tot, wsum);
+        if (zf) szr[PZ + off] = r;
+        PZ += tot;
+    }
+    if (tid == 0) { cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc; cnt->PZ[l] = PZ; }
+    __syncthreads();
+
+    // ---- divide_region (div.pyx:15-76) -----------------------------------------------------------
+    int CH = 0;
+    for (int base = 0; base < PZ; base += NT) {
+        const int z = base + tid;
+        const int n = z < PZ ? div_nchildren(div_plan(B + 4 * (size_t)szr[z])) : 0;
+        int tot;
+        const int ex = block_excl_scan(n, &tot, wsum);
+        if (z < PZ) schoff[z] = CH + ex;
+        CH += tot;
+    }
+    if (CH > LV_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    unsigned long long *ssort = sbuf + W_SORT, *stmp = sbuf + W_BN;
+    unsigned *sbins = reinterpret_cast<unsigned *>(sbuf + W_BINS);
+    int *sczi = reinterpret_cast<int *>(sbuf + W_SCZI);
+    __syncthreads();
+    for (int z = tid; z < PZ; z += NT) {
+        const double *r = B + 4 * (size_t)szr[z];
+        const DivPlan p = div_plan(r);
+        const int nb = div_nchildren(p);
+        const int o = schoff[z];
+        for (int bi = 0; bi < nb; ++bi) {
+            double c[4];
+            const long long key = div_child(r, p, bi, a.min_side, c);
+            ssort[o + bi] = ((unsigned long long)key << 20) | (unsigned)(o + bi);      // key < 1000^4 < 2^40
+            sczi[o + bi] = (z << 16) | bi;
+        }
+    }
+    TSTAMP();
+    // ---- _sift_dup (div.pyx:78-89) ------------------------------------------------------------------
+    block_bucket_sort(ssort, CH, stmp, sbins, 40, wsum, s_mm);              // high part = hash >> 20
+    TSTAMP();
+    double *sBn = reinterpret_cast<double *>(sbuf + W_BN);                  // (the sort is done with its scratch)
+    int Pn = 0;
+    for (int base = 0; base < CH; base += NT) {
+        const int i = base + tid;
+        int head = 0;
+        unsigned long long w = 0;
+        if (i < CH) {
+            w = ssort[i];
+            head = (i == 0) || ((ssort[i - 1] >> 20) != (w >> 20));
+        }
+        int tot;
+        const int ex = block_excl_scan(head, &tot, wsum);
+        if (head) {
+            const int slot = Pn + ex;
+            if (slot < LV_R && slot < a.capR) {
+                const int ci = sczi[(int)(w & 0xFFFFFu)];
+                const double *r = B + 4 * (size_t)szr[ci >> 16];
+                double c[4];
+                div_child(r, div_plan(r), ci & 0xFFFF, a.min_side, c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { sBn[4 * slot + q] = c[q]; a.Bnext[4 * (size_t)slot + q] = c[q]; }
+            }
+        }
+        Pn += tot;
+    }
+    if (Pn > LV_R || Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, Pn > a.capR ? 1 : 8); return; }
+    if (tid == 0) { cnt->CH[l] = CH; cnt->P[l + 1] = Pn; }
+    __syncthreads();
+    TSTAMP();
+    // ---- level l+1: roi projection + feature-space dedup (test.py:61-97, 210-218) ---------------------
+    if (Pn > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
+    const int Un = roi_dedup_sorted(sBn, Pn, a.scale, a.dedup, ssort, ssort + LV_R, sbins, s_mm, wsum, nullptr, a.index,
+                                    a.inv, a.urois, a.ubox);
+    if (tid == 0) cnt->U[l + 1] = Un;
+    TSTAMP();
+    TREPORT();
+}
+
+}  // namespace
+
+void azk_level_geom(hipStream_t s, const AzLevelArgs &a)
+{
+    hipLaunchKernelGGL(k_level_geom, dim3(1), dim3(NT), 0, s, a);
+}

@@ -252,9 +252,10 @@ class AzContext(object):
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
                     dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True,
-                    tune=False, radix_select=False):
+                    tune=False, radix_select=False, fused_levels=True):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
-        slower); fused=False keeps the geometry of those levels as separate launches.  Both
+        slower); fused=False keeps the geometry of those levels as separate launches;
+        fused_levels=False does the same for the levels after them (az_level.hip).  All
         exist for tests and measurements.  tune=True selects the tuner's variant of the search
         (lib/detect/tune.py:256-316) and keeps the anchor history (last_anchors).  radix_select=True
         does the final top-k with the single-workgroup radix select (same result, for tests)."""
@@ -262,7 +263,7 @@ class AzContext(object):
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
                         1 if fixed_num else 0,
                         (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0) |
-                        (8 if radix_select else 0))
+                        (8 if radix_select else 0) | (0 if fused_levels else 16))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates

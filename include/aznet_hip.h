@@ -63,7 +63,9 @@ typedef struct {
                                  256-316): K levels instead of K-1, Tz applied from the second
                                  level on, root not forced, anchor history kept (az_last_anchors);
                                  bit 3: final top-k by the single-workgroup radix select instead of
-                                 the chip-wide counting kernels (same result; for tests)          */
+                                 the chip-wide counting kernels (same result; for tests);
+                                 bit 4: keep the geometry of the levels after the speculative ones as
+                                 separate launches instead of one kernel per level (same bits)    */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
