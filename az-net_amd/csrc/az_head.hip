@@ -245,7 +245,7 @@ constexpr int GEMM_GRID = 512;       // 2 workgroups per CU, multiple of 8 XCDs
 #define W_AUX_STREAM 2      /* cache policy bits of the weight loads of single-strip (weight-streaming) tiles */
 #endif
 #ifndef DENSE_MIN_NRT
-#define DENSE_MIN_NRT 2
+#define DENSE_MIN_NRT 1     /* (1 vs 2: 130 rows = 3 strips | 1 strip + half: 241 -> 234 us; neutral elsewhere) */
 #endif
 static int gemm_grid()
 {
@@ -624,14 +624,14 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     // If the balanced split would end in a 1- or 2-strip tile (the weight-streaming code path), the
     // strips are dealt front-loaded instead -- e.g. 4 strips + half as (3, 1+half), not (2, 2+half).
     bool half_last = false, front = false;
-    if (half_enabled && mloop && (M & 31) && (M & 31) <= 16 && (M >> 5) >= 1) {
+    if ((half_enabled & 1) && mloop && (M & 31) && (M & 31) <= 16 && (M >> 5) >= 1) {
         const int st2 = M >> 5;
         int mt2 = tiles_for(st2), s0, nrt_last;
         mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
         if (nrt_last == 4) {
             ++mt2;
             mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
-            front = nrt_last < 3;
+            front = nrt_last < 3 && !(half_enabled & 4);
         }
         strips = st2; mt = mt2; half_last = true;
     }
@@ -939,7 +939,10 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
                  int N, int K, int S, float *part, int max_strips)
 {
     static int half = -1;                  // AZ_GEMM_HALF=0: pad the last rows to a full strip instead (measurements)
-    if (half < 0) { const char *e = getenv("AZ_GEMM_HALF"); half = e ? atoi(e) : 1; }
+    if (half < 0) {
+        const char *e = getenv("AZ_GEMM_HALF"), *f = getenv("AZ_GEMM_BALANCED");     // (bit 2: balanced tiles, measurements)
+        half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0);
+    }
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
                        fc_chunk(K, S), part, max_strips, half);
 }
