@@ -86,6 +86,7 @@ struct az_ctx {
     az_params last{};
     int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels 1-3 overflowed
     int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which a later level outgrew the fused level kernel
+    int defer_root_env = -1;            // AZ_DEFER_ROOT=0: keep the root's row in the speculative pass (measurements)
     int level_fused_env = -1;           // AZ_LEVEL_FUSED=0: keep levels >= 4 as separate launches (measurements)
     std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
@@ -237,12 +238,12 @@ int set_count(az_ctx *c, int *dptr, int v)
 // One forward of the head on the `U` rois in ctx->urois (anchors in ctx->ubox); scores and
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
-                 float *delta, double min_side = 0.0, bool keep_flags = false)
+                 float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
-                   (size_t)c->maxR * d.K6, c->gemm_parts, 0); }
+                   (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail); }
     { Timed t(c, "fc6_gemm", level, 1);
       if (c->gemm_parts)
           azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
@@ -507,11 +508,16 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     if (c->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); c->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
     const bool fused_lv = fused && nlev > n_spec && !(p->reserved & 16) && c->level_fused_env &&
                           !(p->im_h == c->nofuse_lv_h && p->im_w == c->nofuse_lv_w);
+    // The root's row (zoom forced, candidates only needed by the final selection) moves from the speculative
+    // pass to the first fused level's head pass: 48 rows = 1.5 strips instead of 49 = 2 for a 600x1000 image
+    // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
+    if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
+    const bool defer_root = fused_lv && n_spec == 3 && nlev >= n_spec + 2 && c->defer_root_env;
     if (!fused) azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
     if (fused) {
         Timed t(c, "spec_prepass", -1);
         azk_spec_prepass(s, c->cnt, c->B[0], c->B[1], c->child, c->choff_all, c->urois, p->scale, p->min_side,
-                         c->maxR, c->maxCh, p->im_h, p->im_w);
+                         c->maxR, c->maxCh, p->im_h, p->im_w, defer_root ? 1 : 0);
     } else if (n_spec) {
         Timed t(c, "spec_geometry", -1);
         // children of the root -> B1 (with _sift_dup), exactly what level 1's divide will produce
@@ -538,7 +544,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
         a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
         a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
-        a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0;
+        a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0; a.defer_root = defer_root ? 1 : 0;
         azk_spec_levels(s, a);
     }
     for (int l = fused ? n_spec : 0; l < nlev; ++l) {
@@ -548,7 +554,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         const bool lv_here = fused_lv && l + 1 < nlev;           // (the last level's copy + top-k stay chip-wide)
         if (lv_here) {
             // this level's rois were projected and deduplicated by the previous geometry kernel
-            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true);
+            // (the first fused level's head pass also carries the deferred root: row count from spec_levels)
+            launch_head(c, l == n_spec ? &c->cnt->scratch[4] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u,
+                        c->delta_u, p->min_side, true, (defer_root && l == n_spec) ? 1 : 0);
             Timed t(c, "level_geom", l);
             AzLevelArgs a;
             a.cnt = c->cnt; a.level = l; a.nlev = nlev;
@@ -558,7 +566,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             a.Yall = c->Yall; a.Sall = c->Sall;
             a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
             a.batch = p->batch_size; a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
-            a.force_root = 1;
+            a.force_root = 1; a.root_row = (defer_root && l == n_spec) ? 1 : 0;
             azk_level_geom(s, a);
             continue;
         }

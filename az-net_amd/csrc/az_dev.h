@@ -110,7 +110,7 @@ struct AzFusedArgs {
     int *srcB[2];
     int *index, *inv, *zr, *choff, *csrc;
     float *rois, *urois;          // (next_dedup) roi projection + dedup of the first level after the fused ones
-    int next_dedup;
+    int next_dedup, defer_root;
     const int *choff_all;
     double *ubox, *pred_u, *Yall, *Z, *child;
     float *zoom_u, *score_u, *delta_u, *Sall;
@@ -122,7 +122,8 @@ struct AzFusedArgs {
 
 // (also clears the counters and writes the root region: it is the first kernel of a fused search)
 void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
-                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w);
+                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w,
+                      int defer_root);
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
 
 // ---- launcher (az_level.hip): one level's geometry (and the final selection) in one workgroup ------
@@ -137,6 +138,7 @@ struct AzLevelArgs {
     int *index, *inv;              // this level's inv_index on entry; the next level's index / inv_index on exit
     const unsigned char *keep_u;   // MIN_SIDE filter of this level's decoded boxes (tail kernel)
     const int *Uptr;               // unique rois of this level
+    int root_row;                  // 1: row *Uptr of the head outputs is the deferred root (az_fused.hip)
     double *ubox;                  // next level: anchor boxes of the unique rois
     double *Yall; float *Sall;     // candidates of the whole search
     double scale, Tz, min_side;
@@ -152,7 +154,7 @@ void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
 // (planes[q * plane_stride + ...]) instead of fp32 pool5, for the split-bf16 GEMM.
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
-                  size_t plane_stride, int parts, int min_strips);
+                  size_t plane_stride, int parts, int min_strips, int coop_tail = 0);
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
 // rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);

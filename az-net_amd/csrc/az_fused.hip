@@ -54,7 +54,7 @@ __device__ void unique_slots(const long long *skey, int N, unsigned char *sfirst
 // ==========================================================================================
 __global__ void __launch_bounds__(NT)
 k_spec_prepass(AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
-               float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w)
+               float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w, int defer_root)
 {
     // first kernel of a search: clear the previous search's counters and write the root region
     // (lib/detect/test.py:355) -- what k_init_root does on the multi-launch path
@@ -120,9 +120,13 @@ k_spec_prepass(AzCounts *cnt, double *root, double *B1, double *child, int *chof
         }
     }
     __syncthreads();
-    const int total = 1 + P1 + CH;
+    // (defer_root: the root's row rides on the level-4 launch instead -- its zoom is forced and its candidates
+    //  are only needed by the final selection --, which leaves 48 rows = 1.5 strips here for a 600x1000 image)
+    const int rb = defer_root ? 0 : 1;
+    const int total = rb + P1 + CH;
     for (int i = tid; i < total; i += NT) {
-        const double *b = (i == 0) ? root : (i <= P1 ? B1 + 4 * (size_t)(i - 1) : child + 4 * (size_t)(i - 1 - P1));
+        const int j = i + 1 - rb;                          // row of the undeferred layout
+        const double *b = (j == 0) ? root : (j <= P1 ? B1 + 4 * (size_t)(j - 1) : child + 4 * (size_t)(j - 1 - P1));
         urois[5 * (size_t)i] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) urois[5 * (size_t)i + 1 + q] = (float)(b[q] * scale);
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         if (P == 0) {                                // Z was empty: the reference's loop breaks
             if (tid == 0)
                 for (int ll = l; ll < a.n_fused; ++ll) { cnt->P[ll] = 0; cnt->ytot[ll + 1] = ybase; }
-            return;
+            break;                                   // (the closing stage still runs: a deferred root needs its row)
         }
 
         // ---- roi projection + feature-space dedup (test.py:61-97, 210-218) -------------------
@@ -202,16 +206,19 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
             if (sfirst[i]) sidx[sslot[i]] = i;       // index[]: representative of each unique roi
         __syncthreads();
         // speculative row of region r's representative (level 0: the root; 1: 1 + index; 2: carried)
+        const int rb = a.defer_root ? 0 : 1;          // rows before B1's in the speculative pass
         auto spec_row = [&](int r, int &rep) {
             rep = sidx[sslot[r]];
-            return l == 0 ? 0 : (l == 1 ? 1 + rep : ssrc[cur][rep]);
+            return l == 0 ? 0 : (l == 1 ? rb + rep : ssrc[cur][rep]);
         };
 
         TSTAMP(tsn++);
         // ---- candidates: decode + clip against the representative's box (test.py:106-151), filter,
         //      ordered append to Y / aScores (test.py:171-187, 380-381) ------------------------------
         int run = 0;
-        for (int base = 0; base < P * AZ_NSUB; base += NTL) {
+        const bool deferred = a.defer_root && l == 0;      // the root's candidates arrive with level 4's head pass:
+        if (deferred) run = AZ_NSUB;                        // their slots are reserved (az_level.hip fills / closes them)
+        for (int base = 0; base < P * AZ_NSUB && !deferred; base += NTL) {
             const int c = base + tid;
             int fl = 0;
             double bx[4];
@@ -247,8 +254,8 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
             int zf = 0;
             if (r < P) {
                 int rep;
-                float z = a.zoom_s[spec_row(r, rep)];
-                if (l == 0 && r == 0) z = 1.0f;
+                float z = 1.0f;                                   // test.py:383-384: zoom[0] = 1 at level 1
+                if (!(l == 0 && r == 0)) z = a.zoom_s[spec_row(r, rep)];
                 zf = ((double)z >= a.Tz);
             }
             int tot;
@@ -299,7 +306,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
                 const double *r = B + 4 * pr;
                 div_child(r, div_plan(r), bi, a.min_side, &sB[cur ^ 1][4 * slot]);
                 // level-3 regions remember their row in the speculative pass: (parent in B1, child)
-                ssrc[cur ^ 1][slot] = (l == 1) ? 1 + P1spec + a.choff_all[pr] + bi : 0;
+                ssrc[cur ^ 1][slot] = (l == 1) ? rb + P1spec + a.choff_all[pr] + bi : 0;
             }
         if (tid == 0) cnt->CH[l] = CH;
         P = Pn;
@@ -321,18 +328,32 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         // the next level runs on the fused level kernel (az_level.hip), which expects its rois deduplicated
         if (P > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
         __syncthreads();
-        const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, a.rois,
+        const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, nullptr,
                                        a.index, a.inv, a.urois, a.ubox);
-        if (tid == 0) cnt->U[a.n_fused] = U;
+        if (tid == 0) {
+            cnt->U[a.n_fused] = U;
+            cnt->scratch[4] = U;                       // rows the head evaluates at that level
+            if (a.defer_root) {
+                // the deferred root rides as one more row behind the level's unique rois
+                const double rootb[4] = {0.0, 0.0, a.im_w - 1.0, a.im_h - 1.0};
+                a.urois[5 * (size_t)U] = 0.0f;
+                for (int q = 0; q < 4; ++q) {
+                    a.urois[5 * (size_t)U + 1 + q] = (float)(rootb[q] * a.scale);
+                    a.ubox[4 * (size_t)U + q] = rootb[q];
+                }
+                cnt->scratch[4] = U + 1;
+            }
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
-                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w)
+                      float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w,
+                      int defer_root)
 {
     hipLaunchKernelGGL(k_spec_prepass, dim3(1), dim3(NT), 0, s, cnt, root, B1, child, choff_all, urois, scale,
-                       min_side, capR, capCh, im_h, im_w);
+                       min_side, capR, capCh, im_h, im_w, defer_root);
 }
 
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a)

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                                                   float spatial_scale, const float *__restrict__ urois,
                                                   const int *Uptr, float *__restrict__ pool5,
                                                   unsigned short *__restrict__ planes, size_t plane_stride,
-                                                  int parts, int min_strips)
+                                                  int parts, int min_strips, int coop_tail)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     __shared__ __attribute__((aligned(16))) float spart[4][512];
@@ -81,11 +81,15 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
     const bool to_planes = parts > 0 && ((U + 31) >> 5) >= min_strips;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (coop_tail: the last `coop_tail` rois of a many-roi launch are large all the same -- the deferred root of
+    //  az_fused.hip is the whole image -- and take the cooperative form)
+    int u_lo = 0;
     if (U > ROI_POOL_COOP_MAX) {
         // many rois = small windows (a level deep in the tree): one wave per (roi, bin) with all the
         // channel chunks of a cell in flight; the cooperative form below would idle three waves
         const int nwaves = (gridDim.x * blockDim.x) >> 6;
-        for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < U * PP; item += nwaves) {
+        u_lo = max(U - coop_tail, 0);
+        for (int item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; item < u_lo * PP; item += nwaves) {
             const int u = item / PP, p = item - u * PP;
             const int ph = p / P, pw = p - ph * P;
             const float *roi = urois + 5 * (size_t)u;
@@ -138,9 +142,9 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                     }
             }
         }
-        return;
+        if (u_lo >= U) return;
     }
-    for (int item = blockIdx.x; item < U * PP; item += gridDim.x) {
+    for (int item = u_lo * PP + blockIdx.x; item < U * PP; item += gridDim.x) {
         const int u = item / PP, p = item - u * PP;
         const int ph = p / P, pw = p - ph * P;
         const float *roi = urois + 5 * (size_t)u;
@@ -719,7 +723,10 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
 constexpr int NOUT = AZ_NSUB * 5 + 1;   // 56
 constexpr int TAIL_ROWS = 4;
 constexpr int TAIL_WAVES = 16;
-constexpr int TAIL_KB = 16;             // k values per register batch
+#ifndef AZ_TAIL_KB
+#define AZ_TAIL_KB 16
+#endif
+constexpr int TAIL_KB = AZ_TAIL_KB;     // k values per register batch
 
 // Every wave walks the same number of k (a multiple of two register batches): the weight block
 // and the LDS rows are zero-padded to TAIL_WAVES * kq, so the loop has no conditional loads
@@ -902,11 +909,11 @@ __global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int n
 // --------------------------------------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
                   const int *Uptr, int capU, float *pool5, unsigned short *planes, size_t plane_stride, int parts,
-                  int min_strips)
+                  int min_strips, int coop_tail)
 {
     (void)capU;
     hipLaunchKernelGGL(k_roi_pool, dim3(4096), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
-                       planes, plane_stride, parts, min_strips);
+                       planes, plane_stride, parts, min_strips, coop_tail);
 }
 
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     const int U = *a.Uptr;
     const int ybase = cnt->ytot[l];
     if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
-    if (P > LV_R || U > LV_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
     TSTAMP();
 
     // ---- one round trip: this level's inv_index, zoom scores and keep flags -> LDS; its regions -> cache ----
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         double warm = 0.0;
         for (int r = tid; r < P; r += NT) { sinv[r] = a.inv[r]; warm += B[4 * (size_t)r]; }
         for (int u = tid; u < U; u += NT) szoom[u] = a.zoom_u[u];
-        for (int i = tid; i < U * AZ_NSUB; i += NT) skeep[i] = a.keep_u[i];
+        for (int i = tid; i < (U + a.root_row) * AZ_NSUB; i += NT) skeep[i] = a.keep_u[i];
         if (warm == -1.2345e300) szoom[0] = 0.f;           // (never true; keeps the region loads alive: they warm this CU's caches)
     }
     __syncthreads();
@@ -121,6 +121,51 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         nc = tot;
     }
     if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0) atomicOr(&cnt->err, 2); }
+    int shift = 0;
+    if (a.root_row) {
+        // The root's row rode on this level's head pass (az_fused.hip: its candidates are the first of Y, and the
+        // 11 slots at the head of Y / aScores were reserved for them): the kept ones go there in order, and if
+        // the MIN_SIDE filter dropped some, everything behind closes the gap.
+        __syncthreads();                                    // (this level's candidates are in place)
+        const int kp = (tid < AZ_NSUB) ? (int)skeep[U * AZ_NSUB + tid] : 0;
+        const unsigned long long m = __ballot(kp);          // (wave 0 holds the 11 flags)
+        if (tid == 0) wsum[0] = __popcll(m);
+        if (tid < AZ_NSUB && kp) {
+            const int dst = __popcll(m & ((1ull << tid) - 1ull));
+            const size_t src = (size_t)U * AZ_NSUB + tid;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = a.pred_u[src * 4 + q];
+            a.Sall[dst] = a.score_u[src];
+        }
+        __syncthreads();
+        const int nc0 = wsum[0];
+        shift = AZ_NSUB - nc0;
+        __syncthreads();
+        if (shift > 0) {
+            const int end = ybase + nc;
+            for (int base = AZ_NSUB; base < end; base += NT) {
+                const int i = base + tid;
+                double bx[4] = {0.0, 0.0, 0.0, 0.0};
+                float sc = 0.f;
+                if (i < end) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bx[q] = a.Yall[(size_t)i * 4 + q];
+                    sc = a.Sall[i];
+                }
+                __syncthreads();
+                if (i < end) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a.Yall[(size_t)(i - shift) * 4 + q] = bx[q];
+                    a.Sall[i - shift] = sc;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            cnt->NC[0] = nc0;
+            for (int ll = 1; ll <= l; ++ll) cnt->ytot[ll] -= shift;
+        }
+    }
     TSTAMP();
 
     // ---- zoom selection (test.py:383-387) -----------------------------------------------------------
@@ -139,7 +184,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         if (zf) szr[PZ + off] = r;
         PZ += tot;
     }
-    if (tid == 0) { cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc; cnt->PZ[l] = PZ; }
+    if (tid == 0) { cnt->NC[l] = nc; cnt->ytot[l + 1] = ybase + nc - shift; cnt->PZ[l] = PZ; }
     __syncthreads();
 
     // ---- divide_region (div.pyx:15-76) -----------------------------------------------------------
