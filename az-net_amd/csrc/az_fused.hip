@@ -182,7 +182,23 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     int P = 1;
     int ybase = 0;
     const int P1spec = cnt->specP1;
-    for (int l = 0; l < a.n_fused; ++l) {
+    int l0 = 0;
+    if (a.defer_root) {
+        // Level 1 needs no head output here: the root's zoom is forced (test.py:383-384), its candidates arrive
+        // later (11 reserved slots), and its children after _sift_dup are the pre-pass's B1.
+        const bool rz = (1.0 >= a.Tz);                  // zoom[0] = 1, then indZ = where(zoom >= Tz)
+        P = rz ? P1spec : 0;
+        if (P > FL_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+        for (int i = tid; i < P * 4; i += NTL) sB[1][i] = a.B[1][i];
+        if (tid == 0) {
+            cnt->P[0] = 1; cnt->U[0] = 1; cnt->NC[0] = AZ_NSUB; cnt->ytot[0] = 0; cnt->PZ[0] = rz ? 1 : 0;
+            cnt->CH[0] = rz ? div_nchildren(div_plan(sB[0])) : 0;
+        }
+        ybase = AZ_NSUB;
+        l0 = 1;
+        __syncthreads();
+    }
+    for (int l = l0; l < a.n_fused; ++l) {
         const int cur = l & 1;
         const double *B = sB[cur];
         if (tid == 0) { cnt->P[l] = P; cnt->ytot[l] = ybase; }
