@@ -386,7 +386,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     const size_t R = (size_t)c->maxR;
     int rc;
 #define A(p, n) if ((rc = dalloc(c, &c->p, (n))) != AZ_OK) return rc
-    A(W6, (size_t)n6 * d.K6); A(b6, n6); A(W7, (size_t)d.n7 * n6); A(b7, d.n7);
+    A(W6, azk_tiled_elems(n6, d.K6)); A(b6, n6); A(W7, azk_tiled_elems(d.n7, n6)); A(b7, d.n7);
     A(Wt, 64 * azk_tail_weight_rows(d.n7)); A(bt, 64);
     A(pool5, R * d.K6);
     {
@@ -401,17 +401,22 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
     // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
     // W6's columns to match (c*49 + p  ->  p*C + c).  `part` is big enough to stage it.
+    // The GEMM streams weights tile-major (azk_tile_weights): permute / stack in a row-major temporary, then tile.
+    float *tmp = nullptr;
+    HIPCHK(c, hipMalloc((void **)&tmp, (size_t)n6 * d.K6 * 4));
     HIPCHK(c, hipMemcpy(c->part, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
-    azk_permute_k(c->stream, c->part, c->W6, n6, C, 1);
+    azk_permute_k(c->stream, c->part, tmp, n6, C, 1);
+    if (c->gemm_parts)            // bf16 round-off planes of the (permuted, row-major) int6 weights
+        azk_split_planes(c->stream, tmp, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts);
+    azk_tile_weights(c->stream, tmp, c->W6, n6, d.K6);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->gemm_parts) {          // bf16 round-off planes of the (permuted) int6 weights
-        azk_split_planes(c->stream, c->W6, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
     HIPCHK(c, hipMemcpy(c->b6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
     // int7_1 and int7_2 both read int6: one GEMM with the two weight blocks stacked along N.
-    HIPCHK(c, hipMemcpy(c->W7, W71, (size_t)n71 * n6 * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->W7 + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(tmp, W71, (size_t)n71 * n6 * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(tmp + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
+    azk_tile_weights(c->stream, tmp, c->W7, d.n7, n6);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(tmp));
     HIPCHK(c, hipMemcpy(c->b7, b71, (size_t)n71 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7 + n71, b72, (size_t)n72 * 4, hipMemcpyHostToDevice));
     // tail weights, k-major [n7][64]: outputs 0..10 adj_score, 11..54 adj_bbox (k < n71), output 55
@@ -1052,7 +1057,8 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
     c->det_n6 = n6; c->det_n7 = n7; c->det_ncls = ncls;
     c->det_S6 = azk_fc_split((int)K6); c->det_S7 = azk_fc_split(n6);
 #define A(p, n) if ((rc = dalloc_det(c, &c->p, (n))) != AZ_OK) return rc
-    A(dW6, (size_t)n6 * K6); A(db6, n6); A(dW7, (size_t)n7 * n6); A(db7, n7); A(dWt, NO * n7); A(dbt, NO);
+    A(dW6, azk_tiled_elems(n6, (int)K6)); A(db6, n6); A(dW7, azk_tiled_elems(n7, n6)); A(db7, n7);
+    A(dWt, azk_tiled_elems((int)NO, n7)); A(dbt, NO);
     A(dh6, R * n6); A(dh7, R * n7);
     {
         size_t pm = (size_t)c->det_S6 * R * n6;
@@ -1064,15 +1070,28 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
     if (!c->pool5) { A(pool5, R * K6); }     // normally the AZ head's buffer is shared
 #undef A
     if (!c->head_loaded) { c->d.C = C; c->d.pooled = 7; c->d.K6 = (int)K6; }
-    HIPCHK(c, hipMemcpy(c->dpart, W6, (size_t)n6 * K6 * 4, hipMemcpyHostToDevice));
-    azk_permute_k(c->stream, c->dpart, c->dW6, n6, C, 1);          // bin-major columns, like the AZ head
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        float *tmp = nullptr;
+        size_t te = (size_t)n6 * K6;
+        if ((size_t)n7 * n6 > te) te = (size_t)n7 * n6;
+        if (NO * n7 > te) te = NO * n7;
+        HIPCHK(c, hipMalloc((void **)&tmp, te * 4));
+        HIPCHK(c, hipMemcpy(c->dpart, W6, (size_t)n6 * K6 * 4, hipMemcpyHostToDevice));
+        azk_permute_k(c->stream, c->dpart, tmp, n6, C, 1);          // bin-major columns, like the AZ head
+        azk_tile_weights(c->stream, tmp, c->dW6, n6, (int)K6);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(tmp, W7, (size_t)n7 * n6 * 4, hipMemcpyHostToDevice));
+        azk_tile_weights(c->stream, tmp, c->dW7, n7, n6);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // rows 0..ncls-1 cls_score, ncls..5*ncls-1 bbox_pred
+        HIPCHK(c, hipMemcpy(tmp, Wc, (size_t)ncls * n7 * 4, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(tmp + (size_t)ncls * n7, Wb, (size_t)4 * ncls * n7 * 4, hipMemcpyHostToDevice));
+        azk_tile_weights(c->stream, tmp, c->dWt, (int)NO, n7);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(tmp));
+    }
     HIPCHK(c, hipMemcpy(c->db6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->dW7, W7, (size_t)n7 * n6 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->db7, b7, (size_t)n7 * 4, hipMemcpyHostToDevice));
-    // rows 0..ncls-1 cls_score, ncls..5*ncls-1 bbox_pred
-    HIPCHK(c, hipMemcpy(c->dWt, Wc, (size_t)ncls * n7 * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->dWt + (size_t)ncls * n7, Wb, (size_t)4 * ncls * n7 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dbt, bc, (size_t)ncls * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->dbt + ncls, bb, (size_t)4 * ncls * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipDeviceSynchronize());

@@ -161,6 +161,10 @@ void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, i
 // y[M,N] = act(x[M,K] . W[N,K]^T + b) with a fixed S-way split of K (see az_head.hip):
 // _gemm writes the S partial slabs part[s][m][n], _reduce adds them in order + bias (+ReLU).
 // (launches with more than max_strips 32-row strips are skipped: another kernel owns them)
+// W: the layer's [N][K] weights in the tile-major layout of azk_tile_weights (azk_tiled_elems(N, K) floats);
+// ldw = K
+size_t azk_tiled_elems(int N, int K);
+void azk_tile_weights(hipStream_t s, const float *rowmajor, float *tiled, int N, int K);
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
                  int N, int K, int S, float *part, int max_strips = 1 << 30);
 int azk_fc_chunk(int K, int S);

@@ -60,6 +60,23 @@ __global__ void k_permute_k(const float *__restrict__ in, float *__restrict__ ou
     }
 }
 
+// InnerProduct weights [N][K] row-major -> the tile-major layout the GEMM streams: [N/128][K/32][128][32],
+// zero-padded.  A workgroup's weight tile of one K-step is then ONE contiguous 16 KB block (in the row-major
+// layout it is 128 separate 128-byte pieces 100 KB apart: a DRAM page miss each, and the weight-streaming
+// bound launches -- the speculative pass, level 4's second tile -- ran at 4.3 of ~5.5 TB/s).
+__global__ void k_tile_weights(const float *__restrict__ in, float *__restrict__ out, int N, int K, long long total)
+{
+    const int KT = (K + 31) >> 5;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(idx & 31), row = (int)((idx >> 5) & 127);
+        const long long tile = idx >> 12;
+        const int kt = (int)(tile % KT), nt = (int)(tile / KT);
+        const int n = nt * 128 + row, k = kt * 32 + kk;
+        out[idx] = (n < N && k < K) ? in[(size_t)n * K + k] : 0.f;
+    }
+}
+
 // Caffe ROIPooling (test_fc.prototxt:14-25).  One workgroup (4 waves) per (roi, bin): the bin's
 // window cells are dealt round-robin to the waves, a lane reads 4 consecutive channels of a cell
 // (float4; the map is channel-last), four cells per wave are in flight together, and the four
@@ -340,20 +357,23 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     // descriptors start at the tile's first row; per-thread row offsets are loop-invariant
     const __amdgpu_buffer_rsrc_t rsA = tile_rsrc(X + (size_t)m0 * ldx, (size_t)(M - m0) * ldx);
-    const __amdgpu_buffer_rsrc_t rsB = tile_rsrc(Wt + (size_t)n0 * ldw, (size_t)(N - n0) * ldw);
+    // weights are tile-major (k_tile_weights): the 128 x 32 tile of K-step t of this n-tile is the t-th 16 KB block
+    const int KT = (ldw + BK - 1) / BK;                  // ldw = K of the whole layer
+    const __amdgpu_buffer_rsrc_t rsB = tile_rsrc(Wt + (size_t)(n0 / BN) * KT * (BN * BK), (size_t)KT * (BN * BK));
     unsigned voA[NLA], voB[4];
 #pragma unroll
     for (int i = 0; i < NRT; ++i) voA[i] = (unsigned)((min(srow + 32 * i, M - 1 - m0) * ldx + sc4) * 4);
     // half strip: 16 rows x 8 float4 -- threads t and t + 128 stage the same vector (same value, same place)
     if constexpr (HALF) voA[NRT] = (unsigned)((min(NRT * 32 + (srow & 15), M - 1 - m0) * ldx + sc4) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) voB[i] = (unsigned)((min(srow + 32 * i, N - 1 - n0) * ldw + sc4) * 4);
+    for (int i = 0; i < 4; ++i) voB[i] = (unsigned)(((srow + 32 * i) * BK + sc4) * 4);
     auto gload = [&](int kt, float4 (&ra)[NLA], float4 (&rb)[4]) {
         const unsigned so = (unsigned)(k0 + kt * BK) * 4u;
+        const unsigned sob = (unsigned)(k0 / BK + kt) * (unsigned)(BN * BK * 4);
 #pragma unroll
         for (int i = 0; i < NLA; ++i) ra[i] = buf_ld(rsA, voA[i], so);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = buf_ld<(NRT <= W_AUX_MAX_NRT) ? W_AUX_STREAM : 0>(rsB, voB[i], so);
+        for (int i = 0; i < 4; ++i) rb[i] = buf_ld<(NRT <= W_AUX_MAX_NRT) ? W_AUX_STREAM : 0>(rsB, voB[i], sob);
     };
     auto lstore = [&](int kt, int buf, const float4 (&ra)[NLA], const float4 (&rb)[4]) {
         const bool ok = (k0 + kt * BK + sc4) < kend;
@@ -919,6 +939,13 @@ void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spa
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)
 {
     hipLaunchKernelGGL(k_permute_k, dim3(4096), dim3(256), 0, s, in, out, rows, C, to_bin_major);
+}
+
+size_t azk_tiled_elems(int N, int K) { return (size_t)((N + BN - 1) / BN) * ((K + BK - 1) / BK) * (BN * BK); }
+
+void azk_tile_weights(hipStream_t s, const float *in, float *out, int N, int K)
+{
+    hipLaunchKernelGGL(k_tile_weights, dim3(4096), dim3(256), 0, s, in, out, N, K, (long long)azk_tiled_elems(N, K));
 }
 
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW)
