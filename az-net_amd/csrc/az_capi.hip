@@ -696,6 +696,13 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     return AZ_OK;
 }
 
+int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W)
+{
+    int rc = set_feature_map_common(c, dev_map, false, C, H, W, false);
+    if (rc) return rc;
+    return az_propose_launch(c, p);
+}
+
 int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
 {
     if (!c || !c->launched) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");

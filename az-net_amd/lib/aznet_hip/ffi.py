@@ -32,6 +32,7 @@ SYMBOLS = [
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
+    "az_propose_launch_on",
 ]
 
 
@@ -103,6 +104,7 @@ def load_library(path=None):
     L.az_propose_stage_result_dev.argtypes = [vp, vp, ctypes.c_size_t]
     L.az_propose.argtypes = [vp, ctypes.POINTER(AzParams), dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_propose_launch.argtypes = [vp, ctypes.POINTER(AzParams)]
+    L.az_propose_launch_on.argtypes = [vp, ctypes.POINTER(AzParams), vp, ci, ci, ci]
     L.az_propose_fetch.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_last_candidates.argtypes = [vp, dp, fp, ci, cip]
     L.az_divide_region.argtypes = [vp, dp, ci, cd, dp, ci, cip]
@@ -280,9 +282,23 @@ class AzContext(object):
             out.append(st)
         return out[0] if len(out) == 1 else tuple(out)
 
-    def propose_launch(self, params):
+    def propose_launch(self, params, fmap=None, producer_done=False):
+        """fmap (a CUDA torch tensor [1,C,H,W] / [C,H,W] on this GPU): hand the image's map over in the same call
+        (az_propose_launch_on); it must stay untouched until propose_fetch returns.  producer_done=True skips the
+        synchronisation of torch's current stream (the caller knows the map is complete)."""
         self._last_params = params
-        self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
+        if fmap is None:
+            self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
+            return
+        t = fmap[0] if fmap.dim() == 4 else fmap
+        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32" and t.device.index == self.device
+        if not producer_done:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
+        C, H, W = (int(x) for x in t.shape)
+        self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(t.data_ptr()), C, H, W))
+        self._feat_keepalive = fmap
+        self.feat_shape = (C, H, W)
 
     def propose_fetch(self, want_scores=False, want_stats=False):
         params = self._last_params

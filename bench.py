@@ -188,8 +188,8 @@ def main():
     def run(nsteps, timed):
         if args.inflight == 1:
             for i in range(nsteps):
-                net.set_conv(convs[i % len(convs)], wait=False)       # this step's image (one transpose kernel)
-                net.ctx.propose_launch(params)
+                # this step's image: its map is handed over (one transpose kernel) with the launch
+                net.ctx.propose_launch(params, fmap=convs[i % len(convs)], producer_done=True)
                 if gat is not None:
                     gat.stage(pending[0])
                 net.ctx.propose_fetch(want_scores=True)
@@ -201,8 +201,7 @@ def main():
             n = nets[i % len(nets)]
             if len(q) == len(nets):
                 q.pop(0).ctx.propose_fetch(want_scores=True)
-            n.set_conv(convs[i % len(convs)], wait=False)
-            n.ctx.propose_launch(params)
+            n.ctx.propose_launch(params, fmap=convs[i % len(convs)], producer_done=True)
             q.append(n)
         for m in q:
             m.ctx.propose_fetch(want_scores=True)

@@ -136,6 +136,8 @@ int az_propose(az_ctx *ctx, const az_params *p, double *boxes_out, float *scores
 /* Same search split in two so the caller can overlap other GPU work (the next image's
  * backbone): _launch enqueues everything and returns, _fetch waits and copies out. */
 int az_propose_launch(az_ctx *ctx, const az_params *p);
+/* az_set_feature_map_dev_async + az_propose_launch in one call (one host round trip per image). */
+int az_propose_launch_on(az_ctx *ctx, const az_params *p, const float *dev_map, int C, int H, int W);
 int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out,
                      az_stats *stats);
 /* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size
