@@ -696,9 +696,21 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     return AZ_OK;
 }
 
-int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W)
+int az_set_feature_map_dev_nhwc(az_ctx *c, const float *dev_ptr, int C, int H, int W)
 {
-    int rc = set_feature_map_common(c, dev_map, false, C, H, W, false);
+    int rc = check_ready(c, false);
+    if (rc) return rc;
+    if (!dev_ptr || C != c->d.C || H <= 0 || W <= 0)
+        return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
+    c->feat = dev_ptr;                 // already in the layout RoIPool reads: borrowed, no copy
+    c->d.H = H; c->d.W = W;
+    return AZ_OK;
+}
+
+int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W, int channels_last)
+{
+    int rc = channels_last ? az_set_feature_map_dev_nhwc(c, dev_map, C, H, W)
+                           : set_feature_map_common(c, dev_map, false, C, H, W, false);
     if (rc) return rc;
     return az_propose_launch(c, p);
 }

@@ -19,9 +19,12 @@ VGG16_CONV = [("conv1_1", 64), ("conv1_2", 64), "P", ("conv2_1", 128), ("conv2_2
 
 
 class VGG16Conv5(object):
-    def __init__(self, device="cuda:0", seed=4321, weights=None, width_div=1):
-        """width_div > 1 shrinks every layer's channel count (fast tests); 1 = real VGG16."""
+    def __init__(self, device="cuda:0", seed=4321, weights=None, width_div=1, channels_last_out=False):
+        """width_div > 1 shrinks every layer's channel count (fast tests); 1 = real VGG16.
+        channels_last_out: return conv5_3 in torch.channels_last memory ([H][W][C], the layout RoIPool reads):
+        the HIP context then borrows it without its own transpose."""
         self.device = torch.device(device)
+        self.channels_last_out = bool(channels_last_out)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.layers = []
         cin = 3
@@ -51,6 +54,8 @@ class VGG16Conv5(object):
                 x = F.max_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
             else:
                 x = F.relu_(F.conv2d(x, layer[1], layer[2], padding=1))
+        if self.channels_last_out:
+            return x.contiguous(memory_format=torch.channels_last)
         return x.contiguous()
 
     __call__ = forward

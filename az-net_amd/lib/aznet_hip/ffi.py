@@ -32,7 +32,7 @@ SYMBOLS = [
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
-    "az_propose_launch_on",
+    "az_propose_launch_on", "az_set_feature_map_dev_nhwc",
 ]
 
 
@@ -104,7 +104,8 @@ def load_library(path=None):
     L.az_propose_stage_result_dev.argtypes = [vp, vp, ctypes.c_size_t]
     L.az_propose.argtypes = [vp, ctypes.POINTER(AzParams), dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_propose_launch.argtypes = [vp, ctypes.POINTER(AzParams)]
-    L.az_propose_launch_on.argtypes = [vp, ctypes.POINTER(AzParams), vp, ci, ci, ci]
+    L.az_propose_launch_on.argtypes = [vp, ctypes.POINTER(AzParams), vp, ci, ci, ci, ci]
+    L.az_set_feature_map_dev_nhwc.argtypes = [vp, vp, ci, ci, ci]
     L.az_propose_fetch.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_last_candidates.argtypes = [vp, dp, fp, ci, cip]
     L.az_divide_region.argtypes = [vp, dp, ci, cd, dp, ci, cip]
@@ -236,19 +237,30 @@ class AzContext(object):
             self._chk(self.L.az_set_feature_map_host(self.h, _p(a, ctypes.c_float), C, H, W))
             self._feat_keepalive = None
         else:   # torch tensor on this device
-            t = fmap
-            if t.dim() == 4:
-                assert t.shape[0] == 1
-                t = t[0]
-            assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32"
-            assert t.device.index == self.device, "feature map lives on another GPU than this context"
+            t, cl = self._torch_map(fmap)
             C, H, W = (int(x) for x in t.shape)
             import torch
             torch.cuda.current_stream(t.device).synchronize()     # producer (backbone) done
-            fn = self.L.az_set_feature_map_dev if wait else self.L.az_set_feature_map_dev_async
+            fn = self.L.az_set_feature_map_dev_nhwc if cl else (
+                self.L.az_set_feature_map_dev if wait else self.L.az_set_feature_map_dev_async)
             self._chk(fn(self.h, ctypes.c_void_p(t.data_ptr()), C, H, W))
             self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
+
+    def _torch_map(self, fmap):
+        """(tensor [C,H,W] view, channels_last?) of a CUDA conv5_3 tensor: NCHW-contiguous maps are transposed into
+        ctx memory by the library, torch.channels_last ones ([1,C,H,W] stored [H][W][C]) are borrowed as they are."""
+        import torch
+        t = fmap
+        assert t.is_cuda and str(t.dtype) == "torch.float32" and t.device.index == self.device, \
+            "feature map must be a float32 CUDA tensor on this context's GPU"
+        if t.dim() == 4:
+            assert t.shape[0] == 1
+            if t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+                return t[0], True
+            t = t[0]
+        assert t.is_contiguous()
+        return t, False
 
     # ---- hot path -----------------------------------------------------------------
     @staticmethod
@@ -290,13 +302,13 @@ class AzContext(object):
         if fmap is None:
             self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
             return
-        t = fmap[0] if fmap.dim() == 4 else fmap
-        assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32" and t.device.index == self.device
+        t, cl = self._torch_map(fmap)
         if not producer_done:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
         C, H, W = (int(x) for x in t.shape)
-        self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(t.data_ptr()), C, H, W))
+        self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(t.data_ptr()), C, H, W,
+                                              1 if cl else 0))
         self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
 

@@ -157,7 +157,8 @@ def main():
     im = ims[0]
     blob, scales = _get_image_blob(im, net)                  # HIP front-end kernel -> CUDA tensor
     backbone.normalize_output(blob)                          # random-init weights: unit-RMS conv5_3
-    convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone() for x in ims]   # resident in HBM from here on
+    # resident in HBM from here on, channel-last (what the backbone hands over with channels_last_out=True)
+    convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone().contiguous(memory_format=torch.channels_last) for x in ims]
     conv = convs[0]
     net.set_conv(conv)
     params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS)

@@ -125,6 +125,9 @@ int az_set_feature_map_host(az_ctx *ctx, const float *host_ptr, int C, int H, in
  * so handing over the next image's map costs no host round trip.  The source must stay valid (and
  * unmodified) until the next az_propose_fetch / az_propose on this ctx returns. */
 int az_set_feature_map_dev_async(az_ctx *ctx, const float *dev_ptr, int C, int H, int W);
+/* A map that is already channel-last in HBM ([H][W][C], e.g. a torch.channels_last conv5_3): borrowed as is, no
+ * transpose and no copy.  It must stay valid and unmodified while searches use it. */
+int az_set_feature_map_dev_nhwc(az_ctx *ctx, const float *dev_ptr, int C, int H, int W);
 
 /* ---- the hot path --------------------------------------------------------------- */
 /* Replaces im_propose (lib/detect/test.py:346-414) given the cached conv5_3: the whole
@@ -136,8 +139,10 @@ int az_propose(az_ctx *ctx, const az_params *p, double *boxes_out, float *scores
 /* Same search split in two so the caller can overlap other GPU work (the next image's
  * backbone): _launch enqueues everything and returns, _fetch waits and copies out. */
 int az_propose_launch(az_ctx *ctx, const az_params *p);
-/* az_set_feature_map_dev_async + az_propose_launch in one call (one host round trip per image). */
-int az_propose_launch_on(az_ctx *ctx, const az_params *p, const float *dev_map, int C, int H, int W);
+/* az_set_feature_map_dev_async (channels_last = 0: NCHW source) or az_set_feature_map_dev_nhwc (1) followed by
+ * az_propose_launch, in one call: one host round trip per image. */
+int az_propose_launch_on(az_ctx *ctx, const az_params *p, const float *dev_map, int C, int H, int W,
+                         int channels_last);
 int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out,
                      az_stats *stats);
 /* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size

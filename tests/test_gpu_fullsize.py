@@ -260,3 +260,30 @@ def test_full_size_det_head_vs_cpu_oracle(full, mods):
     assert s.shape == (300, 21) and bx.shape == (300, 84)
     assert np.abs(s - sr).max() <= 1e-4
     np.testing.assert_allclose(bx, bxr, rtol=1e-4, atol=2e-2)
+
+
+def test_channels_last_map_is_borrowed_and_equal(small, mods):
+    """A torch.channels_last conv5_3 is read in place (az_set_feature_map_dev_nhwc, no transpose): same proposals
+    as the NCHW tensor and as the host array; also through the one-call launch (az_propose_launch_on)."""
+    import torch
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    fmap = synth.make_feature_map(12, synth.SMALL_DIMS["C"], 38, 63)
+    p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0)
+    net.set_conv(fmap)
+    want = net.propose(p, want_scores=True)
+    t = torch.from_numpy(fmap).cuda()
+    tcl = t.contiguous(memory_format=torch.channels_last)
+    assert not tcl.is_contiguous()
+    for m in (t, tcl):
+        net.set_conv(m)
+        got = net.propose(p, want_scores=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        net.ctx.propose_launch(p, fmap=m)
+        got = net.ctx.propose_fetch(want_scores=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    from aznet_hip.backbone import VGG16Conv5
+    bb = VGG16Conv5(device="cuda:0", seed=2, width_div=32, channels_last_out=True)
+    x = torch.zeros(1, 3, 64, 96)
+    y = bb(x)
+    assert y.is_contiguous(memory_format=torch.channels_last) and tuple(y.shape) == (1, 16, 4, 6)
