@@ -709,10 +709,18 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
         const int m = (int)(idx / N4);
         const int n = (int)(idx - (long long)m * N4) * 4;
         const float *p = part + (size_t)m * N + n;
-        float4 a = *reinterpret_cast<const float4 *>(p);
-        for (int s = 1; s < S; ++s) {
-            const float4 t = *reinterpret_cast<const float4 *>(p + s * slab);
-            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        // slabs in batches of 8 independent loads (one memory round trip per batch), added in chunk order
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S - 1) * slab);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < S) {
+                    if (s0 + j == 0) a = t[j];
+                    else { a.x += t[j].x; a.y += t[j].y; a.z += t[j].z; a.w += t[j].w; }
+                }
         }
         const float4 b = *reinterpret_cast<const float4 *>(bias + n);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
@@ -788,10 +796,17 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < nr && k < n7) {
                 const float *p = part7 + (size_t)(u0 + r) * n7 + k;
-                v = *reinterpret_cast<const float4 *>(p);
-                for (int sl = 1; sl < S7; ++sl) {
-                    const float4 t = *reinterpret_cast<const float4 *>(p + sl * slab7);
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                // (batches of 8 independent loads: one memory round trip per batch; added in chunk order)
+                for (int s0 = 0; s0 < S7; s0 += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S7 - 1) * slab7);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (s0 + j < S7) {
+                            if (s0 + j == 0) v = t[j];
+                            else { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+                        }
                 }
                 const float4 bb = *reinterpret_cast<const float4 *>(b7 + k);
                 v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
