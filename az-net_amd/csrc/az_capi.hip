@@ -53,6 +53,11 @@ struct az_ctx {
     // speculative levels 1-3: provenance of zoomed regions / children / regions, head outputs of the pass
     int *zr = nullptr, *csrc = nullptr, *choff_all = nullptr, *srcB[2] = {nullptr, nullptr};
     float *zoom_s = nullptr, *score_s = nullptr, *delta_s = nullptr;
+    // the speculative pre-pass depends on the image shape only: its outputs are kept per shape (one entry)
+    float *spec_urois = nullptr;
+    double *specB1 = nullptr;
+    int *spec_choff = nullptr, *spec_U = nullptr;
+    struct { int h = -1, w = -1, defer = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc;
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
@@ -174,6 +179,7 @@ int ensure_geom(az_ctx *c)
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
+    A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -238,11 +244,12 @@ int set_count(az_ctx *c, int *dptr, int v)
 // One forward of the head on the `U` rois in ctx->urois (anchors in ctx->ubox); scores and
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
-                 float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0)
+                 float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0,
+                 const float *urois = nullptr)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
-      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
                    (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail); }
     { Timed t(c, "fc6_gemm", level, 1);
       if (c->gemm_parts)
@@ -484,6 +491,56 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
     return set_feature_map_common(c, dev_ptr, false, C, H, W, false);
 }
 
+// Which form of the search a call takes.
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; };
+
+static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune)
+{
+    SearchPlan q;
+    q.n_spec = (nlev >= 3 && !(p->reserved & 1) && !tune) ? 3 : 0;
+    // The geometry of those three levels is a few dozen elements per stage: by default it runs
+    // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
+    // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
+    q.fused = q.n_spec && !(p->reserved & 2) && !(p->im_h == c->nofuse_h && p->im_w == c->nofuse_w);
+    // Levels after the speculative ones: one single-workgroup kernel per mid-tree level (az_level.hip) instead of
+    // ten launches (params.reserved bit 4 / AZ_LEVEL_FUSED=0 keep the multi-launch form; same bits).
+    if (c->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); c->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
+    q.fused_lv = q.fused && nlev > q.n_spec && !(p->reserved & 16) && c->level_fused_env &&
+                 !(p->im_h == c->nofuse_lv_h && p->im_w == c->nofuse_lv_w);
+    // The root's row (zoom forced, candidates only needed by the final selection) moves from the speculative
+    // pass to the first fused level's head pass: 48 rows = 1.5 strips instead of 49 = 2 for a 600x1000 image
+    // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
+    if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
+    q.defer_root = q.fused_lv && q.n_spec == 3 && nlev >= q.n_spec + 2 && c->defer_root_env;
+    return q;
+}
+
+// The speculative pre-pass (B1 = divide_region(root), all children of B1, the rois of the speculative rows) is a
+// function of the image shape alone: run once per shape, outside any graph capture, its outputs kept in
+// dedicated buffers and its three counters on the host; k_spec_levels restores them for every search.
+static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
+{
+    if (!q.fused) return AZ_OK;
+    auto &k = c->spc;
+    const int defer = q.defer_root ? 1 : 0;
+    if (k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side && k.defer == defer)
+        return AZ_OK;
+    hipStream_t s = c->stream;
+    azk_spec_prepass(s, c->cnt, c->B[0], c->specB1, c->child, c->spec_choff, c->spec_urois, p->scale, p->min_side,
+                     c->maxR, c->maxCh, p->im_h, p->im_w, defer);
+    HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(c->spec_U, &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->h_cnt->err) {               // the speculative rows outgrow the context: take the multi-launch path
+        c->nofuse_h = p->im_h; c->nofuse_w = p->im_w;
+        k.h = -1;
+        return AZ_OK;
+    }
+    k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.defer = defer;
+    k.P1 = c->h_cnt->specP1; k.CH = c->h_cnt->specCH; k.U = c->h_cnt->specU;
+    return AZ_OK;
+}
+
 // --------------------------------------------------------------------------------------
 // Everything az_propose enqueues on the ctx stream (no host synchronisation, no host-dependent sizes:
 // every count is read on the device), so the same sequence can also be captured into a hipGraph.
@@ -497,32 +554,18 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     // instead of three (each of those levels is weight-streaming-bound).  Head outputs are a
     // fixed function of the roi, so the levels below just look their rows up: bit-identical
     // results.  (params.reserved bit 0 turns this off.)
-    const int n_spec = (nlev >= 3 && !(p->reserved & 1) && !tune) ? 3 : 0;
+    const SearchPlan plan = plan_search(c, p, nlev, tune);
+    const int n_spec = plan.n_spec;
+    const bool fused = plan.fused, fused_lv = plan.fused_lv, defer_root = plan.defer_root;
     if (tune && !c->hisB) {
         c->capHis = 2 * c->maxR;
         HIPCHK(c, hipMalloc((void **)&c->hisB, (size_t)c->capHis * 4 * sizeof(double)));
         HIPCHK(c, hipMalloc((void **)&c->hisZ, (size_t)c->capHis * sizeof(float)));
     }
-    // The geometry of those three levels is a few dozen elements per stage: by default it runs
-    // inside single-workgroup kernels (az_fused.hip) instead of ~40 tiny launches.
-    // (params.reserved bit 1 keeps the multi-launch form; same bits, for tests.)
-    const bool fused = n_spec && !(p->reserved & 2) && !(p->im_h == c->nofuse_h && p->im_w == c->nofuse_w);
-    // Levels after the speculative ones: one single-workgroup kernel per level (az_level.hip) instead of ten
-    // launches, the final selection folded into the last one (params.reserved bit 4 / AZ_LEVEL_FUSED=0 keep
-    // the multi-launch form; same bits).  Needs one dedup chunk per level (cfg.SEAR.BATCH_SIZE >= regions).
-    if (c->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); c->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
-    const bool fused_lv = fused && nlev > n_spec && !(p->reserved & 16) && c->level_fused_env &&
-                          !(p->im_h == c->nofuse_lv_h && p->im_w == c->nofuse_lv_w);
-    // The root's row (zoom forced, candidates only needed by the final selection) moves from the speculative
-    // pass to the first fused level's head pass: 48 rows = 1.5 strips instead of 49 = 2 for a 600x1000 image
-    // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
-    if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
-    const bool defer_root = fused_lv && n_spec == 3 && nlev >= n_spec + 2 && c->defer_root_env;
     if (!fused) azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);       // also zeroes the counters
     if (fused) {
-        Timed t(c, "spec_prepass", -1);
-        azk_spec_prepass(s, c->cnt, c->B[0], c->B[1], c->child, c->choff_all, c->urois, p->scale, p->min_side,
-                         c->maxR, c->maxCh, p->im_h, p->im_w, defer_root ? 1 : 0);
+        // (the pre-pass -- B1, all children of B1, the rois of the speculative rows -- depends on the image shape
+        //  only: az_propose_launch ran it for this shape, k_spec_levels restores its counters)
     } else if (n_spec) {
         Timed t(c, "spec_geometry", -1);
         // children of the root -> B1 (with _sift_dup), exactly what level 1's divide will produce
@@ -535,14 +578,19 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                    c->choff_all, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
         azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
     }
-    if (n_spec) launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
+    if (fused)
+        launch_head(c, c->spec_U, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 0,
+                    c->spec_urois);
+    else if (n_spec)
+        launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
     if (fused) {
         Timed t(c, "spec_levels", 0);
         AzFusedArgs a;
         a.cnt = c->cnt;
         a.B[0] = c->B[0]; a.B[1] = c->B[1]; a.srcB[0] = c->srcB[0]; a.srcB[1] = c->srcB[1];
         a.index = c->index; a.inv = c->inv; a.zr = c->zr; a.choff = c->choff; a.csrc = c->csrc;
-        a.choff_all = c->choff_all;
+        a.choff_all = c->spec_choff; a.specB1 = c->specB1;
+        a.reset = 1; a.specP1 = c->spc.P1; a.specCH = c->spc.CH; a.specU = c->spc.U;
         a.ubox = c->ubox; a.pred_u = c->pred_u; a.Yall = c->Yall; a.Z = c->Z; a.child = c->child;
         a.zoom_u = c->zoom_u; a.score_u = c->score_u; a.delta_u = c->delta_u; a.Sall = c->Sall;
         a.zoom_s = c->zoom_s; a.score_s = c->score_s; a.delta_s = c->delta_s;
@@ -649,6 +697,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
+    if ((rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     hipStream_t s = c->stream;
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.

@@ -111,6 +111,8 @@ struct AzFusedArgs {
     int *index, *inv, *zr, *choff, *csrc;
     float *rois, *urois;          // (next_dedup) roi projection + dedup of the first level after the fused ones
     int next_dedup, defer_root;
+    const double *specB1;         // the pre-pass's B1 (children of the root after _sift_dup)
+    int reset, specP1, specCH, specU;   // reset: clear the counters here and restore the (cached) pre-pass's
     const int *choff_all;
     double *ubox, *pred_u, *Yall, *Z, *child;
     float *zoom_u, *score_u, *delta_u, *Sall;

@@ -175,13 +175,21 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 #endif
     TSTAMP(tsn++);
 
+    if (a.reset) {
+        // first kernel of the search that touches the counters (the pre-pass of this image shape is cached,
+        // az_capi.hip): clear the previous search's, restore what the pre-pass would have left
+        int *w = reinterpret_cast<int *>(cnt);
+        for (int i = tid; i < (int)(sizeof(AzCounts) / sizeof(int)); i += NTL) w[i] = 0;
+        __syncthreads();
+        if (tid == 0) { cnt->P[0] = 1; cnt->specP1 = a.specP1; cnt->specCH = a.specCH; cnt->specU = a.specU; }
+    }
     if (tid == 0) {                                  // lib/detect/test.py:355
         sB[0][0] = 0.0; sB[0][1] = 0.0; sB[0][2] = a.im_w - 1.0; sB[0][3] = a.im_h - 1.0;
     }
     __syncthreads();
     int P = 1;
     int ybase = 0;
-    const int P1spec = cnt->specP1;
+    const int P1spec = a.reset ? a.specP1 : cnt->specP1;
     int l0 = 0;
     if (a.defer_root) {
         // Level 1 needs no head output here: the root's zoom is forced (test.py:383-384), its candidates arrive
@@ -189,7 +197,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         const bool rz = (1.0 >= a.Tz);                  // zoom[0] = 1, then indZ = where(zoom >= Tz)
         P = rz ? P1spec : 0;
         if (P > FL_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
-        for (int i = tid; i < P * 4; i += NTL) sB[1][i] = a.B[1][i];
+        for (int i = tid; i < P * 4; i += NTL) sB[1][i] = a.specB1[i];
         if (tid == 0) {
             cnt->P[0] = 1; cnt->U[0] = 1; cnt->NC[0] = AZ_NSUB; cnt->ytot[0] = 0; cnt->PZ[0] = rz ? 1 : 0;
             cnt->CH[0] = rz ? div_nchildren(div_plan(sB[0])) : 0;
