@@ -96,6 +96,7 @@ struct az_ctx {
     std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_nlev = 0;
+    int last_defer = 0;
     void *stage_dst = nullptr;          // az_propose_stage_result_dev target of the search in flight
     size_t stage_cap = 0;
     int his_n = 0;                      // rows of the anchor history of the last fetched tuner search
@@ -698,6 +699,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
     if ((rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
+    c->last_defer = plan_search(c, p, nlev, tune).defer_root ? 1 : 0;
     hipStream_t s = c->stream;
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
@@ -802,6 +804,7 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         st->n_levels = nlev;
         st->n_candidates = h.ytot[nlev];
         st->spec_rows = h.specU;
+        st->root_deferred = c->last_defer;
         for (int l = 0; l < nlev; ++l) {
             st->level_regions[l] = h.P[l];
             st->level_unique[l] = h.U[l];

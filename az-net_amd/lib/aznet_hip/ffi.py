@@ -51,7 +51,7 @@ class AzStats(ctypes.Structure):
                 ("level_regions", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("level_unique", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS),
-                ("spec_rows", ctypes.c_int32)]
+                ("spec_rows", ctypes.c_int32), ("root_deferred", ctypes.c_int32)]
 
 
 class AzError(RuntimeError):

@@ -80,6 +80,8 @@ typedef struct {
     int32_t level_zoomed[AZ_MAX_LEVELS];  /* len(indZ)                                   */
     int32_t spec_rows;                    /* rois forwarded by the speculative pass that serves
                                              levels 1-3 in one launch (0: levels ran one by one) */
+    int32_t root_deferred;                /* 1: the root's row rode on level 4's head pass instead
+                                             (spec_rows excludes it, level 4 evaluated one more row) */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
