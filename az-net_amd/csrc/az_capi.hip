@@ -58,6 +58,19 @@ struct az_ctx {
     double *specB1 = nullptr;
     int *spec_choff = nullptr, *spec_U = nullptr;
     struct { int h = -1, w = -1, defer = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc;
+    // Tz <= 0: the whole tree is a function of the image shape (az_static.hip); its rois / anchors / region -> row
+    // map are kept per shape (one entry), the per-level sizes on the host
+    float *sp_urois = nullptr;
+    double *sp_ubox = nullptr;
+    int *sp_reg_u = nullptr, *sp_meta = nullptr;
+    struct {
+        int h = -1, w = -1, nlev = 0, batch = 0, Utot = 0;
+        double scale = 0, min_side = 0, dedup = 0;
+        int roff[AZ_MAX_LEVELS + 1] = {0}, U[AZ_MAX_LEVELS] = {0}, CH[AZ_MAX_LEVELS] = {0};
+    } stp;
+    int nostatic_h = -1, nostatic_w = -1;     // image shape whose tree outgrew the plan buffers
+    int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
+    int last_static = 0;
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
@@ -181,6 +194,7 @@ int ensure_geom(az_ctx *c)
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
     A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
+    A(sp_urois, R * 5); A(sp_ubox, R * 4); A(sp_reg_u, R); A(sp_meta, 4);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -246,7 +260,7 @@ int set_count(az_ctx *c, int *dptr, int v)
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
                  float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0,
-                 const float *urois = nullptr)
+                 const float *urois = nullptr, const double *ubox = nullptr)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
@@ -263,8 +277,8 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     { Timed t(c, "fc7_gemm", level, 1);
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
-      azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, c->ubox, Uptr, c->maxR, im_h, im_w, eps, zoom,
-               score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side); }
+      azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
+               eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -542,6 +556,112 @@ static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
     return AZ_OK;
 }
 
+// Final selection (test.py:392-400): top-k by score, or everything with score >= Tc.
+static void enqueue_select(az_ctx *c, const az_params *p, int nlev, int k)
+{
+    hipStream_t s = c->stream;
+    Timed t(c, "select", nlev);
+    if (p->fixed_num)
+        azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
+                      c->Sall, (double *)((unsigned char *)c->cnt + RES_HDR),
+                      (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32),
+                      (p->reserved & 8) ? nullptr : c->rank_part);
+    else
+        azk_thresh_select_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, p->Tc, c->maxCand, c->sel_idx,
+                               &c->cnt->nsel, c->Yall, c->Sall, c->Yout, c->Sout);
+}
+
+// ---- Tz <= 0: the tree is known before any score is (az_static.hip) -----------------------------------------------
+// (params.reserved bits 0, 1, 2, 4 ask for one of the level-loop forms; bit 5 / AZ_STATIC_TREE=0 turn the plan off)
+static bool static_wanted(az_ctx *c, const az_params *p, bool tune)
+{
+    if (c->static_env < 0) { const char *e = getenv("AZ_STATIC_TREE"); c->static_env = (e && !atoi(e)) ? 0 : 1; }
+    return !tune && p->Tz <= 0.0 && !(p->reserved & (1 | 2 | 16 | 32)) && c->static_env &&
+           !(p->im_h == c->nostatic_h && p->im_w == c->nostatic_w);
+}
+
+static bool static_plan_matches(const az_ctx *c, const az_params *p, int nlev)
+{
+    const auto &k = c->stp;
+    return k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side &&
+           k.dedup == p->dedup && k.batch == p->batch_size && k.nlev == nlev;
+}
+
+// All levels' regions with every region zoomed: the level loop's own geometry kernels (roi projection + dedup,
+// divide_region + _sift_dup), run once per image shape, outside any graph capture.  Rows of the one head pass:
+// levels 2, 3, ... in order, the root last (RoIPool treats the whole-image roi cooperatively).
+static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
+{
+    if (static_plan_matches(c, p, nlev)) return AZ_OK;
+    auto &k = c->stp;
+    hipStream_t s = c->stream;
+    k.h = -1;
+    auto give_up = [&]() { c->nostatic_h = p->im_h; c->nostatic_w = p->im_w; return (int)AZ_OK; };
+    const size_t tmp = (size_t)c->maxR - 1;          // the root's roi / anchor wait here until the row count is known
+    azk_init_root(s, c->cnt, c->B[0], p->im_h, p->im_w);
+    int roff = 0, uoff = 0;
+    for (int l = 0; l < nlev; ++l) {
+        const int cur = l & 1;
+        azk_rois_dedup(s, c->B[cur], &c->cnt->P[l], c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
+                       c->grp, c->first, c->index, c->inv, c->urois, c->ubox, &c->cnt->U[l]);
+        if (l + 1 < nlev) {
+            azk_divide(s, &c->cnt->P[l], &c->cnt->CH[l], &c->cnt->err, c->maxR, c->maxCh, c->B[cur], p->min_side,
+                       c->choff, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
+            azk_dedup_regions(s, c->ckey, &c->cnt->CH[l], c->maxCh, c->maxR, c->first, c->child, c->B[cur ^ 1],
+                              &c->cnt->P[l + 1], &c->cnt->err, nullptr, nullptr);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (c->h_cnt->err) return give_up();
+        const int P = c->h_cnt->P[l], U = c->h_cnt->U[l];
+        if (l == 0) {
+            if (P != 1 || U != 1) return give_up();
+            HIPCHK(c, hipMemcpyAsync(c->sp_urois + tmp * 5, c->urois, 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(c->sp_ubox + tmp * 4, c->ubox, 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        } else if (P > 0) {
+            if ((size_t)uoff + U + 1 > tmp || roff + P > c->maxR) return give_up();
+            HIPCHK(c, hipMemcpyAsync(c->sp_urois + (size_t)uoff * 5, c->urois, (size_t)U * 5 * sizeof(float),
+                                     hipMemcpyDeviceToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(c->sp_ubox + (size_t)uoff * 4, c->ubox, (size_t)U * 4 * sizeof(double),
+                                     hipMemcpyDeviceToDevice, s));
+            azk_plan_rows(s, c->inv, &c->cnt->P[l], c->maxR, roff, uoff, c->sp_reg_u);
+            uoff += U;
+        }
+        k.roff[l] = roff; k.U[l] = U; k.CH[l] = (l + 1 < nlev) ? c->h_cnt->CH[l] : 0;
+        roff += P;
+    }
+    k.roff[nlev] = roff;
+    k.Utot = uoff + 1;
+    HIPCHK(c, hipMemcpyAsync(c->sp_urois + (size_t)uoff * 5, c->sp_urois + tmp * 5, 5 * sizeof(float),
+                             hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->sp_ubox + (size_t)uoff * 4, c->sp_ubox + tmp * 4, 4 * sizeof(double),
+                             hipMemcpyDeviceToDevice, s));
+    const int meta[2] = {k.Utot, uoff};              // rows of the pass; the root's row = reg_u[0]
+    HIPCHK(c, hipMemcpyAsync(c->sp_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->sp_reg_u, &meta[1], sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));              // (meta lives on this frame)
+    k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.dedup = p->dedup;
+    k.batch = p->batch_size; k.nlev = nlev;
+    return AZ_OK;
+}
+
+static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
+{
+    const auto &q = c->stp;
+    launch_head(c, c->sp_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true, 1,
+                c->sp_urois, c->sp_ubox);
+    { Timed t(c, "static_candidates", nlev - 1);
+      AzStaticArgs a;
+      a.cnt = c->cnt; a.reg_u = c->sp_reg_u; a.keep_u = c->keep_u; a.pred_u = c->pred_u; a.score_u = c->score_u;
+      a.zoom_u = c->zoom_u; a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
+      a.nlev = nlev; a.Utot = q.Utot; a.capCand = c->maxCand;
+      for (int l = 0; l <= nlev; ++l) a.roff[l] = q.roff[l];
+      for (int l = 0; l < nlev; ++l) { a.U[l] = q.U[l]; a.CH[l] = q.CH[l]; }
+      azk_static_candidates(c->stream, a); }
+    enqueue_select(c, p, nlev, k);
+    return AZ_OK;
+}
+
 // --------------------------------------------------------------------------------------
 // Everything az_propose enqueues on the ctx stream (no host synchronisation, no host-dependent sizes:
 // every count is read on the device), so the same sequence can also be captured into a hipGraph.
@@ -656,16 +776,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                                 c->srcB[cur ^ 1]); }
         }
     }
-    {
-      Timed t(c, "select", nlev);
-      if (p->fixed_num)
-          azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
-                        c->Sall, (double *)((unsigned char *)c->cnt + RES_HDR),
-                        (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32),
-                        (p->reserved & 8) ? nullptr : c->rank_part);
-      else
-          azk_thresh_select_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, p->Tc, c->maxCand, c->sel_idx,
-                                 &c->cnt->nsel, c->Yall, c->Sall, c->Yout, c->Sout); }
+    enqueue_select(c, p, nlev, k);
     if (tune && c->pool) {
         Timed t(c, "pool_append", nlev);
         azk_pool_append(s, c->hisZ, &c->cnt->nhis, c->capHis, c->pool, c->pool_n, c->pool_cap);
@@ -698,9 +809,16 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
-    if ((rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
-    c->last_defer = plan_search(c, p, nlev, tune).defer_root ? 1 : 0;
+    bool stat = static_wanted(c, p, tune);
+    if (stat) {
+        if ((rc = ensure_static_plan(c, p, nlev)) != AZ_OK) return rc;
+        stat = static_plan_matches(c, p, nlev);          // (a tree that outgrows the plan buffers: level loop)
+    }
+    c->last_static = stat ? 1 : 0;
+    if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
+    c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     hipStream_t s = c->stream;
+    auto enqueue = [&]() { return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
     if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
@@ -720,15 +838,16 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->nofuse_w, sizeof(int));
         key.append((const char *)&c->nofuse_lv_h, sizeof(int));
         key.append((const char *)&c->nofuse_lv_w, sizeof(int));
+        key.append((const char *)&c->last_static, sizeof(int));
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             // (the first search of a shape also runs once un-captured: one-time attribute calls happen there)
-            if ((rc = enqueue_search(c, p, K, nlev, k, tune)) != AZ_OK) return rc;
+            if ((rc = enqueue()) != AZ_OK) return rc;
             HIPCHK(c, hipStreamSynchronize(s));
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
             HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_search(c, p, K, nlev, k, tune);
+            rc = enqueue();
             HIPCHK(c, hipStreamEndCapture(s, &g));
             if (rc) return rc;
             HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -737,7 +856,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         }
         HIPCHK(c, hipGraphLaunch(it->second, s));
     } else {
-        if ((rc = enqueue_search(c, p, K, nlev, k, tune)) != AZ_OK) return rc;
+        if ((rc = enqueue()) != AZ_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
     c->last = *p;
@@ -805,6 +924,7 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         st->n_candidates = h.ytot[nlev];
         st->spec_rows = h.specU;
         st->root_deferred = c->last_defer;
+        st->static_plan = c->last_static;
         for (int l = 0; l < nlev; ++l) {
             st->level_regions[l] = h.P[l];
             st->level_unique[l] = h.U[l];
@@ -812,6 +932,17 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
             st->num_eval += h.P[l];
             if (h.P[l] > 0) st->depth = (c->last.reserved & 4) ? l : l + 1;   // tune.py counts k from 0
         }
+    }
+    if ((h.err & 32) && c->last_static) {
+        // a zoom score of the tree is not >= Tz (NaN): the one-pass plan's premise fails for this image -> level loop
+        az_params p2 = c->last;
+        p2.reserved |= 32;
+        void *sd = c->stage_dst;
+        const size_t sc = c->stage_cap;
+        int rc2 = az_propose_launch(c, &p2);
+        if (rc2) return rc2;
+        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;
+        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
     }
     if ((h.err & 8) && !(c->last.reserved & 2)) {
         // a fused level outgrew its LDS tables: rerun with the multi-launch kernels and remember

@@ -103,6 +103,23 @@ void azk_region_keys(hipStream_t s, const double *regions, const int *Nptr, int 
 void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, const float *scores,
                      int R, int im_h, int im_w, double eps, double *pred_u, float *score_u);
 
+// ---- launchers (az_static.hip): the whole tree in one head pass when the zoom test cannot fail (Tz <= 0) ------
+struct AzStaticArgs {
+    AzCounts *cnt;
+    const int *reg_u;             // row of the head pass that serves each region, regions of all levels level-major
+    const unsigned char *keep_u;  // MIN_SIDE keep flags of the decoded boxes, [row][11] (written by the tail kernel)
+    const double *pred_u;
+    const float *score_u, *zoom_u;
+    double *Yall;
+    float *Sall;
+    double Tz;
+    int nlev, Utot, capCand;
+    int roff[AZ_MAX_LEVELS + 1];  // first region of each level in reg_u; roff[nlev] = regions of the tree
+    int U[AZ_MAX_LEVELS], CH[AZ_MAX_LEVELS];
+};
+void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u);
+void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);
+
 // ---- launchers (az_fused.hip): the first levels inside one workgroup ---------------------
 struct AzFusedArgs {
     AzCounts *cnt;

@@ -119,6 +119,9 @@ def main():
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra images-in-flight measurement")
     ap.add_argument("--no-fast", action="store_true", help="skip the extra split-bf16 (gemm_mode 2) measurement")
+    ap.add_argument("--level-loop", action="store_true",
+                    help="time the level-by-level form of the search (params.reserved bit 5) as the main measurement")
+    ap.add_argument("--no-level-loop", action="store_true", help="skip the extra level-by-level measurement of the same search")
     ap.add_argument("--no-calibrated", action="store_true",
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
@@ -161,7 +164,8 @@ def main():
     convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone().contiguous(memory_format=torch.channels_last) for x in ims]
     conv = convs[0]
     net.set_conv(conv)
-    params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS)
+    params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS,
+                                       static_tree=not args.level_loop)
 
     def barrier():
         if world > 1:
@@ -260,10 +264,11 @@ def main():
         fc6_shapes = []
         for l, v in sorted(fc6.items()):
             rows = spec_rows if l < 0 else uniq[l] + (1 if (st.root_deferred and l == 3) else 0)
+            label = ("all levels (one pass)" if st.static_plan else "speculative 1-3") if l < 0 else l + 1
             t_us = float(np.mean(v)) * 1e3
             fl = rows * 2.0 * 25088 * 4096
             tmin = max(25088 * 4096 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
-            fc6_shapes.append({"level": "speculative 1-3" if l < 0 else l + 1, "rows": int(rows), "avg_us": t_us,
+            fc6_shapes.append({"level": label, "rows": int(rows), "avg_us": t_us,
                                "tflops": fl / t_us / 1e6, "t_min_us": tmin, "frac": tmin / t_us})
         per_level = {}
         for n, l, ms in ktimes:
@@ -275,9 +280,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "VGG16 AZ proposal hot path, 600x1000 image (scale 1.0), batch=1 per GPU, "
-                                   "Tz=%g, regions/level %s, unique RoIs/level %s (levels 1-3 in one %d-row pass%s), top-%d of %d candidates; "
+                                   "Tz=%g, regions/level %s, unique RoIs/level %s (%s), top-%d of %d candidates; "
                                    "conv5_3 %s resident in HBM, %d distinct images rotated" %
-                                   (args.tz, regions, uniq, spec_rows, ", the root's row on level 4's" if st.root_deferred else "",
+                                   (args.tz, regions, uniq,
+                                    ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows)
+                                    if st.static_plan else
+                                    ("levels 1-3 in one %d-row pass%s" % (spec_rows, ", the root's row on level 4's" if st.root_deferred else "")),
                                     NUM_PROPOSALS, st.n_candidates,
                                     [int(x) for x in conv.shape], len(convs)),
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
@@ -291,9 +299,42 @@ def main():
                          "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic,
                          "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes},
             "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
-                           "frac": floor_us / (ms_step * 1e3)},
+                           "frac": floor_us / (ms_step * 1e3),
+                           "note": "t_min = BASELINE.md section 3: sum over the levels of max(bytes / 8 TB/s, flops / 157.3 TF)"
+                                   + ("; with all levels in one head pass the weights stream once, so the floor of the "
+                                      "launches actually made is one_pass_t_min_us" if st.static_plan else ""),
+                           "one_pass_t_min_us": t_min_us([sum(uniq)], int(conv.numel())) if st.static_plan else None},
             "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in sorted(per_level.items())},
         }
+    # ---- the same search walked level by level (what any Tz > 0 does; here with every zoom test passing) ----------
+    if st.static_plan and not args.no_level_loop:
+        pl = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS, static_tree=False)
+        n_l = max(20, args.steps // 2)
+
+        def runl(k):
+            for i in range(k):
+                net.ctx.propose_launch(pl, fmap=convs[i % len(convs)], producer_done=True)
+                net.ctx.propose_fetch(want_scores=True)
+        runl(10)
+        barrier()
+        t0 = time.perf_counter()
+        runl(n_l)
+        barrier()
+        dl = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dl], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dl = float(tt.item())
+        Yl, Sl, stl = net.propose(pl, want_scores=True, want_stats=True)
+        assert np.array_equal(Yl, Y) and np.array_equal(Sl, S), "level loop and one-pass plan disagree"
+        if rank == 0:
+            rows_l = [int(stl.spec_rows)] + [int(stl.level_unique[l]) + (1 if (stl.root_deferred and l == 3) else 0)
+                                             for l in range(3, stl.n_levels)]
+            out["level_loop"] = {"value": world * NUM_PROPOSALS * n_l / dl, "unit": "proposals/s",
+                                 "ms_per_image": dl / n_l * 1e3, "head_passes": len(rows_l), "rows_per_pass": rows_l,
+                                 "note": "same image, same Tz, params.reserved bit 5: the tree walked level by level "
+                                         "(speculative pass for levels 1-3, then one head pass + geometry kernel per level) -- "
+                                         "the form every Tz > 0 search takes; proposals and scores bit-identical to `value`'s"}
     # ---- same work with two images in flight per GPU (two contexts / streams), for context ------
     if not args.no_pipelined and args.inflight == 1:
         NFL = 3                                   # images in flight (2: +7 %, 3: +11 %, 4: no more)

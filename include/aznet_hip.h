@@ -65,7 +65,11 @@ typedef struct {
                                  bit 3: final top-k by the single-workgroup radix select instead of
                                  the chip-wide counting kernels (same result; for tests);
                                  bit 4: keep the geometry of the levels after the speculative ones as
-                                 separate launches instead of one kernel per level (same bits)    */
+                                 separate launches instead of one kernel per level (same bits);
+                                 bit 5: with Tz <= 0 still walk the tree level by level (by default such a
+                                 search -- every finite zoom score passes `zoom >= Tz`, test.py:386, so the
+                                 tree depends on the image shape only -- forwards the rois of ALL levels in
+                                 ONE head pass; same bits)                                          */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
@@ -82,6 +86,8 @@ typedef struct {
                                              levels 1-3 in one launch (0: levels ran one by one) */
     int32_t root_deferred;                /* 1: the root's row rode on level 4's head pass instead
                                              (spec_rows excludes it, level 4 evaluated one more row) */
+    int32_t static_plan;                  /* 1: Tz <= 0, all levels went through one head pass of
+                                             spec_rows rois (params.reserved bit 5 turns this off)  */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */

@@ -91,9 +91,10 @@ def _calibrated_tz(z_all, q):
     raise AssertionError("no gap in the zoom scores")
 
 
-@pytest.mark.parametrize("mode", ["tz0", "calibrated"])
+@pytest.mark.parametrize("mode", ["tz0", "tz0_level_loop", "calibrated"])
 def test_config_a_full_head_vs_pure_cpu_oracle(full, mods, mode):
-    """BASELINE config A (600x1000, full head) through az_propose vs the oracle's whole loop on the CPU."""
+    """BASELINE config A (600x1000, full head) through az_propose vs the oracle's whole loop on the CPU.
+    tz0: all levels in one head pass (the default when Tz <= 0); tz0_level_loop: the same search level by level."""
     ffi, synth, HipAZNet, orc = mods
     net, head, fmap = full
     net.set_conv(fmap)
@@ -106,14 +107,17 @@ def test_config_a_full_head_vs_pure_cpu_oracle(full, mods, mode):
         Tz = _calibrated_tz(np.concatenate([lv["zoom"][1:] if i == 0 else lv["zoom"]
                                             for i, lv in enumerate(tr0["levels"][:3])]), 0.5)
     Yref, tr = orc.im_propose(nets, (H, W), 1.0, orc.OracleCfg(Tz=Tz), return_trace=True)
-    Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz), want_scores=True, want_stats=True)
+    Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz, static_tree=(mode != "tz0_level_loop")),
+                           want_scores=True, want_stats=True)
+    assert st.static_plan == (1 if mode == "tz0" else 0)
+    assert st.spec_rows == (688 if mode == "tz0" else 48)
     # tree: same regions per level, same unique counts, same zoom sets (integer work: exact)
     assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
     for l, lev in enumerate(tr["levels"]):
         assert st.level_regions[l] == lev["B"].shape[0]
         assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"])
         assert st.level_zoomed[l] == len(lev["indZ"])
-    if mode == "tz0":
+    if mode != "calibrated":
         assert [int(st.level_regions[l]) for l in range(5)] == [1, 8, 32, 134, 564]
         assert [int(st.level_unique[l]) for l in range(5)] == [1, 8, 32, 130, 517]
     else:

@@ -351,8 +351,9 @@ def test_speculative_levels_are_bit_identical(small, mods, H, W, tz):
     fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
     net.set_conv(synth.make_feature_map(6, synth.SMALL_DIMS["C"], fh, fw))
     outs = []
-    for spec, fused in ((True, True), (True, False), (False, False)):
-        p = ffi.AzContext.make_params(H, W, scale, tz, speculate=spec, fused=fused)
+    # (with Tz <= 0 the default is the one-pass plan of az_static.hip: the first variant; the others walk the levels)
+    for spec, fused, static in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        p = ffi.AzContext.make_params(H, W, scale, tz, speculate=spec, fused=fused, static_tree=static)
         Y, S, st = net.propose(p, want_scores=True, want_stats=True)
         Ya, Sa = net.ctx.last_candidates()
         outs.append((Y, S, Ya, Sa, list(st.level_regions), list(st.level_unique), list(st.level_zoomed)))
