@@ -62,7 +62,8 @@ struct az_ctx {
     // map are kept per shape (one entry), the per-level sizes on the host
     float *sp_urois = nullptr;
     double *sp_ubox = nullptr;
-    int *sp_reg_u = nullptr, *sp_meta = nullptr;
+    int *sp_reg_u = nullptr, *sp_meta = nullptr, *sp_cand_src = nullptr;
+    unsigned *key_u = nullptr;                // selection keys of the decoded boxes (tail kernel), [row][11]
     struct {
         int h = -1, w = -1, nlev = 0, batch = 0, Utot = 0;
         double scale = 0, min_side = 0, dedup = 0;
@@ -194,7 +195,8 @@ int ensure_geom(az_ctx *c)
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
     A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
-    A(sp_urois, R * 5); A(sp_ubox, R * 4); A(sp_reg_u, R); A(sp_meta, 4);
+    A(sp_urois, R * 5); A(sp_ubox, R * 4); A(sp_reg_u, R); A(sp_meta, 4); A(sp_cand_src, R * AZ_NSUB);
+    A(key_u, R * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -278,7 +280,8 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
       azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
-               eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side); }
+               eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side,
+               (keep_flags && ubox) ? c->key_u : nullptr); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -639,6 +642,7 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
     const int meta[2] = {k.Utot, uoff};              // rows of the pass; the root's row = reg_u[0]
     HIPCHK(c, hipMemcpyAsync(c->sp_meta, meta, sizeof(meta), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(c->sp_reg_u, &meta[1], sizeof(int), hipMemcpyHostToDevice, s));
+    azk_plan_cands(s, c->sp_reg_u, roff, c->sp_cand_src);
     HIPCHK(c, hipStreamSynchronize(s));              // (meta lives on this frame)
     k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.dedup = p->dedup;
     k.batch = p->batch_size; k.nlev = nlev;
@@ -652,11 +656,17 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
                 c->sp_urois, c->sp_ubox);
     { Timed t(c, "static_candidates", nlev - 1);
       AzStaticArgs a;
-      a.cnt = c->cnt; a.reg_u = c->sp_reg_u; a.keep_u = c->keep_u; a.pred_u = c->pred_u; a.score_u = c->score_u;
+      a.cnt = c->cnt; a.reg_u = c->sp_reg_u; a.cand_src = c->sp_cand_src; a.key_u = c->key_u; a.pred_u = c->pred_u;
+      a.score_u = c->score_u;
       a.zoom_u = c->zoom_u; a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
       a.nlev = nlev; a.Utot = q.Utot; a.capCand = c->maxCand;
       for (int l = 0; l <= nlev; ++l) a.roff[l] = q.roff[l];
       for (int l = 0; l < nlev; ++l) { a.U[l] = q.U[l]; a.CH[l] = q.CH[l]; }
+      a.k = k; a.Yout = (double *)((unsigned char *)c->cnt + RES_HDR);
+      a.Sout = (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32);
+      // fixed proposal count: the same launch ranks the candidates and writes the top k (params.reserved bit 3
+      // keeps the separate selection kernels, for tests)
+      if (p->fixed_num && !(p->reserved & 8) && azk_static_select(c->stream, a)) return AZ_OK;
       azk_static_candidates(c->stream, a); }
     enqueue_select(c, p, nlev, k);
     return AZ_OK;

@@ -70,6 +70,13 @@ static __device__ __forceinline__ bool cand_keep(const double *bx, double min_si
     return side >= min_side;
 }
 
+// Order-preserving map float -> uint (ascending): the sort key of the final selection.
+static __device__ __forceinline__ unsigned score_key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 // ---- launchers (az_geom.hip) -----------------------------------------------------------
 void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w);
 void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
@@ -107,18 +114,26 @@ void azk_decode_unit(hipStream_t s, const double *anchors, const float *deltas, 
 struct AzStaticArgs {
     AzCounts *cnt;
     const int *reg_u;             // row of the head pass that serves each region, regions of all levels level-major
-    const unsigned char *keep_u;  // MIN_SIDE keep flags of the decoded boxes, [row][11] (written by the tail kernel)
+    const int *cand_src;          // reg_u[c / 11] * 11 + c % 11 for every candidate slot c (region-major x 11)
+    const unsigned *key_u;        // [row][11]: selection key of the decoded box, 0 = dropped by the MIN_SIDE filter
+                                  // (written by the tail kernel)
     const double *pred_u;
     const float *score_u, *zoom_u;
     double *Yall;
     float *Sall;
     double Tz;
     int nlev, Utot, capCand;
+    int k;                        // (k_static_select) proposals wanted; Yout / Sout = the result block
+    double *Yout;
+    float *Sout;
     int roff[AZ_MAX_LEVELS + 1];  // first region of each level in reg_u; roff[nlev] = regions of the tree
     int U[AZ_MAX_LEVELS], CH[AZ_MAX_LEVELS];
 };
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u);
+void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src);
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);
+// candidates + final top-k in one launch (fixed proposal count); false: the tree is too large for it
+bool azk_static_select(hipStream_t s, const AzStaticArgs &a);
 
 // ---- launchers (az_fused.hip): the first levels inside one workgroup ---------------------
 struct AzFusedArgs {
@@ -203,7 +218,8 @@ void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const in
 // keep_u (may be NULL): per decoded box, the MIN_SIDE filter of _unwrap_adj_pred (test.py:181-185)
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
-              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u = nullptr, double min_side = 0.0);
+              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u = nullptr, double min_side = 0.0,
+              unsigned *key_u = nullptr);
 size_t azk_tail_lds_bytes(int n7);
 size_t azk_tail_weight_rows(int n7);
 int azk_fc_split(int K);

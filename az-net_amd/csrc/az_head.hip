@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(TAIL_WAVES * 64)
 k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float *__restrict__ b7, int n7, int kq,
              const float *__restrict__ WtT, const float *__restrict__ bt, const double *__restrict__ ubox,
              const int *Uptr, int im_h, int im_w, double eps, float *zoom_u, float *score_u, float *delta_u,
-             double *pred_u, unsigned char *keep_u, double min_side)
+             double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u)
 {
     extern __shared__ __attribute__((aligned(16))) float tail_lds[];
     const int KP = TAIL_WAVES * kq;
@@ -858,7 +858,8 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
                 if (t < AZ_NSUB) {
                     // Caffe Sigmoid: 1. / (1. + exp(-x)) -- f32 exp, double divide, f32 store.
                     const float e = expf(-o[t]);
-                    score_u[(size_t)u * AZ_NSUB + t] = (float)(1.0 / (1.0 + (double)e));
+                    const float sc = (float)(1.0 / (1.0 + (double)e));
+                    score_u[(size_t)u * AZ_NSUB + t] = sc;
                     float d4[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -867,7 +868,12 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
                     }
                     double *pb = pred_u + ((size_t)u * AZ_NSUB + t) * 4;
                     az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pb);
-                    if (keep_u) keep_u[(size_t)u * AZ_NSUB + t] = cand_keep(pb, min_side) ? 1 : 0;
+                    if (keep_u) {
+                        const bool kp = cand_keep(pb, min_side);
+                        keep_u[(size_t)u * AZ_NSUB + t] = kp ? 1 : 0;
+                        // selection key of the candidate (az_static.hip): 0 = dropped by the MIN_SIDE filter
+                        if (key_u) { const unsigned kk = score_key(sc); key_u[(size_t)u * AZ_NSUB + t] = kp ? (kk ? kk : 1u) : 0u; }
+                    }
                 } else {
                     const float e = expf(-o[NOUT - 1]);
                     zoom_u[u] = (float)(1.0 / (1.0 + (double)e));
@@ -1016,13 +1022,13 @@ size_t azk_tail_weight_rows(int n7) { return (size_t)TAIL_WAVES * tail_kq(n7) + 
 
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
-              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u, double min_side)
+              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u)
 {
     int grid = (capU + TAIL_ROWS - 1) / TAIL_ROWS;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, part7, S7,
                        (size_t)capU * n7, b7, n7, tail_kq(n7), WtT, bt, ubox, Uptr, im_h, im_w, eps, zoom_u, score_u,
-                       delta_u, pred_u, keep_u, min_side);
+                       delta_u, pred_u, keep_u, min_side, key_u);
 }
 
 void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,

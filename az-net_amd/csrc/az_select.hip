@@ -7,13 +7,6 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned score_key(float f)
-{
-    // order-preserving map float -> uint (ascending)
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
 __device__ int block_excl_scan1024(int v, int *total, int *wsum)
 {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

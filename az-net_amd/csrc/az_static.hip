@@ -24,17 +24,19 @@ __global__ void k_plan_rows(const int *__restrict__ inv, const int *Pptr, int ro
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < P; r += gridDim.x * blockDim.x) reg_u[roff + r] = uoff + inv[r];
 }
 
-constexpr int SC_NT = 1024;
-constexpr int SC_RB = SC_NT / AZ_NSUB;       // regions per workgroup (93 -> 1023 candidates)
-
-__device__ __forceinline__ int keep_count(const unsigned char *__restrict__ keep_u, int u)
+// cand_src[c] = reg_u[c / 11] * 11 + c % 11: where candidate slot c (region-major x 11) finds its decoded box,
+// score and selection key in the head pass's per-row outputs
+__global__ void k_plan_cands(const int *__restrict__ reg_u, int Rtot, int *__restrict__ cand_src)
 {
-    const unsigned char *k = keep_u + (size_t)u * AZ_NSUB;
-    int n = 0;
-#pragma unroll
-    for (int t = 0; t < AZ_NSUB; ++t) n += k[t];
-    return n;
+    const int N = Rtot * AZ_NSUB;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += gridDim.x * blockDim.x) {
+        const int r = c / AZ_NSUB;
+        cand_src[c] = reg_u[r] * AZ_NSUB + (c - r * AZ_NSUB);
+    }
 }
+
+constexpr int SC_NT = 1024;
+constexpr int SC_B = 8;                      // independent loads in flight per thread
 
 __device__ __forceinline__ int block_sum(int v, int *red /* >= 16 ints */)
 {
@@ -48,31 +50,40 @@ __device__ __forceinline__ int block_sum(int v, int *red /* >= 16 ints */)
     return tot;
 }
 
+// keys of slots tid + 1024*(m0 .. m0+7) (0 past the end): 8 + 8 independent loads, two memory round trips
+__device__ __forceinline__ void load_keys8(const AzStaticArgs &a, int Nv, int m0, int tid, unsigned (&key)[SC_B])
+{
+    int src[SC_B];
+#pragma unroll
+    for (int j = 0; j < SC_B; ++j) src[j] = a.cand_src[min((m0 + j) * SC_NT + tid, Nv - 1)];
+#pragma unroll
+    for (int j = 0; j < SC_B; ++j) key[j] = a.key_u[src[j]];
+#pragma unroll
+    for (int j = 0; j < SC_B; ++j) key[j] = ((m0 + j) * SC_NT + tid < Nv) ? key[j] : 0u;
+}
+
 // Candidates of all levels, level-major, region-major, sub-region order (test.py:171-187, 380-381): workgroup b
-// owns regions [b*93, b*93+93); its output offset is the number of kept candidates of all earlier regions, which it
-// counts itself from the keep flags (<= a few thousand bytes, L2-resident) -- no inter-workgroup hand-off.
-// Workgroup 0 also writes every counter of the search and checks the premise.
-__global__ void __launch_bounds__(SC_NT) k_static_candidates(AzStaticArgs a)
+// owns candidate slots [1024 b, 1024 b + 1024); its output offset is the number of kept candidates in all earlier
+// slots, which it counts itself from the keys (a few thousand words, L2-resident) -- no inter-workgroup hand-off.
+__device__ __forceinline__ void copy_role(const AzStaticArgs &a, int bid)
 {
     __shared__ int red[16];
     __shared__ int wsum[17];
-    __shared__ int lev[16][AZ_MAX_LEVELS];
-    __shared__ int sbad;
     const int tid = threadIdx.x;
-    const int Rtot = a.roff[a.nlev];
-    const int r0 = blockIdx.x * SC_RB;
-
+    const int Nv = a.roff[a.nlev] * AZ_NSUB;
     int before = 0;
-    for (int r = tid; r < r0; r += SC_NT) before += keep_count(a.keep_u, a.reg_u[r]);
+    for (int m0 = 0; m0 < bid; m0 += SC_B) {
+        unsigned key[SC_B];
+        load_keys8(a, Nv, m0, tid, key);
+#pragma unroll
+        for (int j = 0; j < SC_B; ++j) before += (m0 + j < bid && key[j] != 0u) ? 1 : 0;
+    }
     const int base = block_sum(before, red);
-
-    const int rl = tid / AZ_NSUB, s = tid - rl * AZ_NSUB;
-    const int r = r0 + rl;
-    int fl = 0;
-    size_t src = 0;
-    if (rl < SC_RB && r < Rtot) {
-        src = (size_t)a.reg_u[r] * AZ_NSUB + s;
-        fl = a.keep_u[src];
+    const int c = bid * SC_NT + tid;
+    int fl = 0, src = 0;
+    if (c < Nv) {
+        src = a.cand_src[c];
+        fl = a.key_u[src] != 0u;
     }
     int tot;
     const int off = block_excl_scan(fl, &tot, wsum);
@@ -80,38 +91,71 @@ __global__ void __launch_bounds__(SC_NT) k_static_candidates(AzStaticArgs a)
         const int dst = base + off;
         if (dst < a.capCand) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a.Yall[(size_t)dst * 4 + k] = a.pred_u[src * 4 + k];
+            for (int k = 0; k < 4; ++k) a.Yall[(size_t)dst * 4 + k] = a.pred_u[(size_t)src * 4 + k];
             a.Sall[dst] = a.score_u[src];
         }
     }
-    if (blockIdx.x != 0) return;
+}
 
-    // ---- workgroup 0: the counters of the whole search --------------------------------------------------------
+// One workgroup writes every counter of the search (nothing else touches AzCounts in this launch) and checks the
+// premise: indZ = where(zoom >= Tz) selects every region (the root is forced, test.py:383-384).
+__device__ __forceinline__ void counters_role(const AzStaticArgs &a, int nsel_k)
+{
+    __shared__ int lev[16][AZ_MAX_LEVELS];
+    __shared__ int sroff[AZ_MAX_LEVELS + 1];
+    __shared__ int snc[AZ_MAX_LEVELS];
+    __shared__ int sbad;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Rtot = a.roff[a.nlev];
+    const int Nv = Rtot * AZ_NSUB;
     if (tid == 0) sbad = 0;
-    const int wave = tid >> 6;
-    for (int l = 0; l < a.nlev; ++l) {
-        int n = 0;
-        for (int q = a.roff[l] + tid; q < a.roff[l + 1]; q += SC_NT) n += keep_count(a.keep_u, a.reg_u[q]);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
-        if (lane_id() == 0) lev[wave][l] = n;
-    }
-    __syncthreads();
-    // the premise: indZ = where(zoom >= Tz) selects every region (the root is forced, test.py:383-384)
+    if (tid <= AZ_MAX_LEVELS) sroff[tid] = tid <= a.nlev ? a.roff[tid] : 0x7fffffff;
+    for (int i = tid; i < 16 * AZ_MAX_LEVELS; i += SC_NT) (&lev[0][0])[i] = 0;
     int bad = 0;
     for (int q = 1 + tid; q < Rtot; q += SC_NT) bad |= !((double)a.zoom_u[a.reg_u[q]] >= a.Tz);
+    __syncthreads();
     if (bad) sbad = 1;
+    // kept candidates per level: a wave's 64 slots are consecutive, so they span levels l(first) .. l(last)
+    auto level_of = [&](int slot) {
+        const int r = slot / AZ_NSUB;
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < AZ_MAX_LEVELS; ++q) l += (r >= sroff[q]) ? 1 : 0;
+        return min(l, a.nlev - 1);
+    };
+    for (int m0 = 0; m0 * SC_NT < Nv; m0 += SC_B) {
+        unsigned key[SC_B];
+        load_keys8(a, Nv, m0, tid, key);
+#pragma unroll
+        for (int j = 0; j < SC_B; ++j) {
+            const int slot = (m0 + j) * SC_NT + tid;
+            const int mine = level_of(min(slot, Nv - 1));
+            const int lo = __builtin_amdgcn_readfirstlane(mine);
+            const int hi = __builtin_amdgcn_readlane(mine, 63);
+            for (int l = lo; l <= hi; ++l) {
+                const int n = __popcll(__ballot(key[j] != 0u && mine == l));
+                if (lane == 0) lev[wave][l] += n;
+            }
+        }
+    }
     int *ci = reinterpret_cast<int *>(a.cnt);
     for (int i = tid; i < (int)(sizeof(AzCounts) / sizeof(int)); i += SC_NT) ci[i] = 0;
+    __syncthreads();
+    if (tid < a.nlev) {
+        int nc = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) nc += lev[w][tid];
+        snc[tid] = nc;
+    }
     __syncthreads();
     if (tid == 0) {
         AzCounts *c = a.cnt;
         int err = sbad ? 32 : 0, y = 0;
         for (int l = 0; l < a.nlev; ++l) {
-            int nc = 0;
-            for (int w = 0; w < 16; ++w) nc += lev[w][l];
+            int nc = snc[l];
             if (y + nc > a.capCand) { nc = a.capCand - y; err |= 2; }
-            c->P[l] = a.roff[l + 1] - a.roff[l];
+            c->P[l] = sroff[l + 1] - sroff[l];
             c->U[l] = a.U[l];
             c->PZ[l] = c->P[l];
             c->CH[l] = a.CH[l];
@@ -122,6 +166,83 @@ __global__ void __launch_bounds__(SC_NT) k_static_candidates(AzStaticArgs a)
         c->ytot[a.nlev] = y;
         c->specU = a.Utot;
         c->err = err;
+        if (nsel_k > 0) c->nsel = nsel_k < y ? nsel_k : y;
+    }
+}
+
+// workgroups [0, nb): candidate writers; workgroup nb: the counters
+__global__ void __launch_bounds__(SC_NT) k_static_candidates(AzStaticArgs a, int nb)
+{
+    if ((int)blockIdx.x < nb) copy_role(a, blockIdx.x);
+    else counters_role(a, 0);
+}
+
+// The same launch also makes the final selection (test.py:396-400: argsort(-aScores)[:k]; ties: lower candidate
+// index first, as az_select.hip).  Workgroups [0, nbC) are the candidate writers, workgroup nbC the counters,
+// workgroup nbC + 1 + g ranks the 32 candidate slots [32g, 32g+32) of the UNCOMPACTED list (a dropped candidate has
+// key 0 and never counts): rank(i) = #{j: key_j > key_i} + #{j < i: key_j == key_i} -- slot order is candidate
+// order, so the ranks are those of az_select.hip's k_rank_count on the compacted list.
+// Wave w of a ranking workgroup holds the w-th sixteenth of all keys in registers, one key per lane and register;
+// for each own slot i the key k_i is a scalar and ONE v_cmp + s_bcnt1 counts 64 keys against it (a ballot).  Keys of
+// 64-slot ranges before the own slots' range are compared as k_j + 1 > k_i (= k_j >= k_i: ties count), later ones
+// as k_j > k_i; the one register that holds the own slots adds its ties among the lower lanes.
+constexpr int SEL_I = 32;                    // own slots per ranking workgroup (255 workgroups for 8129 candidates)
+constexpr int SEL_Q = 8;                     // keys per lane per pass (512 slots per wave per pass)
+
+__global__ void __launch_bounds__(SC_NT) k_static_select(AzStaticArgs a, int nbC)
+{
+    if ((int)blockIdx.x < nbC) { copy_role(a, blockIdx.x); return; }
+    if ((int)blockIdx.x == nbC) { counters_role(a, a.k); return; }
+    __shared__ int part[16][SEL_I];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Nv = a.roff[a.nlev] * AZ_NSUB;
+    const int Np = (Nv + SC_NT - 1) / SC_NT * SC_NT;      // slots, padded (padding keys are 0)
+    const int jl = Np / 16;                               // slots per wave: a multiple of 64
+    const int jb = wave * jl;
+    const int i0 = ((int)blockIdx.x - nbC - 1) * SEL_I;
+    const int ibase = i0 & ~63, ioff = i0 - ibase;        // the 64-slot register range the own slots sit in
+    const int i = i0 + lane;
+    const int isrc = a.cand_src[min(i, Nv - 1)];
+    const unsigned kiv = (lane < SEL_I && i < Nv) ? a.key_u[isrc] : 0u;     // lane l < 32: the key of own slot i0 + l
+    int cntv = 0;                                         // lane l: earlier-sorting candidates found by this wave
+    for (int p0 = 0; p0 < jl; p0 += SEL_Q * 64) {
+        int src[SEL_Q];
+        unsigned key[SEL_Q];
+#pragma unroll
+        for (int q = 0; q < SEL_Q; ++q) src[q] = a.cand_src[min(jb + p0 + q * 64 + lane, Nv - 1)];
+#pragma unroll
+        for (int q = 0; q < SEL_Q; ++q) key[q] = a.key_u[src[q]];
+        unsigned long long own = 0;                       // (wave-uniform) ballot source of the register that is the own slots
+        unsigned kown = 0;
+#pragma unroll
+        for (int q = 0; q < SEL_Q; ++q) {
+            const int jq = jb + p0 + q * 64;              // wave-uniform
+            const bool live = jq < jl + jb && jq + lane < Nv;
+            key[q] = live ? key[q] : 0u;
+            if (jq == ibase) { kown = key[q]; own = 1; }
+            else if (jq < ibase) key[q] = key[q] == 0xFFFFFFFFu ? key[q] : key[q] + (key[q] ? 1u : 0u);
+        }
+        for (int ii = 0; ii < SEL_I; ++ii) {
+            const unsigned ki = __builtin_amdgcn_readlane(kiv, ii);
+            int n = 0;
+#pragma unroll
+            for (int q = 0; q < SEL_Q; ++q) n += __popcll(__ballot(key[q] > ki));
+            if (own) n += __popcll(__ballot(kown == ki) & ((1ull << (ii + ioff)) - 1ull));
+            cntv += (lane == ii) ? n : 0;
+        }
+    }
+    if (lane < SEL_I) part[wave][lane] = cntv;
+    __syncthreads();
+    if (wave == 0 && lane < SEL_I && kiv != 0u) {
+        int rank = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) rank += part[w][lane];
+        if (rank < a.k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.Yout[(size_t)rank * 4 + q] = a.pred_u[(size_t)isrc * 4 + q];
+            a.Sout[rank] = a.score_u[isrc];
+        }
     }
 }
 
@@ -132,9 +253,25 @@ void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int
     k_plan_rows<<<dim3((capR + 255) / 256 > 64 ? 64 : (capR + 255) / 256), dim3(256), 0, s>>>(inv, Pptr, roff, uoff, reg_u);
 }
 
+bool azk_static_select(hipStream_t s, const AzStaticArgs &a)
+{
+    const int Nv = a.roff[a.nlev] * AZ_NSUB;
+    if (a.k <= 0 || Nv <= 0) return false;
+    const int nbC = (Nv + SC_NT - 1) / SC_NT;
+    const int nbR = (Nv + SEL_I - 1) / SEL_I;
+    k_static_select<<<dim3(nbC + 1 + nbR), dim3(SC_NT), 0, s>>>(a, nbC);
+    return true;
+}
+
+void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src)
+{
+    const int nb = (Rtot * AZ_NSUB + 255) / 256;
+    k_plan_cands<<<dim3(nb > 256 ? 256 : (nb > 0 ? nb : 1)), dim3(256), 0, s>>>(reg_u, Rtot, cand_src);
+}
+
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a)
 {
-    const int Rtot = a.roff[a.nlev];
-    const int nb = (Rtot + SC_RB - 1) / SC_RB;
-    k_static_candidates<<<dim3(nb > 0 ? nb : 1), dim3(SC_NT), 0, s>>>(a);
+    const int Nv = a.roff[a.nlev] * AZ_NSUB;
+    const int nb = (Nv + SC_NT - 1) / SC_NT;
+    k_static_candidates<<<dim3(nb + 1), dim3(SC_NT), 0, s>>>(a, nb);
 }

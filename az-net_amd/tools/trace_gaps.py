@@ -15,7 +15,7 @@ def short(n):
 def main():
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(sys.argv[1]))]
     rows.sort()
-    first = sys.argv[2] if len(sys.argv) > 2 else "k_nchw_to_nhwc"
+    first = sys.argv[2] if len(sys.argv) > 2 else "k_rank_count"      # once per search (final selection)
     # keep the steady-state tail: last 60 % of the trace
     rows = rows[int(len(rows) * 0.4):]
     gaps = collections.defaultdict(list)
