@@ -72,6 +72,7 @@ struct az_ctx {
     int nostatic_h = -1, nostatic_w = -1;     // image shape whose tree outgrew the plan buffers
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
+    int gemm12_min_rows = 257;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN)
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
@@ -262,7 +263,7 @@ int set_count(az_ctx *c, int *dptr, int v)
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
                  float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0,
-                 const float *urois = nullptr, const double *ubox = nullptr)
+                 const float *urois = nullptr, const double *ubox = nullptr, int rows_hint = 0)
 {
     const AzHeadDims &d = c->d;
     { Timed t(c, "roi_pool", level);
@@ -272,6 +273,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       if (c->gemm_parts)
           azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
                            c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part);
+      else if (rows_hint >= c->gemm12_min_rows && (d.n6 / 128) * c->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
+               azk_fc_chunk(d.K6, c->S6) * c->S6 == d.K6 && azk_fc_chunk(d.K6, c->S6) >= 64)
+          // the caller knows the row count on the host (a one-pass plan): many rows -> one weight tile per 12 strips
+          azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
+                        azk_fc_chunk(d.K6, c->S6), c->part);
       else
           azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part); }
     { Timed t(c, "fc6_reduce", level);
@@ -578,7 +584,11 @@ static void enqueue_select(az_ctx *c, const az_params *p, int nlev, int k)
 // (params.reserved bits 0, 1, 2, 4 ask for one of the level-loop forms; bit 5 / AZ_STATIC_TREE=0 turn the plan off)
 static bool static_wanted(az_ctx *c, const az_params *p, bool tune)
 {
-    if (c->static_env < 0) { const char *e = getenv("AZ_STATIC_TREE"); c->static_env = (e && !atoi(e)) ? 0 : 1; }
+    if (c->static_env < 0) {
+        const char *e = getenv("AZ_STATIC_TREE"), *f = getenv("AZ_GEMM12_MIN");
+        c->static_env = (e && !atoi(e)) ? 0 : 1;
+        if (f) c->gemm12_min_rows = atoi(f) > 0 ? atoi(f) : 0x7fffffff;
+    }
     return !tune && p->Tz <= 0.0 && !(p->reserved & (1 | 2 | 16 | 32)) && c->static_env &&
            !(p->im_h == c->nostatic_h && p->im_w == c->nostatic_w);
 }
@@ -653,7 +663,7 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 {
     const auto &q = c->stp;
     launch_head(c, c->sp_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true, 1,
-                c->sp_urois, c->sp_ubox);
+                c->sp_urois, c->sp_ubox, q.Utot);
     { Timed t(c, "static_candidates", nlev - 1);
       AzStaticArgs a;
       a.cnt = c->cnt; a.reg_u = c->sp_reg_u; a.cand_src = c->sp_cand_src; a.key_u = c->key_u; a.pred_u = c->pred_u;
@@ -1145,7 +1155,8 @@ int az_head_forward(az_ctx *c, const float *rois, int R, float *zoom_prob, float
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!(c->profiling & 4)) clear_events(c);
-    launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0, c->zoom_u, c->score_u, c->delta_u);
+    // (the row count is known on the host here: many rows take the many-row GEMM, as a one-pass search does)
+    launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0, c->zoom_u, c->score_u, c->delta_u, 0.0, false, 0, nullptr, nullptr, R);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (R && zoom_prob) HIPCHK(c, hipMemcpy(zoom_prob, c->zoom_u, (size_t)R * 4, hipMemcpyDeviceToHost));

@@ -151,3 +151,21 @@ def test_static_plan_with_graphs_and_staged_result(small, mods):
             assert np.array_equal(Y0, Y1) and np.array_equal(S0, S1)
     finally:
         net.ctx.set_graphs(False)
+
+
+def test_full_head_one_pass_bits_equal_level_loop(mods):
+    """Config A at the full head: the one-pass search (int6 through the 12-wave many-row GEMM of az_head12.hip) and the
+    level loop (k_fc_splitk at 48 / 131 / 517 rows) give the same bits -- proposals, scores, all 8129 candidates."""
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+    net = HipAZNet(head, name="full", max_regions=4096)
+    net.set_conv(synth.make_feature_map(4, 512, 38, 63))
+    a, b = _both(net, ffi, 600, 1000, 1.0, 0.0)
+    assert a["st"].static_plan == 1 and a["st"].spec_rows == 688 and b["st"].static_plan == 0
+    assert a["Ya"].shape[0] > 8000
+    _same(a, b)
+    # ... and at BASELINE config 4's tree (2672 rois in one pass)
+    net.set_conv(synth.make_feature_map(5, 512, 38, 57))
+    a, b = _both(net, ffi, 800, 1200, 0.75, 0.0)
+    assert a["st"].static_plan == 1 and b["st"].static_plan == 0
+    _same(a, b)
