@@ -11,9 +11,14 @@
 // fixed K chunks in the same k order (0,4,1,5,2,6,3,7 inside each 8-wide group), one slab per chunk -- a row's bits
 // do not depend on which kernel (or which m-tile) computed it (tests/test_gpu_parity.py).
 // Per K-step and wave: 4 k-groups x (<= 4 strips x 4) MFMAs; fragments of the next k-group are read while the current
-// group's MFMAs run (two fragment sets); the next K-step's tile is requested at the start of the step (one register
-// set: three waves per SIMD hide the HBM latency), written to the other LDS buffer during the third k-group, and
-// the one barrier of the step sits before the fourth, whose MFMAs are already queued with operands in registers.
+// group's MFMAs run (two fragment sets); tiles are requested two K-steps ahead with ONE register set (freed when its
+// tile goes to LDS during the third k-group, re-used for the request right behind the step's one barrier, which sits
+// before the fourth k-group, whose operands are already in registers); work items are chained through LDS (the
+// last steps of an item fetch the next item's first tile).
+// Measured at 688 rows (config A, one pass): 1009-1019 us against 1022-1035 for k_fc_splitk on the same boxes, matrix
+// pipe 90 % busy, FETCH_SIZE x 2 + WRITE_SIZE = 1.13 GB per launch against 2.79 GB; no LDS bank conflicts.
+// Tried here and dropped: the 16x16x4 half strip for the last <= 16 rows (bit-identical, +10 us: its row group drifts
+// from the other two), s_setprio around the MFMA groups, either way (+60 us).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "az_dev.h"
@@ -60,9 +65,7 @@ struct Item12 {
 // of a tile nobody reads) and stages it in the LDS buffer that step leaves free, so the next item starts with its
 // operands already in LDS[pb] (`preloaded`) -- with one workgroup per CU nothing else would cover that latency.
 // Returns the buffer holding the next item's first tile.
-// (Rows past the last full strip are a padded strip here: the 16x16x4 half strip of az_head.hip was measured in this
-//  kernel too -- bit-identical, but 1036 us against 1026 at 688 rows: the row group that carries it drifts from the
-//  other two.)
+// (Rows past the last full strip are a padded strip here.)
 template <int NRT>
 __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                       int M, int N, const Item12 &it, int my0, const Item12 &nx, bool has_next,

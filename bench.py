@@ -291,7 +291,10 @@ def main():
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
                        "gather": ("RCCL all_gather every %d images/rank" % args.gather_every) if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "k_fc_splitk (int6, int7_1|int7_2; v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("k_fc_splitk12 (int6, many-row tiles) + k_fc_splitk (int7_1|int7_2); v_mfma_f32_32x32x2_f32"
+                                    if (st.static_plan and spec_rows >= 257) else
+                                    "k_fc_splitk (int6, int7_1|int7_2; v_mfma_f32_32x32x2_f32)"),
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": flops_per_image / (n_launch / max(args.steps, 1)),
