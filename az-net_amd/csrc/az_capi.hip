@@ -72,6 +72,7 @@ struct az_ctx {
     int nostatic_h = -1, nostatic_w = -1;     // image shape whose tree outgrew the plan buffers
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
+    int gemm12_env = -1;
     int gemm12_min_rows = 257;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN)
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
@@ -266,6 +267,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
                  const float *urois = nullptr, const double *ubox = nullptr, int rows_hint = 0)
 {
     const AzHeadDims &d = c->d;
+    if (c->gemm12_env < 0) {            // AZ_GEMM12_MIN=<rows> (0: never): measurements
+        const char *f = getenv("AZ_GEMM12_MIN");
+        if (f) c->gemm12_min_rows = atoi(f) > 0 ? atoi(f) : 0x7fffffff;
+        c->gemm12_env = 1;
+    }
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
                    (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail); }
@@ -584,11 +590,7 @@ static void enqueue_select(az_ctx *c, const az_params *p, int nlev, int k)
 // (params.reserved bits 0, 1, 2, 4 ask for one of the level-loop forms; bit 5 / AZ_STATIC_TREE=0 turn the plan off)
 static bool static_wanted(az_ctx *c, const az_params *p, bool tune)
 {
-    if (c->static_env < 0) {
-        const char *e = getenv("AZ_STATIC_TREE"), *f = getenv("AZ_GEMM12_MIN");
-        c->static_env = (e && !atoi(e)) ? 0 : 1;
-        if (f) c->gemm12_min_rows = atoi(f) > 0 ? atoi(f) : 0x7fffffff;
-    }
+    if (c->static_env < 0) { const char *e = getenv("AZ_STATIC_TREE"); c->static_env = (e && !atoi(e)) ? 0 : 1; }
     return !tune && p->Tz <= 0.0 && !(p->reserved & (1 | 2 | 16 | 32)) && c->static_env &&
            !(p->im_h == c->nostatic_h && p->im_w == c->nostatic_w);
 }
