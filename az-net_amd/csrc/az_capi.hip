@@ -59,19 +59,26 @@ struct az_ctx {
     int *spec_choff = nullptr, *spec_U = nullptr;
     struct { int h = -1, w = -1, defer = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc;
     // Tz <= 0: the whole tree is a function of the image shape (az_static.hip); its rois / anchors / region -> row
-    // map are kept per shape (one entry), the per-level sizes on the host
-    float *sp_urois = nullptr;
-    double *sp_ubox = nullptr;
-    int *sp_reg_u = nullptr, *sp_meta = nullptr, *sp_cand_src = nullptr;
-    unsigned *key_u = nullptr;                // selection keys of the decoded boxes (tail kernel), [row][11]
-    struct {
+    // map are kept per shape in exact-size HBM buffers (~100 B per roi: 70 KB for a 600x1000 image), least recently
+    // used shapes are dropped beyond AZ_PLAN_CACHE entries; the per-level sizes stay on the host
+    struct StaticPlan {
         int h = -1, w = -1, nlev = 0, batch = 0, Utot = 0, coop = 1;
         double scale = 0, min_side = 0, dedup = 0;
         int roff[AZ_MAX_LEVELS + 1] = {0}, U[AZ_MAX_LEVELS] = {0}, CH[AZ_MAX_LEVELS] = {0};
-    } stp;
+        float *urois = nullptr;
+        double *ubox = nullptr;
+        int *reg_u = nullptr, *cand_src = nullptr, *meta = nullptr;
+        unsigned long long last_use = 0;
+    };
+    std::vector<StaticPlan *> plans;
+    StaticPlan *plan = nullptr;               // the plan of the search being launched / in flight
+    unsigned long long plan_clock = 0;
+    int plan_cache_max = 64;
+    unsigned *key_u = nullptr;                // selection keys of the decoded boxes (tail kernel), [row][11]
     int nostatic_h = -1, nostatic_w = -1;     // image shape whose tree outgrew the plan buffers
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
+    int final_env = 1;                        // AZ_FINAL_FUSED=0: separate candidate / selection kernels at the last level
     int gemm12_env = -1;
     int gemm12_min_rows = 257;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN)
     // Fast R-CNN head on the shared map (az_load_det_head)
@@ -197,7 +204,6 @@ int ensure_geom(az_ctx *c)
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
     A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
-    A(sp_urois, R * 5); A(sp_ubox, R * 4); A(sp_reg_u, R); A(sp_meta, 4); A(sp_cand_src, R * AZ_NSUB);
     A(key_u, R * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
@@ -264,7 +270,7 @@ int set_count(az_ctx *c, int *dptr, int v)
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
                  float *delta, double min_side = 0.0, bool keep_flags = false, int coop_tail = 0,
-                 const float *urois = nullptr, const double *ubox = nullptr, int rows_hint = 0)
+                 const float *urois = nullptr, const double *ubox = nullptr, int rows_hint = 0, bool keys = false)
 {
     const AzHeadDims &d = c->d;
     if (c->gemm12_env < 0) {            // AZ_GEMM12_MIN=<rows> (0: never): measurements
@@ -293,7 +299,7 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
       azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
                eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side,
-               (keep_flags && ubox) ? c->key_u : nullptr); }
+               (keep_flags && keys) ? c->key_u : nullptr); }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -308,6 +314,13 @@ int ev_grow(az_ctx *c, int i, void **slot, size_t bytes)
     if (e != hipSuccess) return fail(c, AZ_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     c->ev_sz[i] = want;
     return AZ_OK;
+}
+
+void free_plan(az_ctx::StaticPlan *q)
+{
+    for (void *p : {(void *)q->urois, (void *)q->ubox, (void *)q->reg_u, (void *)q->cand_src, (void *)q->meta})
+        if (p) hipFree(p);
+    q->urois = nullptr; q->ubox = nullptr; q->reg_u = nullptr; q->cand_src = nullptr; q->meta = nullptr;
 }
 
 int check_geom(az_ctx *c)
@@ -362,6 +375,8 @@ int az_destroy(az_ctx *c)
     c->allocs_geom.clear();
     for (void *p : c->allocs_det) hipFree(p);
     c->allocs_det.clear();
+    for (auto *q : c->plans) { free_plan(q); delete q; }
+    c->plans.clear();
     if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
     for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
                     (void *)c->hisZ, (void *)c->pool, (void *)c->pool_tmp, (void *)c->pool_n, (void *)c->pool_hist})
@@ -590,27 +605,37 @@ static void enqueue_select(az_ctx *c, const az_params *p, int nlev, int k)
 // (params.reserved bits 0, 1, 2, 4 ask for one of the level-loop forms; bit 5 / AZ_STATIC_TREE=0 turn the plan off)
 static bool static_wanted(az_ctx *c, const az_params *p, bool tune)
 {
-    if (c->static_env < 0) { const char *e = getenv("AZ_STATIC_TREE"); c->static_env = (e && !atoi(e)) ? 0 : 1; }
+    if (c->static_env < 0) {
+        const char *e = getenv("AZ_STATIC_TREE"), *f = getenv("AZ_FINAL_FUSED"), *g = getenv("AZ_PLAN_CACHE");
+        c->static_env = (e && !atoi(e)) ? 0 : 1;
+        c->final_env = (f && !atoi(f)) ? 0 : 1;
+        if (g && atoi(g) > 0) c->plan_cache_max = atoi(g);
+    }
     return !tune && p->Tz <= 0.0 && !(p->reserved & (1 | 2 | 16 | 32)) && c->static_env &&
            !(p->im_h == c->nostatic_h && p->im_w == c->nostatic_w);
 }
 
-static bool static_plan_matches(const az_ctx *c, const az_params *p, int nlev)
+static bool plan_is_for(const az_ctx::StaticPlan &k, const az_params *p, int nlev)
 {
-    const auto &k = c->stp;
     return k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side &&
            k.dedup == p->dedup && k.batch == p->batch_size && k.nlev == nlev;
+}
+
+static bool static_plan_matches(const az_ctx *c, const az_params *p, int nlev)
+{
+    return c->plan && plan_is_for(*c->plan, p, nlev);
 }
 
 // All levels' regions with every region zoomed: the level loop's own geometry kernels (roi projection + dedup,
 // divide_region + _sift_dup), run once per image shape, outside any graph capture.
 static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
 {
-    if (static_plan_matches(c, p, nlev)) return AZ_OK;
-    auto &k = c->stp;
+    for (auto *q : c->plans)
+        if (plan_is_for(*q, p, nlev)) { c->plan = q; q->last_use = ++c->plan_clock; return AZ_OK; }
+    c->plan = nullptr;
     hipStream_t s = c->stream;
-    k.h = -1;
     auto give_up = [&]() { c->nostatic_h = p->im_h; c->nostatic_w = p->im_w; return (int)AZ_OK; };
+    az_ctx::StaticPlan k;
     // Two passes over the tree: sizes first, then placement.  Rows of the one head pass: levels 2, 3, ... in order, the
     // root last (RoIPool treats that one whole-image roi cooperatively: a workgroup per bin instead of a wave.
     // Deepest level first with levels 1-3 cooperative was measured too: 26.2 us against 24.5).
@@ -639,11 +664,11 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
             } else {
                 const int P = k.roff[l + 1] - k.roff[l], U = k.U[l];
                 if (P > 0) {
-                    HIPCHK(c, hipMemcpyAsync(c->sp_urois + (size_t)uoff[l] * 5, c->urois, (size_t)U * 5 * sizeof(float),
+                    HIPCHK(c, hipMemcpyAsync(k.urois + (size_t)uoff[l] * 5, c->urois, (size_t)U * 5 * sizeof(float),
                                              hipMemcpyDeviceToDevice, s));
-                    HIPCHK(c, hipMemcpyAsync(c->sp_ubox + (size_t)uoff[l] * 4, c->ubox, (size_t)U * 4 * sizeof(double),
+                    HIPCHK(c, hipMemcpyAsync(k.ubox + (size_t)uoff[l] * 4, c->ubox, (size_t)U * 4 * sizeof(double),
                                              hipMemcpyDeviceToDevice, s));
-                    azk_plan_rows(s, c->inv, &c->cnt->P[l], c->maxR, k.roff[l], uoff[l], c->sp_reg_u);
+                    azk_plan_rows(s, c->inv, &c->cnt->P[l], c->maxR, k.roff[l], uoff[l], k.reg_u);
                 }
             }
         }
@@ -655,24 +680,49 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
             k.Utot = tot + 1;
             if (k.Utot > c->maxR || roff > c->maxR) return give_up();
             k.coop = 1;
+            // exact-size buffers of this shape's plan
+            auto grab = [&](void **q, size_t bytes) { return hipMalloc(q, bytes + 256) == hipSuccess; };
+            if (!grab((void **)&k.urois, (size_t)k.Utot * 5 * sizeof(float)) ||
+                !grab((void **)&k.ubox, (size_t)k.Utot * 4 * sizeof(double)) ||
+                !grab((void **)&k.reg_u, (size_t)roff * sizeof(int)) ||
+                !grab((void **)&k.cand_src, (size_t)roff * AZ_NSUB * sizeof(int)) || !grab((void **)&k.meta, 16)) {
+                free_plan(&k);
+                return fail(c, AZ_ERR_HIP, "hipMalloc failed for a static plan");
+            }
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->sp_meta, &k.Utot, sizeof(int), hipMemcpyHostToDevice, s));
-    azk_plan_cands(s, c->sp_reg_u, k.roff[nlev], c->sp_cand_src);
-    HIPCHK(c, hipStreamSynchronize(s));
+    if (hipMemcpyAsync(k.meta, &k.Utot, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
+        (azk_plan_cands(s, k.reg_u, k.roff[nlev], k.cand_src), hipStreamSynchronize(s)) != hipSuccess) {
+        free_plan(&k);
+        return fail(c, AZ_ERR_HIP, "static plan: copy failed");
+    }
     k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.dedup = p->dedup;
     k.batch = p->batch_size; k.nlev = nlev;
+    k.last_use = ++c->plan_clock;
+    if (c->plan_cache_max < 1) c->plan_cache_max = 1;
+    if ((int)c->plans.size() >= c->plan_cache_max) {
+        // drop the least recently used shape; captured launch sequences may hold its pointers: drop those too
+        size_t lru = 0;
+        for (size_t i = 1; i < c->plans.size(); ++i) if (c->plans[i]->last_use < c->plans[lru]->last_use) lru = i;
+        for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+        c->graphs.clear();
+        free_plan(c->plans[lru]);
+        delete c->plans[lru];
+        c->plans.erase(c->plans.begin() + (long)lru);
+    }
+    c->plans.push_back(new az_ctx::StaticPlan(k));
+    c->plan = c->plans.back();
     return AZ_OK;
 }
 
 static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 {
-    const auto &q = c->stp;
-    launch_head(c, c->sp_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true,
-                q.coop, c->sp_urois, c->sp_ubox, q.Utot);
+    const auto &q = *c->plan;
+    launch_head(c, q.meta, -1, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, true,
+                q.coop, q.urois, q.ubox, q.Utot, true);
     { Timed t(c, "static_candidates", nlev - 1);
       AzStaticArgs a;
-      a.cnt = c->cnt; a.reg_u = c->sp_reg_u; a.cand_src = c->sp_cand_src; a.key_u = c->key_u; a.pred_u = c->pred_u;
+      a.cnt = c->cnt; a.reg_u = q.reg_u; a.cand_src = q.cand_src; a.key_u = c->key_u; a.pred_u = c->pred_u;
       a.score_u = c->score_u;
       a.zoom_u = c->zoom_u; a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
       a.nlev = nlev; a.Utot = q.Utot; a.capCand = c->maxCand;
@@ -774,12 +824,30 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
           Timed t(c, "rois_dedup", l);
           azk_rois_dedup(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
                          c->grp, c->first, c->index, c->inv, c->urois, c->ubox, Uptr); }
+        // The last level of a default search with a fixed proposal count: its candidates, its counters and the final
+        // top-k come from ONE launch (az_static.hip: k_final_select) instead of k_flags, k_compact, k_rank_count and
+        // k_rank_scatter; the tail kernel emits the selection keys.  (params.reserved bits 1 / 3 keep the separate
+        // kernels: same bits.)
+        const bool final_fused = fused && !tune && l + 1 == nlev && l >= n_spec && p->fixed_num && !(p->reserved & 8) &&
+                                 c->final_env;
         if (l < n_spec) {
             Timed t(c, "spec_lookup", l);
             azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
                             p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
         } else {
-            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u);
+            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, final_fused,
+                        0, nullptr, nullptr, 0, final_fused);
+        }
+        if (final_fused) {
+            Timed t(c, "final_select", l);
+            AzFinalArgs a;
+            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = c->key_u; a.pred_u = c->pred_u;
+            a.score_u = c->score_u; a.zoom_u = c->zoom_u; a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
+            a.force_root = (l == 0) ? 1 : 0; a.capCand = c->maxCand; a.k = k;
+            a.Yout = (double *)((unsigned char *)c->cnt + RES_HDR);
+            a.Sout = (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32);
+            azk_final_select(s, a);
+            return AZ_OK;
         }
         if (tune) {
             Timed t(c, "record_anchors", l);
@@ -865,6 +933,8 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->nofuse_lv_h, sizeof(int));
         key.append((const char *)&c->nofuse_lv_w, sizeof(int));
         key.append((const char *)&c->last_static, sizeof(int));
+        const void *pp = stat ? (const void *)c->plan : nullptr;
+        key.append((const char *)&pp, sizeof(pp));
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             // (the first search of a shape also runs once un-captured: one-time attribute calls happen there)

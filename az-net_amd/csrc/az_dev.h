@@ -129,6 +129,23 @@ struct AzStaticArgs {
     int roff[AZ_MAX_LEVELS + 1];  // first region of each level in reg_u; roff[nlev] = regions of the tree
     int U[AZ_MAX_LEVELS], CH[AZ_MAX_LEVELS];
 };
+// The level loop's last level (fixed proposal count): append its kept candidates, write its counters and make the final
+// top-k in ONE launch (instead of k_flags, k_compact, k_rank_count, k_rank_scatter).
+struct AzFinalArgs {
+    AzCounts *cnt;
+    int level;                    // the last level
+    const int *inv;               // region -> unique row of that level
+    const unsigned *key_u;        // selection keys of the level's decoded boxes (tail kernel), 0 = dropped
+    const double *pred_u;
+    const float *score_u, *zoom_u;
+    double *Yall;                 // candidates of the earlier levels, [0, ytot[level])
+    float *Sall;
+    double Tz;
+    int force_root, capCand, k;
+    double *Yout;
+    float *Sout;
+};
+void azk_final_select(hipStream_t s, const AzFinalArgs &a);
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u);
 void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src);
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);

@@ -246,6 +246,135 @@ __global__ void __launch_bounds__(SC_NT) k_static_select(AzStaticArgs a, int nbC
     }
 }
 
+// ---- the level loop's last level: candidates + counters + top-k in one launch -------------------------------------
+// The list to rank is [candidates of the earlier levels, already in Yall / Sall] ++ [the last level's 11 P slots,
+// found through inv]; list order is candidate order.  Roles as in k_static_select; all sizes are read on the device: a
+// fixed grid whose workgroups take turns (48 writers, 512 rankers: one turn each up to 16 384 candidates).
+__device__ __forceinline__ unsigned final_key(const AzFinalArgs &a, int prev, int Ns, int j)
+{
+    if (j < prev) { const unsigned k = score_key(a.Sall[j]); return k ? k : 1u; }
+    const int c = j - prev;
+    if (c >= Ns) return 0u;
+    const int r = c / AZ_NSUB;
+    return a.key_u[(size_t)a.inv[r] * AZ_NSUB + (c - r * AZ_NSUB)];
+}
+
+constexpr int FIN_NBC = 48;        // writer workgroups (1024 slots each per turn)
+constexpr int FIN_NBR = 512;       // ranking workgroups (32 slots each per turn)
+
+__global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
+{
+    constexpr int nbC = FIN_NBC;
+    __shared__ int red[16];
+    __shared__ int wsum[17];
+    __shared__ int part[16][SEL_I];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.cnt->P[a.level], prev = a.cnt->ytot[a.level];
+    const int Ns = P * AZ_NSUB, Nv = prev + Ns;
+    if ((int)blockIdx.x < nbC) {
+        // ---- writers: the last level's kept candidates go behind the earlier levels' (test.py:380-381)
+        for (int bid = blockIdx.x; bid * SC_NT < Ns; bid += nbC) {
+            int before = 0;
+            for (int c = tid; c < bid * SC_NT; c += SC_NT) before += final_key(a, 0, Ns, c) != 0u;
+            const int base = block_sum(before, red);
+            const int c = bid * SC_NT + tid;
+            int fl = 0, src = 0;
+            if (c < Ns) {
+                const int r = c / AZ_NSUB;
+                src = a.inv[r] * AZ_NSUB + (c - r * AZ_NSUB);
+                fl = a.key_u[src] != 0u;
+            }
+            int tot;
+            const int off = block_excl_scan(fl, &tot, wsum);
+            if (fl) {
+                const int dst = prev + base + off;
+                if (dst < a.capCand) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = a.pred_u[(size_t)src * 4 + q];
+                    a.Sall[dst] = a.score_u[src];
+                }
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x == nbC) {
+        // ---- the level's counters (test.py:383-387: zoom[0] = 1 at level 1; indZ = where(zoom >= Tz))
+        int kept = 0, zoomed = 0;
+        for (int c = tid; c < Ns; c += SC_NT) kept += final_key(a, 0, Ns, c) != 0u;
+        for (int r = tid; r < P; r += SC_NT) {
+            float z = a.zoom_u[a.inv[r]];
+            if (a.force_root && r == 0) z = 1.0f;
+            zoomed += ((double)z >= a.Tz) ? 1 : 0;
+        }
+        const int nc_all = block_sum(kept, red);
+        const int nz = block_sum(zoomed, red);
+        if (tid == 0) {
+            int nc = nc_all;
+            if (prev + nc > a.capCand) { nc = a.capCand - prev; atomicOr(&a.cnt->err, 2); }
+            a.cnt->NC[a.level] = nc;
+            a.cnt->ytot[a.level + 1] = prev + nc;
+            a.cnt->PZ[a.level] = nz;
+            a.cnt->nsel = a.k < prev + nc ? a.k : prev + nc;
+        }
+        return;
+    }
+    // ---- rankers (see k_static_select)
+    const int Np = (Nv + SC_NT - 1) / SC_NT * SC_NT;
+    const int jl = Np / 16, jb = wave * jl;
+    for (int i0 = ((int)blockIdx.x - nbC - 1) * SEL_I; i0 < Nv; i0 += FIN_NBR * SEL_I) {
+        const int ibase = i0 & ~63, ioff = i0 - ibase;
+        const int i = i0 + lane;
+        const unsigned kiv = (lane < SEL_I && i < Nv) ? final_key(a, prev, Ns, i) : 0u;
+        int cntv = 0;
+        for (int p0 = 0; p0 < jl; p0 += SEL_Q * 64) {
+            unsigned key[SEL_Q];
+#pragma unroll
+            for (int q = 0; q < SEL_Q; ++q) {
+                const int jq = jb + p0 + q * 64;
+                key[q] = (jq < jb + jl && jq + lane < Nv) ? final_key(a, prev, Ns, jq + lane) : 0u;
+            }
+            unsigned long long own = 0;
+            unsigned kown = 0;
+#pragma unroll
+            for (int q = 0; q < SEL_Q; ++q) {
+                const int jq = jb + p0 + q * 64;
+                if (jq == ibase) { kown = key[q]; own = 1; }
+                else if (jq < ibase) key[q] = key[q] == 0xFFFFFFFFu ? key[q] : key[q] + (key[q] ? 1u : 0u);
+            }
+            for (int ii = 0; ii < SEL_I; ++ii) {
+                const unsigned ki = __builtin_amdgcn_readlane(kiv, ii);
+                int n = 0;
+#pragma unroll
+                for (int q = 0; q < SEL_Q; ++q) n += __popcll(__ballot(key[q] > ki));
+                if (own) n += __popcll(__ballot(kown == ki) & ((1ull << (ii + ioff)) - 1ull));
+                cntv += (lane == ii) ? n : 0;
+            }
+        }
+        __syncthreads();             // (the previous turn's readers of `part` are done)
+        if (lane < SEL_I) part[wave][lane] = cntv;
+        __syncthreads();
+        if (wave == 0 && lane < SEL_I && kiv != 0u) {
+            int rank = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) rank += part[w][lane];
+            if (rank < a.k) {
+                if (i < prev) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a.Yout[(size_t)rank * 4 + q] = a.Yall[(size_t)i * 4 + q];
+                    a.Sout[rank] = a.Sall[i];
+                } else {
+                    const int c = i - prev, r = c / AZ_NSUB;
+                    const size_t src = (size_t)a.inv[r] * AZ_NSUB + (c - r * AZ_NSUB);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a.Yout[(size_t)rank * 4 + q] = a.pred_u[src * 4 + q];
+                    a.Sout[rank] = a.score_u[src];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u)
@@ -261,6 +390,11 @@ bool azk_static_select(hipStream_t s, const AzStaticArgs &a)
     const int nbR = (Nv + SEL_I - 1) / SEL_I;
     k_static_select<<<dim3(nbC + 1 + nbR), dim3(SC_NT), 0, s>>>(a, nbC);
     return true;
+}
+
+void azk_final_select(hipStream_t s, const AzFinalArgs &a)
+{
+    k_final_select<<<dim3(FIN_NBC + 1 + FIN_NBR), dim3(SC_NT), 0, s>>>(a);
 }
 
 void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src)

@@ -169,3 +169,29 @@ def test_full_head_one_pass_bits_equal_level_loop(mods):
     a, b = _both(net, ffi, 800, 1200, 0.75, 0.0)
     assert a["st"].static_plan == 1 and b["st"].static_plan == 0
     _same(a, b)
+
+
+def test_plan_cache_eviction_with_graphs(mods, monkeypatch):
+    """The per-shape plans live in an LRU cache (AZ_PLAN_CACHE entries, default 64): cycle five shapes through a
+    two-entry cache, with hipGraph replay on (a dropped plan takes the captured launch sequences with it)."""
+    ffi, synth, HipAZNet, orc = mods
+    monkeypatch.setenv("AZ_PLAN_CACHE", "2")
+    net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="lru")
+    shapes = [(600, 1000), (375, 500), (480, 640), (333, 777), (500, 353)]
+    ref = {}
+    net.ctx.set_graphs(True)
+    try:
+        for rnd in range(3):
+            for H, W in shapes:
+                scale = _scale(H, W)
+                fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+                net.set_conv(synth.make_feature_map(21, synth.SMALL_DIMS["C"], fh, fw))
+                Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, 0.0), want_scores=True, want_stats=True)
+                assert st.static_plan == 1
+                if (H, W) not in ref:
+                    net.ctx.set_graphs(False)
+                    ref[(H, W)] = net.propose(ffi.AzContext.make_params(H, W, scale, 0.0, static_tree=False), want_scores=True)
+                    net.ctx.set_graphs(True)
+                assert np.array_equal(Y, ref[(H, W)][0]) and np.array_equal(S, ref[(H, W)][1])
+    finally:
+        net.ctx.set_graphs(False)
