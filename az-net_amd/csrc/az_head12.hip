@@ -15,8 +15,10 @@
 // tile goes to LDS during the third k-group, re-used for the request right behind the step's one barrier, which sits
 // before the fourth k-group, whose operands are already in registers); work items are chained through LDS (the
 // last steps of an item fetch the next item's first tile).
-// Measured at 688 rows (config A, one pass): 1009-1019 us against 1022-1035 for k_fc_splitk on the same boxes, matrix
-// pipe 90 % busy, FETCH_SIZE x 2 + WRITE_SIZE = 1.13 GB per launch against 2.79 GB; no LDS bank conflicts.
+// Inside a k-group the LDS / VMEM instructions are dealt one per MFMA issue slot with the MFMAs in front
+// (sched_group_barrier): 1012 -> 985 us.
+// Measured at 688 rows (config A, one pass): 985 us against 1022-1035 for k_fc_splitk on the same boxes,
+// FETCH_SIZE x 2 + WRITE_SIZE = 1.13 GB per launch against 2.79 GB; no LDS bank conflicts.
 // Tried here and dropped: the 16x16x4 half strip for the last <= 16 rows (bit-identical, +10 us: its row group drifts
 // from the other two), s_setprio around the MFMA groups, either way (+60 us).
 #include <hip/hip_runtime.h>
@@ -161,20 +163,53 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
     float4 a0[NA], a1[NA], b0, b1;
     frag(pb, 0, a0, b0);
     // one K-step on LDS[buf]; the tile in flight is staged into LDS[buf^1], then tile `gkt` of `g` is requested
+    // Inside a k group the other instructions are dealt one per MFMA issue slot (sched_group_barrier), the MFMAs
+    // in front: the matrix pipe is fed from the first cycle after the barrier and up to the last one before it.
+    constexpr int NM = 4 * NRT, NR = NRT + 1, NV = W_NLA + W_NLB;       // MFMAs, fragment reads, tile vectors per group
+    constexpr bool PACE = NRT >= 3;
     auto step = [&](int buf, const Src &g, int gkt, bool request, bool prefetch_frag) {
         // k group 0 | fragments of group 1
         __builtin_amdgcn_sched_barrier(0);
         frag(buf, 1, a1, b1);
         mfma8(a0, b0);
+        if constexpr (PACE) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // k group 1 | fragments of group 2
         frag(buf, 2, a0, b0);
         mfma8(a1, b1);
+        if constexpr (PACE) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        // k group 2 | fragments of group 3 | staged tile -> LDS[buf^1]
+        // k group 2 | staged tile -> LDS[buf^1] | fragments of group 3
+        lstore(buf ^ 1, ra, rb);
         frag(buf, 3, a1, b1);
         mfma8(a0, b0);
-        lstore(buf ^ 1, ra, rb);
+        if constexpr (PACE) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 2);   // 1 DS write
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - NR, 2);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();             // LDS[buf^1] complete; everyone's reads of LDS[buf] issued
         __builtin_amdgcn_sched_barrier(0);
@@ -182,6 +217,19 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
         if (request) gload(g, gkt, ra, rb);
         if (prefetch_frag) frag(buf ^ 1, 0, a0, b0);
         mfma8(a1, b1);
+        if constexpr (PACE) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 3);   // 1 VMEM read
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 3);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - NR, 3);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int kt = 0; kt + 2 < nk; ++kt) step((kt & 1) ^ pb, cur, kt + 2, true, true);
