@@ -6,11 +6,12 @@
 // alone.  The regions of ALL levels, their rois, the 1/16 dedup maps and the anchors are then computed once per
 // image shape (the same geometry kernels as the level loop, az_capi.hip: ensure_static_plan) and every image runs
 //   ONE head pass over the unique rois of all levels (RoIPool, int6, int7, tail), then
-//   k_static_candidates: candidates of all levels appended in the reference's order + the per-level counters,
-//   then the final selection
+//   k_static_select (fixed proposal count) -- candidates of all levels appended in the reference's order, the
+//   per-level counters and the final top-k in one launch -- or k_static_candidates + the selection kernels
 // instead of one head pass + geometry per level: same rows through the same arithmetic (a roi's bits do not depend
-// on which launch it sits in), no level-to-level dependency left.  k_static_candidates also verifies the premise
+// on which launch it sits in), no level-to-level dependency left.  The counters workgroup also verifies the premise
 // (every zoom score of the tree >= Tz, i.e. no NaN): if it fails the host reruns the level loop.
+// The level loop's LAST level uses the same construction (k_final_select at the end of this file).
 #include <hip/hip_runtime.h>
 #include "az_dev.h"
 #include "az_geom_dev.h"
