@@ -16,11 +16,11 @@
 // before the fourth k-group, whose operands are already in registers); work items are chained through LDS (the
 // last steps of an item fetch the next item's first tile).
 // Inside a k-group the LDS / VMEM instructions are dealt one per MFMA issue slot with the MFMAs in front
-// (sched_group_barrier): 1012 -> 985 us.
-// Measured at 688 rows (config A, one pass): 985 us against 1022-1035 for k_fc_splitk on the same boxes,
+// (sched_group_barrier): 1012 -> 985 us.  The launch's last <= 16 rows are a 16x16x4 half strip (az_head.hip's, same
+// bits) in the row group that ends the last m-tile: 982 -> 972 us (without the pacing it cost 10 us instead).
+// Measured at 688 rows (config A, one pass): 972 us against 1022-1035 for k_fc_splitk on the same boxes,
 // FETCH_SIZE x 2 + WRITE_SIZE = 1.13 GB per launch against 2.79 GB; no LDS bank conflicts.
-// Tried here and dropped: the 16x16x4 half strip for the last <= 16 rows (bit-identical, +10 us: its row group drifts
-// from the other two), s_setprio around the MFMA groups, either way (+60 us).
+// Tried here and dropped: s_setprio around the MFMA groups, either polarity (+60 us).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "az_dev.h"
@@ -28,6 +28,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int W_NT = 768;                 // 12 waves
@@ -67,8 +68,10 @@ struct Item12 {
 // of a tile nobody reads) and stages it in the LDS buffer that step leaves free, so the next item starts with its
 // operands already in LDS[pb] (`preloaded`) -- with one workgroup per CU nothing else would cover that latency.
 // Returns the buffer holding the next item's first tile.
-// (Rows past the last full strip are a padded strip here.)
-template <int NRT>
+// HALF: the row group ends with a 16-row half strip (the launch's last <= 16 rows) on v_mfma_f32_16x16x4_f32, fed so
+// that its accumulation chain is the 32x32x2 one (az_head.hip: per 8-wide k group two instructions, k slots
+// (0,4,1,5) then (2,6,3,7)): half the matrix-pipe time of a padded strip, same bits.
+template <int NRT, bool HALF>
 __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
                                       int M, int N, const Item12 &it, int my0, const Item12 &nx, bool has_next,
                                       bool preloaded, int pb, float *sA, float *sB)
@@ -78,7 +81,9 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
     const int cs = wave & 3;
     const int lrow = lane & 31, lk = (lane >> 5) * 4;
     const int nk = (it.kend - it.k0 + W_BK - 1) / W_BK;
+    static_assert(!HALF || NRT <= 3, "a row group has at most four strip slots");
     constexpr int NA = NRT > 0 ? NRT : 1;
+    floatx4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     floatx16 acc[NA];
 #pragma unroll
     for (int r = 0; r < NRT; ++r)
@@ -153,6 +158,32 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
     // of three waves (~12 000 cycles) to come back.  Across work items only the LDS tile is carried: the step before
     // last requests the next item's first tile, the last step stages it (and requests nothing, so that no load is in
     // flight through the epilogue), and an item that starts with its tile 0 in LDS[pb] requests tile 1 at once.
+    // half-strip fragments of one 8-wide k group: lane = (row or column lane & 15, k slot lane >> 4);
+    // slot s feeds k = {0,4,1,5}[s] to the first instruction and k + 2 to the second
+    struct HalfFrag { float a1, a2, b1[2], b2[2]; };
+    const int hk = ((lane >> 4) & 1) * 4 + (lane >> 5);
+    const float *ha_base = sA + ((my0 + NRT) * 32 + (lane & 15)) * W_LDT + hk;
+    const float *hb_base = sB + (cs * 32 + (lane & 15)) * W_LDT + hk;
+    auto hfrag = [&](int buf, int g8, HalfFrag &f) {
+        if constexpr (HALF) {
+            const float *pa = ha_base + buf * (W_BM * W_LDT) + g8 * 8;
+            f.a1 = pa[0]; f.a2 = pa[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *pbh = hb_base + buf * (W_BN * W_LDT) + h * 16 * W_LDT + g8 * 8;
+                f.b1[h] = pbh[0]; f.b2[h] = pbh[2];
+            }
+        }
+    };
+    auto hmfma = [&](const HalfFrag &f) {
+        if constexpr (HALF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acch[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b1[h], acch[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acch[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a2, f.b2[h], acch[h], 0, 0, 0);
+        }
+    };
+
     float4 ra[W_NLA], rb[W_NLB];
     if (!preloaded) {                // (workgroup-uniform) the workgroup's first item
         gload(cur, 0, ra, rb);
@@ -161,17 +192,22 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
     }
     gload(cur, 1, ra, rb);
     float4 a0[NA], a1[NA], b0, b1;
+    HalfFrag h0, h1;
     frag(pb, 0, a0, b0);
+    hfrag(pb, 0, h0);
     // one K-step on LDS[buf]; the tile in flight is staged into LDS[buf^1], then tile `gkt` of `g` is requested
     // Inside a k group the other instructions are dealt one per MFMA issue slot (sched_group_barrier), the MFMAs
     // in front: the matrix pipe is fed from the first cycle after the barrier and up to the last one before it.
-    constexpr int NM = 4 * NRT, NR = NRT + 1, NV = W_NLA + W_NLB;       // MFMAs, fragment reads, tile vectors per group
-    constexpr bool PACE = NRT >= 3;
+    // (a half strip adds 4 short MFMAs and 3 two-word DS reads per group)
+    constexpr int NM = 4 * NRT + (HALF ? 4 : 0), NR = NRT + 1 + (HALF ? 3 : 0), NV = W_NLA + W_NLB;
+    constexpr bool PACE = NM >= NV + NR;
     auto step = [&](int buf, const Src &g, int gkt, bool request, bool prefetch_frag) {
         // k group 0 | fragments of group 1
         __builtin_amdgcn_sched_barrier(0);
         frag(buf, 1, a1, b1);
+        hfrag(buf, 1, h1);
         mfma8(a0, b0);
+        hmfma(h0);
         if constexpr (PACE) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -183,7 +219,9 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
         __builtin_amdgcn_sched_barrier(0);
         // k group 1 | fragments of group 2
         frag(buf, 2, a0, b0);
+        hfrag(buf, 2, h0);
         mfma8(a1, b1);
+        hmfma(h1);
         if constexpr (PACE) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -196,7 +234,9 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
         // k group 2 | staged tile -> LDS[buf^1] | fragments of group 3
         lstore(buf ^ 1, ra, rb);
         frag(buf, 3, a1, b1);
+        hfrag(buf, 3, h1);
         mfma8(a0, b0);
+        hmfma(h0);
         if constexpr (PACE) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -215,8 +255,9 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
         __builtin_amdgcn_sched_barrier(0);
         // k group 3 | request the tile after next | fragments of group 0 of the next tile
         if (request) gload(g, gkt, ra, rb);
-        if (prefetch_frag) frag(buf ^ 1, 0, a0, b0);
+        if (prefetch_frag) { frag(buf ^ 1, 0, a0, b0); hfrag(buf ^ 1, 0, h0); }
         mfma8(a1, b1);
+        hmfma(h1);
         if constexpr (PACE) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
@@ -247,6 +288,18 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
                 if (row < M) it.slab[(size_t)row * N + col] = acc[r][e];
             }
     }
+    if constexpr (HALF) {
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hcol = it.n0 + cs * 32 + 16 * h + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = it.m0 + (my0 + NRT) * 32 + 4 * (lane >> 4) + e;
+                if (hcol < N && row < M) it.slab[(size_t)row * N + hcol] = acch[h][e];
+            }
+        }
+    }
     return (nk & 1) ^ pb;
 }
 
@@ -258,6 +311,8 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
     float *sA = lds12, *sB = lds12 + 2 * W_BM * W_LDT;
     const int M = *Mptr;
     if (M <= 0) return;
+    // strip slots: full strips, then (<= 16 trailing rows) one half-strip slot, the last slot of the last m-tile
+    const bool has_half = (M & 31) != 0 && (M & 31) <= 16;
     const int strips = (M + 31) >> 5;
     const int mt = (strips + 11) / 12;
     const int nt = (N + W_BN - 1) / W_BN;
@@ -286,14 +341,27 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
         const Item12 nx = item_at(has_next ? idx + 1 : idx);
         // ... then to the three row groups of a tile
         const int rb_ = it.nst / 3, rr = it.nst - rb_ * 3;
-        const int my0 = rg * rb_ + (rg < rr ? rg : rr), nrt = rb_ + (rg < rr ? 1 : 0);
-#define TILE12(NRT_) pb = tile12<NRT_>(X, ldx, Wt, ldw, M, N, it, my0, nx, has_next, idx > 0, pb, sA, sB)
-        switch (nrt) {
-        case 0: TILE12(0); break;
-        case 1: TILE12(1); break;
-        case 2: TILE12(2); break;
-        case 3: TILE12(3); break;
-        default: TILE12(4); break;
+        const int my0 = rg * rb_ + (rg < rr ? rg : rr);
+        int nrt = rb_ + (rg < rr ? 1 : 0);
+        // the half slot: last slot of the launch's last m-tile, i.e. of the row group that ends at the tile's end
+        const bool half = has_half && (idx % mt) == mt - 1 && nrt > 0 && my0 + nrt == it.nst;
+        if (half) --nrt;
+#define TILE12(NRT_, HALF_) pb = tile12<NRT_, HALF_>(X, ldx, Wt, ldw, M, N, it, my0, nx, has_next, idx > 0, pb, sA, sB)
+        if (half) {
+            switch (nrt) {
+            case 0: TILE12(0, true); break;
+            case 1: TILE12(1, true); break;
+            case 2: TILE12(2, true); break;
+            default: TILE12(3, true); break;
+            }
+        } else {
+            switch (nrt) {
+            case 0: TILE12(0, false); break;
+            case 1: TILE12(1, false); break;
+            case 2: TILE12(2, false); break;
+            case 3: TILE12(3, false); break;
+            default: TILE12(4, false); break;
+            }
         }
 #undef TILE12
     }
