@@ -79,6 +79,7 @@ struct az_ctx {
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
     int final_env = 1;                        // AZ_FINAL_FUSED=0: separate candidate / selection kernels at the last level
+    int hint_rows[AZ_MAX_LEVELS] = {0};       // unique rois per level of the last fetched level-loop search (kernel choice)
     int gemm12_env = -1;
     int gemm12_min_rows = 257;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN)
     // Fast R-CNN head on the shared map (az_load_det_head)
@@ -285,13 +286,24 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       if (c->gemm_parts)
           azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
                            c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part);
-      else if (rows_hint >= c->gemm12_min_rows && (d.n6 / 128) * c->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
-               azk_fc_chunk(d.K6, c->S6) * c->S6 == d.K6 && azk_fc_chunk(d.K6, c->S6) >= 64)
-          // the caller knows the row count on the host (a one-pass plan): many rows -> one weight tile per 12 strips
-          azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
-                        azk_fc_chunk(d.K6, c->S6), c->part);
-      else
-          azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part); }
+      else {
+          const bool can12 = (d.n6 / 128) * c->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
+                             azk_fc_chunk(d.K6, c->S6) * c->S6 == d.K6 && azk_fc_chunk(d.K6, c->S6) >= 64 &&
+                             c->gemm12_min_rows < 0x7fffffff;
+          if (can12 && rows_hint >= c->gemm12_min_rows)
+              // the caller knows the row count on the host (a one-pass plan): many rows -> one weight tile per 12 strips
+              azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
+                            azk_fc_chunk(d.K6, c->S6), c->part);
+          else if (can12 && rows_hint == -1) {
+              // only the device knows the row count, and the last search had many rows at this level: both kernels
+              // are launched and the one that does not own the row count leaves at once (~6 us for the idle launch)
+              azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part,
+                          (c->gemm12_min_rows - 1) / 32);
+              azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
+                            azk_fc_chunk(d.K6, c->S6), c->part, ((c->gemm12_min_rows - 1) / 32) * 32 + 1);
+          } else
+              azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part);
+      } }
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
     { Timed t(c, "fc7_gemm", level, 1);
@@ -738,6 +750,14 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
     return AZ_OK;
 }
 
+// In the level loop only the device knows a level's row count.  If the previous search on this context forwarded many
+// rois at level l, the next one probably does too: its int6 is then sent to both GEMM kernels (rows_hint -1, see
+// launch_head).  A wrong guess costs an idle launch, never a result.
+static int many_rows_expected(const az_ctx *c, int l)
+{
+    return (l >= 0 && l < AZ_MAX_LEVELS && c->hint_rows[l] >= c->gemm12_min_rows) ? -1 : 0;
+}
+
 // --------------------------------------------------------------------------------------
 // Everything az_propose enqueues on the ctx stream (no host synchronisation, no host-dependent sizes:
 // every count is read on the device), so the same sequence can also be captured into a hipGraph.
@@ -806,7 +826,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             // this level's rois were projected and deduplicated by the previous geometry kernel
             // (the first fused level's head pass also carries the deferred root: row count from spec_levels)
             launch_head(c, l == n_spec ? &c->cnt->scratch[4] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u,
-                        c->delta_u, p->min_side, true, (defer_root && l == n_spec) ? 1 : 0);
+                        c->delta_u, p->min_side, true, (defer_root && l == n_spec) ? 1 : 0, nullptr, nullptr,
+                        many_rows_expected(c, l));
             Timed t(c, "level_geom", l);
             AzLevelArgs a;
             a.cnt = c->cnt; a.level = l; a.nlev = nlev;
@@ -836,7 +857,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                             p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
         } else {
             launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, final_fused,
-                        0, nullptr, nullptr, 0, final_fused);
+                        0, nullptr, nullptr, many_rows_expected(c, l), final_fused);
         }
         if (final_fused) {
             Timed t(c, "final_select", l);
@@ -933,6 +954,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->nofuse_lv_h, sizeof(int));
         key.append((const char *)&c->nofuse_lv_w, sizeof(int));
         key.append((const char *)&c->last_static, sizeof(int));
+        for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
         const void *pp = stat ? (const void *)c->plan : nullptr;
         key.append((const char *)&pp, sizeof(pp));
         auto it = c->graphs.find(key);
@@ -1060,6 +1082,8 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         return fail(c, AZ_ERR_CAPACITY,
                     std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
                         "): raise az_set_limits");
+    if (!c->last_static)
+        for (int l = 0; l < AZ_MAX_LEVELS; ++l) c->hint_rows[l] = l < nlev ? h.U[l] : 0;
     const int n = h.nsel;
     c->cand_n = h.ytot[nlev];
     c->his_n = h.nhis;

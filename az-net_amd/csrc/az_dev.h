@@ -216,9 +216,11 @@ void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, i
 // ldw = K
 size_t azk_tiled_elems(int N, int K);
 void azk_tile_weights(hipStream_t s, const float *rowmajor, float *tiled, int N, int K);
-// many-row shape (az_head12.hip): 12-wave workgroups, one weight tile per <= 12 row strips; same bits as azk_fc_gemm
+// many-row shape (az_head12.hip): 12-wave workgroups, one weight tile per <= 12 row strips; same bits as azk_fc_gemm.
+// min_rows > 0: the kernel leaves at once when *Mptr is smaller (a launch whose row count only the device knows is
+// sent to both kernels, azk_fc_gemm with max_strips = (min_rows - 1) / 32).
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
-                   int K, int S, int Kc, float *part);
+                   int K, int S, int Kc, float *part, int min_rows = 0);
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
                  int N, int K, int S, float *part, int max_strips = 1 << 30);
 int azk_fc_chunk(int K, int S);

@@ -305,12 +305,12 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
 
 __global__ void __launch_bounds__(W_NT)
 k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw, const int *Mptr, int capM,
-              int N, int K, int S, int Kc, float *__restrict__ part)
+              int N, int K, int S, int Kc, float *__restrict__ part, int min_rows)
 {
     extern __shared__ __attribute__((aligned(16))) float lds12[];
     float *sA = lds12, *sB = lds12 + 2 * W_BM * W_LDT;
     const int M = *Mptr;
-    if (M <= 0) return;
+    if (M <= 0 || M < min_rows) return;      // (fewer rows: k_fc_splitk, launched beside this kernel, owns the launch)
     // strip slots: full strips, then (<= 16 trailing rows) one half-strip slot, the last slot of the last m-tile
     const bool has_half = (M & 31) != 0 && (M & 31) <= 16;
     const int strips = (M + 31) >> 5;
@@ -372,7 +372,7 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
 // One workgroup per CU; the caller knows the row count on the host (a one-pass search's plan) and takes this
 // kernel for many-row launches of layers whose (n-tile, K-chunk) groups fill the chip.
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
-                   int K, int S, int Kc, float *part)
+                   int K, int S, int Kc, float *part, int min_rows)
 {
     static bool attr = false;
     const size_t lds = (size_t)(2 * W_BM * W_LDT + 2 * W_BN * W_LDT + 512 * 4) * sizeof(float);   // + junk slots
@@ -383,5 +383,5 @@ void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int l
     }
     static int grid = -1;
     if (grid < 0) { const char *e = getenv("AZ_GEMM12_GRID"); grid = e ? atoi(e) : 256; }
-    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds, s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part);
+    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds, s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows);
 }

@@ -164,6 +164,12 @@ def test_full_head_one_pass_bits_equal_level_loop(mods):
     assert a["st"].static_plan == 1 and a["st"].spec_rows == 688 and b["st"].static_plan == 0
     assert a["Ya"].shape[0] > 8000
     _same(a, b)
+    # the level loop again: the context now expects many rows at level 5 (517 rois in the search just fetched) and
+    # sends that level's int6 to both GEMM kernels, of which the many-row one owns the launch -- same bits
+    p_ll = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, static_tree=False)
+    Y2, S2, st2 = net.propose(p_ll, want_scores=True, want_stats=True)
+    Ya2, Sa2 = net.ctx.last_candidates()
+    _same(dict(Y=Y2, S=S2, Ya=Ya2, Sa=Sa2, st=st2), b)
     # ... and at BASELINE config 4's tree (2672 rois in one pass)
     net.set_conv(synth.make_feature_map(5, 512, 38, 57))
     a, b = _both(net, ffi, 800, 1200, 0.75, 0.0)
