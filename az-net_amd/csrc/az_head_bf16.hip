@@ -180,20 +180,43 @@ __device__ __forceinline__ void fc_tile_bf16(const unsigned short *__restrict__ 
     lstore(0, 0, ra0, rb0);
     __syncthreads();
     frag(0, 0, a0, b0);
+    // Per step: [tile kt+1 -> LDS[buf^1] | request tile kt+2 | fragments of k block 1 | MFMAs of k block 0], barrier,
+    // [fragments of k block 0 of tile kt+1 | MFMAs of k block 1].  The MFMAs lead each half and the other
+    // instructions are dealt into their issue slots (sched_group_barrier), so the matrix pipe is fed from the first
+    // cycle after the barrier (the fragments it needs were read before it) up to the last one before it.
+    // (LDS[buf^1] is free for the store from the start of the step: its last readers -- k block 1 of the previous
+    //  step's first half -- issued their reads before the previous step's barrier.)
+    constexpr int NMF = NRTW * (PARTS * (PARTS + 1) / 2);            // MFMAs per k block
+    constexpr int NRD = PARTS * (NRTW + 1);                          // fragment reads per k block
+    constexpr int NWR = PARTS * (2 + NB);                            // tile vectors per thread (stores = loads)
     auto step = [&](int kt, int buf, v4u (&rl_a)[PARTS][2], v4u (&rl_b)[PARTS][NB], const v4u (&rw_a)[PARTS][2],
                     const v4u (&rw_b)[PARTS][NB]) {
         __builtin_amdgcn_sched_barrier(0);
+        lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
         gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
         frag(buf, 1, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
         mfma16(a0, b0);
+        if constexpr (NMF > 0) {
+            constexpr int per = (NWR + NWR + NRD + NMF - 1) / NMF;
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // 1 MFMA, then up to `per` of:
+                __builtin_amdgcn_sched_group_barrier(0x200 | 0x020 | 0x100, per, 0);   // DS write | VMEM read | DS read
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         frag(buf ^ 1, 0, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
         mfma16(a1, b1);
+        if constexpr (NMF > 0) {
+            constexpr int per = (NRD + NMF - 1) / NMF;
+#pragma unroll
+            for (int i = 0; i < NMF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, per, 1);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int kt = 0; kt < nk; kt += 2) {
