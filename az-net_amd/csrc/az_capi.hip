@@ -81,7 +81,9 @@ struct az_ctx {
     int final_env = 1;                        // AZ_FINAL_FUSED=0: separate candidate / selection kernels at the last level
     int hint_rows[AZ_MAX_LEVELS] = {0};       // unique rois per level of the last fetched level-loop search (kernel choice)
     int gemm12_env = -1;
-    int gemm12_min_rows = 257;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN)
+    int gemm12_min_rows = 161;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN;
+                                              // measured crossover with k_fc_splitk: 160 rows)
+    int gemm12_dual_rows = 257;               // ... and from which a device-known one is worth the second (idle) launch
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
@@ -298,9 +300,9 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
               // only the device knows the row count, and the last search had many rows at this level: both kernels
               // are launched and the one that does not own the row count leaves at once (~6 us for the idle launch)
               azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part,
-                          (c->gemm12_min_rows - 1) / 32);
+                          (c->gemm12_dual_rows - 1) / 32);
               azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
-                            azk_fc_chunk(d.K6, c->S6), c->part, ((c->gemm12_min_rows - 1) / 32) * 32 + 1);
+                            azk_fc_chunk(d.K6, c->S6), c->part, ((c->gemm12_dual_rows - 1) / 32) * 32 + 1);
           } else
               azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part);
       } }
@@ -755,7 +757,8 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 // launch_head).  A wrong guess costs an idle launch, never a result.
 static int many_rows_expected(const az_ctx *c, int l)
 {
-    return (l >= 0 && l < AZ_MAX_LEVELS && c->hint_rows[l] >= c->gemm12_min_rows) ? -1 : 0;
+    return (l >= 0 && l < AZ_MAX_LEVELS && c->hint_rows[l] >= c->gemm12_dual_rows &&
+            c->gemm12_min_rows < 0x7fffffff) ? -1 : 0;
 }
 
 // --------------------------------------------------------------------------------------

@@ -201,6 +201,8 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
     // (a half strip adds 4 short MFMAs and 3 two-word DS reads per group)
     constexpr int NM = 4 * NRT + (HALF ? 4 : 0), NR = NRT + 1 + (HALF ? 3 : 0), NV = W_NLA + W_NLB;
     constexpr bool PACE = NM >= NV + NR;
+    constexpr bool PACE2 = !PACE && NM > 0;     // few MFMAs (1-2 strips): several other instructions per MFMA slot
+    constexpr int NMD = NM > 0 ? NM : 1;
     auto step = [&](int buf, const Src &g, int gkt, bool request, bool prefetch_frag) {
         // k group 0 | fragments of group 1
         __builtin_amdgcn_sched_barrier(0);
@@ -215,6 +217,12 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+        } else if constexpr (PACE2) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (NR + NMD - 1) / NMD, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // k group 1 | fragments of group 2
@@ -229,6 +237,12 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 1);
+        } else if constexpr (PACE2) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, (NR + NMD - 1) / NMD, 1);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // k group 2 | staged tile -> LDS[buf^1] | fragments of group 3
@@ -249,6 +263,12 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 2);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - NR, 2);
+        } else if constexpr (PACE2) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 2);
+                __builtin_amdgcn_sched_group_barrier(0x200 | 0x100, (NV + NR + NMD - 1) / NMD, 2);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();             // LDS[buf^1] complete; everyone's reads of LDS[buf] issued
@@ -270,6 +290,12 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 3);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NM - NV - NR, 3);
+        } else if constexpr (PACE2) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 3);
+                __builtin_amdgcn_sched_group_barrier(0x020 | 0x100, (NV + NR + NMD - 1) / NMD, 3);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };

@@ -249,15 +249,15 @@ def test_head_rows_same_bits_in_full_half_and_padded_strips(small, full, mods, w
 
 def test_many_row_gemm_same_bits_as_the_tile_gemm(full, mods):
     """Launches whose row count the host knows (az_head_forward, the one-pass search) take the 12-wave many-row
-    GEMM (az_head12.hip) from 257 rows on: m-tiles of <= 12 strip slots dealt to three row groups, the trailing
+    GEMM (az_head12.hip) from 161 rows on: m-tiles of <= 12 strip slots dealt to three row groups, the trailing
     <= 16 rows as a half strip.  A roi's bits must not depend on the kernel, the m-tile, the row group or the
-    kind of strip it lands in: sub-batches (<= 256 rows: k_fc_splitk) and shifted windows against a 1000-row launch."""
+    kind of strip it lands in: sub-batches (<= 160 rows: k_fc_splitk) and shifted windows against a 1000-row launch."""
     ffi, synth, HipAZNet, orc = mods
     net, head = full
     net.set_conv(synth.make_feature_map(3, 512, 38, 63))
     rois = _rand_rois(np.random.RandomState(11), 1000, 1000, 600)
     ref = net.ctx.head_forward(rois)                       # 1000 rows = 31 strips + 8 rows: 3 m-tiles, half strip
-    for n in [64, 200, 256, 257, 272, 273, 288, 300, 352, 353, 368, 369, 384, 385, 400, 401, 517, 688, 689, 700, 704,
+    for n in [64, 128, 160, 161, 176, 177, 192, 193, 200, 224, 225, 256, 257, 272, 273, 288, 300, 352, 353, 368, 369, 384, 385, 400, 401, 517, 688, 689, 700, 704,
               705, 720, 721, 737, 768, 769, 784, 785, 999]:
         got = net.ctx.head_forward(rois[:n])
         for a, b in zip(got, ref):
