@@ -75,7 +75,7 @@ struct az_ctx {
     unsigned long long plan_clock = 0;
     int plan_cache_max = 64;
     unsigned *key_u = nullptr;                // selection keys of the decoded boxes (tail kernel), [row][11]
-    int nostatic_h = -1, nostatic_w = -1;     // image shape whose tree outgrew the plan buffers
+    std::vector<std::pair<int, int>> nostatic; // image shapes whose trees outgrew the plan buffers (a few; oldest dropped)
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
     int final_env = 1;                        // AZ_FINAL_FUSED=0: separate candidate / selection kernels at the last level
@@ -97,6 +97,7 @@ struct az_ctx {
     int *nms_order = nullptr;
     unsigned long long *nms_mask = nullptr;
     long long *nms_keep = nullptr;
+    unsigned char *h_nms = nullptr;     // host-mapped block of az_nms's small case
     // tuner (az_eval.hip): anchor history of the last search, score pool over an image set
     double *hisB = nullptr;
     float *hisZ = nullptr;
@@ -119,10 +120,15 @@ struct az_ctx {
     int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which a later level outgrew the fused level kernel
     int defer_root_env = -1;            // AZ_DEFER_ROOT=0: keep the root's row in the speculative pass (measurements)
     int level_fused_env = -1;           // AZ_LEVEL_FUSED=0: keep levels >= 4 as separate launches (measurements)
-    std::map<std::string, hipGraphExec_t> graphs;   // captured launch sequences (az_set_graphs)
+    struct GraphEntry { hipGraphExec_t exec; int npass; int pass_src[AZ_MAX_LEVELS + 2]; };
+    std::map<std::string, GraphEntry> graphs;        // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_nlev = 0;
     int last_defer = 0;
+    // head passes of the search being enqueued / last launched: where each one's row count lives
+    // (>= 0: int index into AzCounts; < 0: -(rows + 1), a count the host knows)
+    int npass = 0;
+    int pass_src[AZ_MAX_LEVELS + 2] = {0};
     void *stage_dst = nullptr;          // az_propose_stage_result_dev target of the search in flight
     size_t stage_cap = 0;
     int his_n = 0;                      // rows of the anchor history of the last fetched tuner search
@@ -276,6 +282,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
                  const float *urois = nullptr, const double *ubox = nullptr, int rows_hint = 0, bool keys = false)
 {
     const AzHeadDims &d = c->d;
+    if (c->npass < AZ_MAX_LEVELS + 2) {
+        const int *c0 = reinterpret_cast<const int *>(c->cnt);
+        const bool in_cnt = Uptr >= c0 && Uptr < c0 + sizeof(AzCounts) / sizeof(int);
+        c->pass_src[c->npass++] = in_cnt ? (int)(Uptr - c0) : -(rows_hint > 0 ? rows_hint : 0) - 1;
+    }
     if (c->gemm12_env < 0) {            // AZ_GEMM12_MIN=<rows> (0: never): measurements
         const char *f = getenv("AZ_GEMM12_MIN");
         if (f) c->gemm12_min_rows = atoi(f) > 0 ? atoi(f) : 0x7fffffff;
@@ -382,7 +393,7 @@ int az_destroy(az_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     clear_events(c);
-    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second.exec);
     c->graphs.clear();
     free_all(c);
     for (void *p : c->allocs_geom) hipFree(p);
@@ -397,6 +408,7 @@ int az_destroy(az_ctx *c)
         if (p) hipFree(p);
     if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
+    if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -468,8 +480,14 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
     // W6's columns to match (c*49 + p  ->  p*C + c).  `part` is big enough to stage it.
     // The GEMM streams weights tile-major (azk_tile_weights): permute / stack in a row-major temporary, then tile.
-    float *tmp = nullptr;
-    HIPCHK(c, hipMalloc((void **)&tmp, (size_t)n6 * d.K6 * 4));
+    // (`tmp` serves both layers: the larger of the two row-major blocks)
+    struct TmpGuard { float *p = nullptr; ~TmpGuard() { if (p) hipFree(p); } } tg;
+    {
+        size_t te = (size_t)n6 * d.K6;
+        if ((size_t)d.n7 * n6 > te) te = (size_t)d.n7 * n6;
+        HIPCHK(c, hipMalloc((void **)&tg.p, te * 4));
+    }
+    float *tmp = tg.p;
     HIPCHK(c, hipMemcpy(c->part, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
     azk_permute_k(c->stream, c->part, tmp, n6, C, 1);
     if (c->gemm_parts)            // bf16 round-off planes of the (permuted, row-major) int6 weights
@@ -482,7 +500,6 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipMemcpy(tmp + (size_t)n71 * n6, W72, (size_t)n72 * n6 * 4, hipMemcpyHostToDevice));
     azk_tile_weights(c->stream, tmp, c->W7, d.n7, n6);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(tmp));
     HIPCHK(c, hipMemcpy(c->b7, b71, (size_t)n71 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->b7 + n71, b72, (size_t)n72 * 4, hipMemcpyHostToDevice));
     // tail weights, k-major [n7][64]: outputs 0..10 adj_score, 11..54 adj_bbox (k < n71), output 55
@@ -501,6 +518,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipMemcpy(c->bt + 11, bab, 44 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->bt + 55, bz, 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipDeviceSynchronize());
+    // the many-row GEMM's LDS opt-in is per device; without it every launch stays on k_fc_splitk
+    if (azk_fc_gemm12_prepare() != 0) { (void)hipGetLastError(); c->gemm12_min_rows = 0x7fffffff; c->gemm12_env = 1; }
     c->head_loaded = true;
     return AZ_OK;
 }
@@ -625,8 +644,10 @@ static bool static_wanted(az_ctx *c, const az_params *p, bool tune)
         c->final_env = (f && !atoi(f)) ? 0 : 1;
         if (g && atoi(g) > 0) c->plan_cache_max = atoi(g);
     }
-    return !tune && p->Tz <= 0.0 && !(p->reserved & (1 | 2 | 16 | 32)) && c->static_env &&
-           !(p->im_h == c->nostatic_h && p->im_w == c->nostatic_w);
+    if (tune || !(p->Tz <= 0.0) || (p->reserved & (1 | 2 | 16 | 32)) || !c->static_env) return false;
+    for (const auto &hw : c->nostatic)
+        if (hw.first == p->im_h && hw.second == p->im_w) return false;
+    return true;
 }
 
 static bool plan_is_for(const az_ctx::StaticPlan &k, const az_params *p, int nlev)
@@ -648,8 +669,14 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
         if (plan_is_for(*q, p, nlev)) { c->plan = q; q->last_use = ++c->plan_clock; return AZ_OK; }
     c->plan = nullptr;
     hipStream_t s = c->stream;
-    auto give_up = [&]() { c->nostatic_h = p->im_h; c->nostatic_w = p->im_w; return (int)AZ_OK; };
-    az_ctx::StaticPlan k;
+    auto give_up = [&]() {
+        if (c->nostatic.size() >= 32) c->nostatic.erase(c->nostatic.begin());
+        c->nostatic.emplace_back(p->im_h, p->im_w);
+        return (int)AZ_OK;
+    };
+    // (the plan under construction owns five device buffers until it is handed to the cache: freed on every other exit)
+    struct PlanGuard { az_ctx::StaticPlan k; bool keep = false; ~PlanGuard() { if (!keep) free_plan(&k); } } pg;
+    az_ctx::StaticPlan &k = pg.k;
     // Two passes over the tree: sizes first, then placement.  Rows of the one head pass: levels 2, 3, ... in order, the
     // root last (RoIPool treats that one whole-image roi cooperatively: a workgroup per bin instead of a wave.
     // Deepest level first with levels 1-3 cooperative was measured too: 26.2 us against 24.5).
@@ -699,17 +726,13 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
             if (!grab((void **)&k.urois, (size_t)k.Utot * 5 * sizeof(float)) ||
                 !grab((void **)&k.ubox, (size_t)k.Utot * 4 * sizeof(double)) ||
                 !grab((void **)&k.reg_u, (size_t)roff * sizeof(int)) ||
-                !grab((void **)&k.cand_src, (size_t)roff * AZ_NSUB * sizeof(int)) || !grab((void **)&k.meta, 16)) {
-                free_plan(&k);
+                !grab((void **)&k.cand_src, (size_t)roff * AZ_NSUB * sizeof(int)) || !grab((void **)&k.meta, 16))
                 return fail(c, AZ_ERR_HIP, "hipMalloc failed for a static plan");
-            }
         }
     }
     if (hipMemcpyAsync(k.meta, &k.Utot, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess ||
-        (azk_plan_cands(s, k.reg_u, k.roff[nlev], k.cand_src), hipStreamSynchronize(s)) != hipSuccess) {
-        free_plan(&k);
+        (azk_plan_cands(s, k.reg_u, k.roff[nlev], k.cand_src), hipStreamSynchronize(s)) != hipSuccess)
         return fail(c, AZ_ERR_HIP, "static plan: copy failed");
-    }
     k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.dedup = p->dedup;
     k.batch = p->batch_size; k.nlev = nlev;
     k.last_use = ++c->plan_clock;
@@ -718,13 +741,14 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
         // drop the least recently used shape; captured launch sequences may hold its pointers: drop those too
         size_t lru = 0;
         for (size_t i = 1; i < c->plans.size(); ++i) if (c->plans[i]->last_use < c->plans[lru]->last_use) lru = i;
-        for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+        for (auto &g : c->graphs) hipGraphExecDestroy(g.second.exec);
         c->graphs.clear();
         free_plan(c->plans[lru]);
         delete c->plans[lru];
         c->plans.erase(c->plans.begin() + (long)lru);
     }
     c->plans.push_back(new az_ctx::StaticPlan(k));
+    pg.keep = true;
     c->plan = c->plans.back();
     return AZ_OK;
 }
@@ -800,7 +824,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     }
     if (fused)
         launch_head(c, c->spec_U, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 0,
-                    c->spec_urois);
+                    c->spec_urois, nullptr, c->spc.U);
     else if (n_spec)
         launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
     if (fused) {
@@ -936,7 +960,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     hipStream_t s = c->stream;
-    auto enqueue = [&]() { return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
+    auto enqueue = [&]() { c->npass = 0; return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
     if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
@@ -969,13 +993,24 @@ int az_propose_launch(az_ctx *c, const az_params *p)
             hipGraphExec_t ge = nullptr;
             HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             rc = enqueue();
-            HIPCHK(c, hipStreamEndCapture(s, &g));
-            if (rc) return rc;
-            HIPCHK(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            // (whatever enqueue() returned, the capture ends here: the stream must never be left capturing)
+            const hipError_t ec = hipStreamEndCapture(s, &g);
+            if (rc || ec != hipSuccess) {
+                if (g) hipGraphDestroy(g);
+                (void)hipGetLastError();
+                return rc ? rc : fail(c, AZ_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+            }
+            const hipError_t ei = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
-            it = c->graphs.emplace(key, ge).first;
+            if (ei != hipSuccess) return fail(c, AZ_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+            az_ctx::GraphEntry ent;
+            ent.exec = ge; ent.npass = c->npass;
+            std::memcpy(ent.pass_src, c->pass_src, sizeof(ent.pass_src));
+            it = c->graphs.emplace(key, ent).first;
         }
-        HIPCHK(c, hipGraphLaunch(it->second, s));
+        c->npass = it->second.npass;
+        std::memcpy(c->pass_src, it->second.pass_src, sizeof(c->pass_src));
+        HIPCHK(c, hipGraphLaunch(it->second.exec, s));
     } else {
         if ((rc = enqueue()) != AZ_OK) return rc;
     }
@@ -1046,6 +1081,11 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         st->spec_rows = h.specU;
         st->root_deferred = c->last_defer;
         st->static_plan = c->last_static;
+        const int *hc = reinterpret_cast<const int *>(&h);
+        for (int i = 0; i < c->npass && i < AZ_MAX_LEVELS; ++i) {
+            const int r = c->pass_src[i] >= 0 ? hc[c->pass_src[i]] : -c->pass_src[i] - 1;
+            if (r > 0) st->pass_rows[st->n_passes++] = r;
+        }
         for (int l = 0; l < nlev; ++l) {
             st->level_regions[l] = h.P[l];
             st->level_unique[l] = h.U[l];
@@ -1333,6 +1373,26 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
     if (n == 0) return AZ_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (n <= azk_nms_small_max()) {
+        // the reference's own call-site size (apply_nms, test.py:467-484: <= 100 boxes per class): ONE launch, no copy
+        // commands -- the workgroup reads the boxes from and writes the keep list to host-mapped memory
+        if (!c->h_nms) HIPCHK(c, hipHostMalloc((void **)&c->h_nms, 8192, hipHostMallocMapped));
+        float *hd = (float *)c->h_nms;                                  // [256][5] f32 = 5120 B
+        long long *hk = (long long *)(c->h_nms + 5120);                 // [256] i64 = 2048 B, then the count
+        int *hn = (int *)(c->h_nms + 5120 + 2048);
+        std::memcpy(hd, dets, (size_t)n * 5 * sizeof(float));
+        *hn = -1;
+        if (!(c->profiling & 4)) clear_events(c);
+        { Timed t(c, "nms", n);
+          azk_nms_one_small(s, hd, n, thresh, hk, hn); }
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        const int nk = *hn;
+        if (nk < 0 || nk > n) return fail(c, AZ_ERR_HIP, "az_nms: the kernel left no result");
+        *n_keep = nk;
+        for (int i = 0; i < nk; ++i) keep[i] = hk[i];
+        return AZ_OK;
+    }
     if (n > c->nms_cap) {
         HIPCHK(c, hipStreamSynchronize(s));
         if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
@@ -1350,7 +1410,9 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
     }
     int *nk = c->nms_order + c->nms_cap;      // spare int after the order array
     HIPCHK(c, hipMemcpyAsync(c->nms_dets, dets, (size_t)n * 5 * 4, hipMemcpyHostToDevice, s));
-    azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, c->nms_keep, nk);
+    if (!(c->profiling & 4)) clear_events(c);
+    { Timed t(c, "nms", n);
+      azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, c->nms_keep, nk); }
     int h_nk = 0;
     HIPCHK(c, hipMemcpyAsync(&h_nk, nk, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
@@ -1397,11 +1459,12 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
 #undef A
     if (!c->head_loaded) { c->d.C = C; c->d.pooled = 7; c->d.K6 = (int)K6; }
     {
-        float *tmp = nullptr;
+        struct TmpGuard { float *p = nullptr; ~TmpGuard() { if (p) hipFree(p); } } tg;
         size_t te = (size_t)n6 * K6;
         if ((size_t)n7 * n6 > te) te = (size_t)n7 * n6;
         if (NO * n7 > te) te = NO * n7;
-        HIPCHK(c, hipMalloc((void **)&tmp, te * 4));
+        HIPCHK(c, hipMalloc((void **)&tg.p, te * 4));
+        float *tmp = tg.p;
         HIPCHK(c, hipMemcpy(c->dpart, W6, (size_t)n6 * K6 * 4, hipMemcpyHostToDevice));
         azk_permute_k(c->stream, c->dpart, tmp, n6, C, 1);          // bin-major columns, like the AZ head
         azk_tile_weights(c->stream, tmp, c->dW6, n6, (int)K6);
@@ -1414,7 +1477,6 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
         HIPCHK(c, hipMemcpy(tmp + (size_t)ncls * n7, Wb, (size_t)4 * ncls * n7 * 4, hipMemcpyHostToDevice));
         azk_tile_weights(c->stream, tmp, c->dWt, (int)NO, n7);
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipFree(tmp));
     }
     HIPCHK(c, hipMemcpy(c->db6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->db7, b7, (size_t)n7 * 4, hipMemcpyHostToDevice));
@@ -1532,8 +1594,10 @@ int az_nms_batched(az_ctx *c, const float *dets, const int32_t *offsets, int n_g
         HIPCHK(c, hipMemcpyAsync(c->ev_b, offsets, ((size_t)n_groups + 1) * sizeof(int), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->ev_c, small.data(), small.size() * sizeof(int), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemsetAsync(c->ev_e, 0, (size_t)n_groups * sizeof(int), s));
-        azk_nms_small(s, (const float *)c->ev_a, (const int *)c->ev_b, (const int *)c->ev_c, (int)small.size(), thresh,
-                      (long long *)c->ev_d, (int *)c->ev_e);
+        if (!(c->profiling & 4)) clear_events(c);
+        { Timed t(c, "nms_batched", (int)small.size());
+          azk_nms_small(s, (const float *)c->ev_a, (const int *)c->ev_b, (const int *)c->ev_c, (int)small.size(), thresh,
+                        (long long *)c->ev_d, (int *)c->ev_e); }
         std::vector<long long> hk((size_t)total);
         HIPCHK(c, hipMemcpyAsync(hk.data(), c->ev_d, (size_t)total * sizeof(long long), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipMemcpyAsync(n_keep, c->ev_e, (size_t)n_groups * sizeof(int), hipMemcpyDeviceToHost, s));

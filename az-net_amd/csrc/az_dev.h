@@ -219,6 +219,7 @@ void azk_tile_weights(hipStream_t s, const float *rowmajor, float *tiled, int N,
 // many-row shape (az_head12.hip): 12-wave workgroups, one weight tile per <= 12 row strips; same bits as azk_fc_gemm.
 // min_rows > 0: the kernel leaves at once when *Mptr is smaller (a launch whose row count only the device knows is
 // sent to both kernels, azk_fc_gemm with max_strips = (min_rows - 1) / 32).
+int azk_fc_gemm12_prepare();      // per device, with that device current; != 0: keep azk_fc_gemm for every launch
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
                    int K, int S, int Kc, float *part, int min_rows = 0);
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
@@ -275,6 +276,8 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
                    long long *keep, int *nkeep);
 int azk_nms_small_max();
+// one problem of n <= azk_nms_small_max() boxes in one launch (dets / keep / nkeep may be host-mapped)
+void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep);
 #define AZ_TOPK_MAX 4096
 
 // ---- launchers (az_eval.hip): front-end, recall evaluation, threshold tuner ----------------

@@ -397,17 +397,20 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
 
 // One workgroup per CU; the caller knows the row count on the host (a one-pass search's plan) and takes this
 // kernel for many-row launches of layers whose (n-tile, K-chunk) groups fill the chip.
+static size_t lds12_bytes() { return (size_t)(2 * W_BM * W_LDT + 2 * W_BN * W_LDT + 512 * 4) * sizeof(float); }   // + junk slots
+
+// The kernel's 149 KB of dynamic LDS need an opt-in that is recorded per DEVICE: every context calls this once with
+// its device current (az_load_head) and keeps k_fc_splitk for all launches if it fails.
+int azk_fc_gemm12_prepare()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc_splitk12), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds12_bytes()) == hipSuccess ? 0 : -1;
+}
+
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
                    int K, int S, int Kc, float *part, int min_rows)
 {
-    static bool attr = false;
-    const size_t lds = (size_t)(2 * W_BM * W_LDT + 2 * W_BN * W_LDT + 512 * 4) * sizeof(float);   // + junk slots
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc_splitk12), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr = true;
-    }
-    static int grid = -1;
+    static int grid = -1;               // AZ_GEMM12_GRID: an environment switch, the same for every device
     if (grid < 0) { const char *e = getenv("AZ_GEMM12_GRID"); grid = e ? atoi(e) : 256; }
-    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds, s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows);
+    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds12_bytes(), s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows);
 }

@@ -410,14 +410,16 @@ constexpr int NMS_SMALL = 256;
 
 __global__ void __launch_bounds__(256)
 k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const int *__restrict__ gsel,
-            double thresh, long long *__restrict__ keep, int *__restrict__ nkeep)
+            int n_single, double thresh, long long *__restrict__ keep, int *__restrict__ nkeep)
 {
     __shared__ float sd[NMS_SMALL][5];                     // sorted: x1, y1, x2, y2, area
     __shared__ int sorder[NMS_SMALL];
     __shared__ float ss[NMS_SMALL];
     __shared__ unsigned long long smask[NMS_SMALL][NMS_SMALL / 64];
-    const int g = gsel[blockIdx.x];
-    const int o = goff[g], n = goff[g + 1] - o;
+    // (goff == NULL: ONE problem of n_single boxes at dets, results at keep[0..], nkeep[0] -- az_nms's small case,
+    //  where dets / keep / nkeep may be host-mapped memory: each is touched once)
+    const int g = goff ? gsel[blockIdx.x] : 0;
+    const int o = goff ? goff[g] : 0, n = goff ? goff[g + 1] - o : n_single;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *d = dets + 5 * (size_t)o;
     const int i = tid;
@@ -535,7 +537,13 @@ void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int 
                    long long *keep, int *nkeep)
 {
     if (n_sel > 0)
-        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(256), 0, s, dets, goff, gsel, thresh, keep, nkeep);
+        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(256), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep);
+}
+
+void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep)
+{
+    hipLaunchKernelGGL(k_nms_small, dim3(1), dim3(256), 0, s, dets, (const int *)nullptr, (const int *)nullptr, n, thresh,
+                       keep, nkeep);
 }
 
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,

@@ -128,10 +128,14 @@ class DeviceGather(object):
     stream (complete when propose_fetch returns); gather() marks the rows past n_local as padding,
     runs ONE all_gather_into_tensor on the device buffers and unpacks on the host."""
 
-    def __init__(self, ctx, num_proposals, rows, device, group=None):
+    def __init__(self, ctx, num_proposals, rows, device, group=None, always_collective=None):
         import torch
+        import torch.distributed as dist
         from aznet_hip import ffi
         self.ctx, self.k, self.rows, self.group = ctx, int(num_proposals), int(rows), group
+        # a process group of ONE rank still runs the collective (RCCL on the one GPU) unless told otherwise: the
+        # single-GPU run then exercises the code path the 8-GPU run takes
+        self.collective = dist.is_initialized() if always_collective is None else bool(always_collective)
         self.layout = ffi.AzContext.result_record_layout(self.k)
         self.rec_bytes = self.layout[0]
         self.device = device
@@ -152,7 +156,10 @@ class DeviceGather(object):
         import torch.distributed as dist
         if n_local < self.rows:
             self.send[n_local:] = self._pad
-        if self.world > 1:
+        if self.world > 1 or self.collective:
+            # stage() copies ran on the ctx stream and are complete (propose_fetch synchronised it); the pad write
+            # above and the collective are ordered by torch's current stream, which all_gather_into_tensor joins
+            # with RCCL's stream on both sides (async_op=False)
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
             got = self.recv
         else:

@@ -52,7 +52,8 @@ class AzStats(ctypes.Structure):
                 ("level_unique", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("spec_rows", ctypes.c_int32), ("root_deferred", ctypes.c_int32),
-                ("static_plan", ctypes.c_int32)]
+                ("static_plan", ctypes.c_int32), ("n_passes", ctypes.c_int32),
+                ("pass_rows", ctypes.c_int32 * AZ_MAX_LEVELS)]
 
 
 class AzError(RuntimeError):
@@ -297,16 +298,29 @@ class AzContext(object):
             out.append(st)
         return out[0] if len(out) == 1 else tuple(out)
 
-    def propose_launch(self, params, fmap=None, producer_done=False):
+    def wait_event(self, event):
+        """Make the ctx stream wait (on the device, no host synchronisation) for a torch.cuda.Event -- e.g. the one
+        recorded behind the backbone's last kernel on torch's stream."""
+        import torch
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(int(self.L.az_stream(self.h)),
+                                                         device=torch.device("cuda", self.device))
+        self._ext_stream.wait_event(event)
+
+    def propose_launch(self, params, fmap=None, producer_done=False, producer_event=None):
         """fmap (a CUDA torch tensor [1,C,H,W] / [C,H,W] on this GPU): hand the image's map over in the same call
         (az_propose_launch_on); it must stay untouched until propose_fetch returns.  producer_done=True skips the
-        synchronisation of torch's current stream (the caller knows the map is complete)."""
+        synchronisation of torch's current stream (the caller knows the map is complete); producer_event (a
+        torch.cuda.Event recorded behind the map's producer) orders the search behind it ON THE DEVICE instead, so the
+        host can go on and enqueue the next image's backbone while this search runs."""
         self._last_params = params
         if fmap is None:
             self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
             return
         t, cl = self._torch_map(fmap)
-        if not producer_done:
+        if producer_event is not None:
+            self.wait_event(producer_event)
+        elif not producer_done:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
         C, H, W = (int(x) for x in t.shape)

@@ -4,16 +4,21 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one image: az_propose on the cached VGG16 conv5_3
-map (roi projection + dedup, RoIPool, fc head, decode, filter, zoom select, divide_region,
-top-300), 300 proposals copied back to the host.  The conv5_3 map is resident in HBM when
-the timed region starts (it is the hot path's input); the PyTorch backbone is timed
-separately and reported as `end_to_end`.  Images shard one-per-GPU (rank r owns image seed r,
-weak scaling); proposals are exchanged with one RCCL all-gather per batch of images.
+One step = one pass of the hot path over one image: az_propose on the cached VGG16 conv5_3 map -- the level loop
+of lib/detect/test.py:346-414 (roi projection + dedup, RoIPool, fc head, decode, filter, zoom select,
+divide_region, ..., top-300), 300 proposals copied back to the host.  The conv5_3 map is resident in HBM when the
+timed region starts (it is the hot path's input); the PyTorch backbone is timed separately (`end_to_end`).
+`value` is the LEVEL-BY-LEVEL form of the search -- the form every Tz > 0 takes, i.e. what tools/prop_az.py runs
+(cfg_set_mode('Test', Tz), config.py:272-280) -- at the Tz given (default 0: every zoom test passes, the full,
+deterministic tree of SURVEY 8d).  The one-pass form that exists only for Tz <= 0 is reported as `one_pass`.
+Images shard one-per-GPU (rank r owns image seeds r, r + N, ...; weak scaling); proposals are exchanged with one
+RCCL all-gather per batch of images -- also on ONE GPU (a one-rank "nccl" group), so that N = 1 times the same
+code path as N = 8.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the
-dominant kernel (the fp32-MFMA fc GEMM, timed with HIP events on the ctx stream during the
-timed steps) and `cpu_baseline` (the oracle's NumPy/C/BLAS restatement on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (the
+fp32-MFMA fc GEMM, timed with HIP events on the ctx stream during the timed steps) and `cpu_baseline` (the
+oracle's NumPy/C/BLAS restatement on the host cores).  Extra keys: `one_pass`, `calibrated_tz`, `deep_tree`
+(BASELINE config 4), `shared_detection` (config 3), `nms`, `pipelined`, `end_to_end`, `end_to_end_pipelined`.
 """
 import argparse
 import json
@@ -30,12 +35,13 @@ sys.path.insert(0, REPO)
 H_IM, W_IM = 600, 1000
 NUM_PROPOSALS = 300
 # per RoI 216 119 808 FLOP for the whole head = 2*(25088*4096 + 4096*1024 + 4096*256 +
-# 1024*55 + 256).  int6 and int7_1|int7_2 (99.95 % of it) run in the fc GEMM kernel (k_fc_splitk): its
+# 1024*55 + 256).  int6 and int7_1|int7_2 (99.95 % of it) run in the fc GEMM kernels: their
 # algorithmic flops per RoI are 2*(25088*4096 + 4096*1280); the 56-output tail is a vector-ALU kernel.
 HEAD_FLOP_PER_ROI = 216119808
 GEMM_FLOP_PER_ROI = 2 * (25088 * 4096 + 4096 * 1280)
 PEAK_F32_MFMA_TFLOPS = 157.3
 HBM_PEAK = 8.0e12
+VGG16_FLOP_600x1000 = 367.7e9
 
 
 def t_min_us(unique_per_level, fmap_elems):
@@ -71,8 +77,8 @@ def cpu_baseline(head, fmap, Tz, budget_s=20.0):
         times.append(time.time() - t)
     med = float(np.median(times))
     return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(cores), "kind": "port",
-            "sample": "%d images of the same 600x1000 full-tree workload (median %.3f s/image), "
-                      "hot path only (conv5_3 given)" % (len(times), med)}
+            "sample": "%d images of the same 600x1000 workload at Tz=%g (median %.3f s/image), "
+                      "hot path only (conv5_3 given)" % (len(times), Tz, med)}
 
 
 def self_launch(n):
@@ -86,8 +92,9 @@ def self_launch(n):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [a for a in sys.argv[1:] if a != "--launcher"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
     last_json = None
     for line in proc.stdout:
@@ -112,6 +119,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tz", type=float, default=0.0, help="zoom threshold; 0 = full tree (deterministic work)")
     ap.add_argument("--gather-every", type=int, default=8, help="images per rank per RCCL gather")
+    ap.add_argument("--launcher", action="store_true",
+                    help="start the ranks through torch.distributed.run also for --gpus 1 (the plumbing N > 1 uses)")
+    ap.add_argument("--no-rccl", action="store_true", help="single GPU: no process group, no gather in the timed loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--inflight", type=int, default=1,
@@ -119,16 +129,19 @@ def main():
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra images-in-flight measurement")
     ap.add_argument("--no-fast", action="store_true", help="skip the extra split-bf16 (gemm_mode 2) measurement")
-    ap.add_argument("--level-loop", action="store_true",
-                    help="time the level-by-level form of the search (params.reserved bit 5) as the main measurement")
-    ap.add_argument("--no-level-loop", action="store_true", help="skip the extra level-by-level measurement of the same search")
+    ap.add_argument("--one-pass", action="store_true",
+                    help="time the one-pass form (Tz <= 0 only: all levels' rois in one head pass) as the main measurement")
+    ap.add_argument("--level-loop", action="store_true", help="(default since round 3) the level-by-level form is `value`")
+    ap.add_argument("--no-one-pass", action="store_true", help="skip the extra one-pass measurement of the same search")
+    ap.add_argument("--no-level-loop", action="store_true", help="(with --one-pass) skip the extra level-by-level measurement")
     ap.add_argument("--no-calibrated", action="store_true",
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
+    ap.add_argument("--no-extras", action="store_true", help="skip deep_tree / shared_detection / nms")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.launcher) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: start the N ranks as fresh processes (one per GPU, RCCL) BEFORE this
         # process touches the GPU, relay rank 0's JSON line and exit with the launcher's code.
         sys.exit(self_launch(args.gpus))
@@ -136,7 +149,7 @@ def main():
     import torch
     import torch.distributed as dist
     from aznet_hip import ffi, synth
-    from aznet_hip.net import HipAZNet
+    from aznet_hip.net import HipAZNet, HipDetNet
     from aznet_hip.backbone import VGG16Conv5
     from aznet_hip import dist as azdist
 
@@ -146,9 +159,26 @@ def main():
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # The exchange step runs over RCCL whatever N is: under a launcher the rendezvous comes from the environment;
+    # a bare `python bench.py` (N = 1) makes a one-rank group on 127.0.0.1.  If that cannot be built on this box
+    # the single-GPU run goes on without the gather and says so in the line.
+    rccl = {"backend": None, "collectives": 0}
+    if world > 1 or "WORLD_SIZE" in os.environ:
         dist.init_process_group("nccl", device_id=dev)
+        rccl["backend"] = "nccl"
+    elif not args.no_rccl:
+        try:
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+            rccl["backend"] = "nccl"
+        except Exception as e:                                 # noqa: BLE001 -- reported, never hidden
+            rccl["error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+    dist_on = rccl["backend"] is not None
 
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
     backbone = VGG16Conv5(device=dev, seed=4321)
@@ -161,18 +191,31 @@ def main():
     blob, scales = _get_image_blob(im, net)                  # HIP front-end kernel -> CUDA tensor
     backbone.normalize_output(blob)                          # random-init weights: unit-RMS conv5_3
     # resident in HBM from here on, channel-last (what the backbone hands over with channels_last_out=True)
-    convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone().contiguous(memory_format=torch.channels_last) for x in ims]
+    blobs = [_get_image_blob(x, net)[0] for x in ims]
+    convs = [net.compute_conv(b).clone().contiguous(memory_format=torch.channels_last) for b in blobs]
     conv = convs[0]
     net.set_conv(conv)
-    params = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS,
-                                       static_tree=not args.level_loop)
+    scale0 = float(scales[0])
+    one_pass_main = bool(args.one_pass) and args.tz <= 0.0
+
+    def mk(static):
+        return ffi.AzContext.make_params(H_IM, W_IM, scale0, args.tz, num_proposals=NUM_PROPOSALS, static_tree=static)
+
+    params = mk(one_pass_main)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev) if world > 1 else None
+    def maxr(x):
+        if world > 1:
+            tt = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev) if dist_on else None
     pending = [0]
     # extra contexts for pipelining independent images on one GPU (same weights, same map)
     nets = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
@@ -183,18 +226,19 @@ def main():
     def finish(last):
         """One image done; every gather_every images per rank (and at the end): ONE RCCL all-gather of the
         records staged device-to-device by the searches, then the host copy of all ranks' proposals."""
-        if world > 1:
+        if gat is not None:
             pending[0] += 1
             if pending[0] == args.gather_every or last:
                 res = gat.gather(pending[0])
                 assert len(res) == world * pending[0]
                 pending[0] = 0
+                rccl["collectives"] += 1
 
-    def run(nsteps, timed):
+    def run(nsteps, prm):
         if args.inflight == 1:
             for i in range(nsteps):
-                # this step's image: its map is handed over (one transpose kernel) with the launch
-                net.ctx.propose_launch(params, fmap=convs[i % len(convs)], producer_done=True)
+                # this step's image: its map is handed over with the launch
+                net.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
                 if gat is not None:
                     gat.stage(pending[0])
                 net.ctx.propose_fetch(want_scores=True)
@@ -206,28 +250,34 @@ def main():
             n = nets[i % len(nets)]
             if len(q) == len(nets):
                 q.pop(0).ctx.propose_fetch(want_scores=True)
-            n.ctx.propose_launch(params, fmap=convs[i % len(convs)], producer_done=True)
+            n.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
             q.append(n)
         for m in q:
             m.ctx.propose_fetch(want_scores=True)
 
-    # one-time initialisation per image shape (the search's shape-dependent plan, first-use allocations): not a step
-    for n in nets:
+    # one-time initialisation per image shape (the search's shape-dependent pre-pass / plan, first-use allocations): not
+    # a step, but timed and reported (`plan_build_ms`)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net.propose(params)
+    first_ms = (time.perf_counter() - t0) * 1e3
+    for n in nets[1:]:
         n.propose(params)
-    run(args.warmup, False)
+    run(args.warmup, params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net.propose(params)
+    steady_ms = (time.perf_counter() - t0) * 1e3
     pending[0] = 0
+    rccl["collectives"] = 0
     for n in nets:
         n.ctx.set_profiling(0)
         n.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
     barrier()
     t0 = time.perf_counter()
-    run(args.steps, True)
+    run(args.steps, params)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = maxr(time.perf_counter() - t0)
     ktimes = []
     for n in nets:
         ktimes += n.ctx.last_kernel_times()
@@ -236,7 +286,15 @@ def main():
     Y, S, st = net.propose(params, want_scores=True, want_stats=True)
     uniq = [int(st.level_unique[l]) for l in range(st.n_levels)]
     regions = [int(st.level_regions[l]) for l in range(st.n_levels)]
-    spec_rows = int(st.spec_rows)      # root + its children + ALL children of those (one pass serves levels 1-3)
+    spec_rows = int(st.spec_rows)
+    fmap_elems = int(conv.numel())
+
+    def rows_per_pass(s):
+        """rows of the head passes of a level-by-level search, from its stats (see az_stats in include/aznet_hip.h)"""
+        try:
+            return [int(x) for x in list(s.pass_rows)[:int(s.n_passes)]]
+        except AttributeError:
+            return None
 
     out = None
     if rank == 0:
@@ -260,15 +318,21 @@ def main():
                                   % tj.get("source", "committed summary"))
             except Exception:
                 traffic = None
-        # the three int6 launch shapes, each against ITS bound: max(weights / 8 TB/s, flops / 157.3 TF)
+        # the int6 launch shapes, each against ITS bound: max(weights / 8 TB/s, flops / 157.3 TF)
         fc6 = {}
         for n, l, ms in ktimes:
             if n == "fc6_gemm":
                 fc6.setdefault(l, []).append(ms)
+        prow = rows_per_pass(st)
         fc6_shapes = []
-        for l, v in sorted(fc6.items()):
-            rows = spec_rows if l < 0 else uniq[l] + (1 if (st.root_deferred and l == 3) else 0)
-            label = ("all levels (one pass)" if st.static_plan else "speculative 1-3") if l < 0 else l + 1
+        for pi, (l, v) in enumerate(sorted(fc6.items())):
+            if st.static_plan:
+                rows, label = spec_rows, "all levels (one pass)"
+            elif prow is not None and pi < len(prow):
+                rows, label = prow[pi], ("pass %d (first level %s)" % (pi + 1, "2" if l < 0 else str(l + 1)))
+            else:
+                rows = spec_rows if l < 0 else uniq[l] + (1 if (st.root_deferred and l == 3) else 0)
+                label = "speculative 1-3" if l < 0 else l + 1
             t_us = float(np.mean(v)) * 1e3
             fl = rows * 2.0 * 25088 * 4096
             tmin = max(25088 * 4096 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
@@ -277,7 +341,9 @@ def main():
         per_level = {}
         for n, l, ms in ktimes:
             per_level.setdefault("%s@L%d" % (n, l + 1), []).append(ms)
-        floor_us = t_min_us(uniq, int(conv.numel()))
+        floor_us = t_min_us(uniq, fmap_elems)
+        form = ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows) if st.static_plan else \
+               ("level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
         out = {
             "metric": "AZ proposals/sec (600x1000 img)", "value": value, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -286,70 +352,88 @@ def main():
             "config": {"workload": "VGG16 AZ proposal hot path, 600x1000 image (scale 1.0), batch=1 per GPU, "
                                    "Tz=%g, regions/level %s, unique RoIs/level %s (%s), top-%d of %d candidates; "
                                    "conv5_3 %s resident in HBM, %d distinct images rotated" %
-                                   (args.tz, regions, uniq,
-                                    ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows)
-                                    if st.static_plan else
-                                    ("levels 1-3 in one %d-row pass%s" % (spec_rows, ", the root's row on level 4's" if st.root_deferred else "")),
-                                    NUM_PROPOSALS, st.n_candidates,
+                                   (args.tz, regions, uniq, form, NUM_PROPOSALS, st.n_candidates,
                                     [int(x) for x in conv.shape], len(convs)),
+                       "search_form": "one_pass" if st.static_plan else "level_loop",
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
-                       "gather": ("RCCL all_gather every %d images/rank" % args.gather_every) if world > 1 else "none"},
+                       "gather": ("RCCL all_gather every %d images/rank (in the timed loop)" % args.gather_every)
+                                 if gat is not None else "none"},
+            "rccl": dict(rccl, world=world,
+                         note="one process per GPU; a one-rank group still builds an RCCL communicator and runs the "
+                              "all-gather on the GPU, so N = 1 times the code path of N = 8"),
             "roofline": {"bound": "mfma",
-                         "kernel": ("k_fc_splitk12 (int6, many-row tiles) + k_fc_splitk (int7_1|int7_2); v_mfma_f32_32x32x2_f32"
-                                    if (st.static_plan and spec_rows >= 257) else
-                                    "k_fc_splitk (int6, int7_1|int7_2; v_mfma_f32_32x32x2_f32)"),
+                         "kernel": "fc GEMMs of the head passes: k_fc_splitk12 (int6 at >= 161 / 257 rows) and k_fc_splitk "
+                                   "(int6 below, int7_1|int7_2); v_mfma_f32_32x32x2_f32",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "flops_per_launch": flops_per_image / (n_launch / max(args.steps, 1)),
                          "avg_launch_ms": gemm_ms_total / n_launch,
                          "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic,
-                         "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes},
+                         "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes,
+                         "note": "achieved = ALGORITHMIC flops (unique RoIs of the tree x 216 006 656) / time inside the "
+                                 "fc GEMM launches (HIP events on the ctx stream); speculative rows that the tree did "
+                                 "not need are work done but not counted"},
             "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
                            "frac": floor_us / (ms_step * 1e3),
-                           "note": "t_min = BASELINE.md section 3: sum over the levels of max(bytes / 8 TB/s, flops / 157.3 TF)"
-                                   + ("; with all levels in one head pass the weights stream once, so the floor of the "
-                                      "launches actually made is one_pass_t_min_us" if st.static_plan else ""),
-                           "one_pass_t_min_us": t_min_us([sum(uniq)], int(conv.numel())) if st.static_plan else None},
+                           "note": "t_min = BASELINE.md section 3: sum over the levels of max(bytes / 8 TB/s, flops / 157.3 TF)"},
+            "plan_build_ms": {"first_call_ms": first_ms, "steady_call_ms": steady_ms, "one_time_ms": max(first_ms - steady_ms, 0.0),
+                              "note": "one-time work per image shape (shape-dependent pre-pass / plan, first-use allocations), "
+                                      "done before the warm-up and not part of `value`"},
             "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in sorted(per_level.items())},
         }
-    # ---- the same search walked level by level (what any Tz > 0 does; here with every zoom test passing) ----------
-    if st.static_plan and not args.no_level_loop:
-        pl = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), args.tz, num_proposals=NUM_PROPOSALS, static_tree=False)
-        n_l = max(20, args.steps // 2)
 
-        def runl(k):
+    def timed_loop(fn, n, warm=10):
+        fn(warm)
+        barrier()
+        t = time.perf_counter()
+        fn(n)
+        barrier()
+        return maxr(time.perf_counter() - t)
+
+    def simple_run(prm, ctxnet=None):
+        cn = ctxnet or net
+
+        def f(k):
             for i in range(k):
-                net.ctx.propose_launch(pl, fmap=convs[i % len(convs)], producer_done=True)
-                net.ctx.propose_fetch(want_scores=True)
-        runl(10)
-        barrier()
-        t0 = time.perf_counter()
-        runl(n_l)
-        barrier()
-        dl = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dl], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dl = float(tt.item())
-        net.set_conv(conv)             # same image as Y / S above
-        Yl, Sl, stl = net.propose(pl, want_scores=True, want_stats=True)
-        assert np.array_equal(Yl, Y) and np.array_equal(Sl, S), "level loop and one-pass plan disagree"
+                cn.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
+                cn.ctx.propose_fetch(want_scores=True)
+        return f
+
+    # ---- the same search in its other form (bit-identical results are asserted) ------------------------------------
+    other_wanted = (args.tz <= 0.0) and not (args.no_level_loop if one_pass_main else args.no_one_pass)
+    if other_wanted:
+        po = mk(not one_pass_main)
+        n_o = max(20, args.steps // 2)
+        net.propose(po)
+        d_o = timed_loop(simple_run(po), n_o)
+        net.set_conv(conv)
+        Yo, So, sto = net.propose(po, want_scores=True, want_stats=True)
+        assert np.array_equal(Yo, Y) and np.array_equal(So, S), "level loop and one-pass plan disagree"
         if rank == 0:
-            rows_l = [int(stl.spec_rows)] + [int(stl.level_unique[l]) + (1 if (stl.root_deferred and l == 3) else 0)
-                                             for l in range(3, stl.n_levels)]
-            out["level_loop"] = {"value": world * NUM_PROPOSALS * n_l / dl, "unit": "proposals/s",
-                                 "ms_per_image": dl / n_l * 1e3, "head_passes": len(rows_l), "rows_per_pass": rows_l,
-                                 "note": "same image, same Tz, params.reserved bit 5: the tree walked level by level "
-                                         "(speculative pass for levels 1-3, then one head pass + geometry kernel per level) -- "
-                                         "the form every Tz > 0 search takes; proposals and scores bit-identical to `value`'s"}
-    # ---- same work with two images in flight per GPU (two contexts / streams), for context ------
+            uo = [int(sto.level_unique[l]) for l in range(sto.n_levels)]
+            if one_pass_main:
+                out["level_loop"] = {"value": world * NUM_PROPOSALS * n_o / d_o, "unit": "proposals/s",
+                                     "ms_per_image": d_o / n_o * 1e3, "rows_per_pass": rows_per_pass(sto),
+                                     "path_floor_frac": t_min_us(uo, fmap_elems) / (d_o / n_o * 1e6),
+                                     "note": "same image, same Tz, walked level by level; bit-identical to `value`'s"}
+            else:
+                out["one_pass"] = {"value": world * NUM_PROPOSALS * n_o / d_o, "unit": "proposals/s",
+                                   "ms_per_image": d_o / n_o * 1e3, "rows": int(sto.spec_rows),
+                                   "path_floor_frac": t_min_us(uo, fmap_elems) / (d_o / n_o * 1e6),
+                                   "one_pass_t_min_us": t_min_us([sum(uo)], fmap_elems),
+                                   "note": "Tz <= 0 ONLY (the reference's TRAIN-phase setting, config.py:275): every zoom test "
+                                           "passes, the tree is a function of the image shape, all levels' rois go through "
+                                           "ONE head pass (az_static.hip); proposals and scores bit-identical to `value`'s. "
+                                           "No Tz > 0 search can take this form."}
+    # ---- same work with three images in flight per GPU (three contexts / streams), for context ------
     if not args.no_pipelined and args.inflight == 1:
-        NFL = 3                                   # images in flight (2: +7 %, 3: +11 %, 4: no more)
+        NFL = 3
         nets2 = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
                          for _ in range(NFL - 1)]
         for n in nets2[1:]:
             n.set_conv(conv)
+            n.propose(params)
         n_p = max(20, args.steps // 2)
 
         def run2(k):
@@ -362,16 +446,7 @@ def main():
                 q.append(n)
             for m in q:
                 m.ctx.propose_fetch()
-        run2(10)
-        barrier()
-        t0 = time.perf_counter()
-        run2(n_p)
-        barrier()
-        dp = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dp], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dp = float(tt.item())
+        dp = timed_loop(run2, n_p)
         if rank == 0:
             out["pipelined"] = {"value": world * NUM_PROPOSALS * n_p / dp, "unit": "proposals/s",
                                 "ms_per_image": dp / n_p * 1e3, "images_in_flight_per_gpu": NFL,
@@ -379,77 +454,55 @@ def main():
                                         "geometry kernels of one image hide under the other's GEMMs"}
         del nets2[1:]
     # ---- opt-in fast mode: int6 on the bf16 matrix cores, fp32 operands split in two bf16 terms ----
-    if not args.no_fast and ffi.AzContext.make_params and net.ctx.gemm_mode == 0:
-        nf = [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=2)
-              for _ in range(2)]
-        for n in nf:
-            n.set_conv(conv)
+    if not args.no_fast and net.ctx.gemm_mode == 0:
+        nf = HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=2)
+        nf.set_conv(conv)
+        nf.propose(params)
         n_f = max(20, args.steps // 2)
-        for _ in range(10):
-            nf[0].propose(params)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n_f):
-            nf[0].propose(params)
-        barrier()
-        d1 = time.perf_counter() - t0
-
-        def runf(k):
-            q = []
-            for i in range(k):
-                n = nf[i % 2]
-                if len(q) == 2:
-                    q.pop(0).ctx.propose_fetch()
-                n.ctx.propose_launch(params)
-                q.append(n)
-            for m in q:
-                m.ctx.propose_fetch()
-        runf(10)
-        barrier()
-        t0 = time.perf_counter()
-        runf(n_f)
-        barrier()
-        d2 = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([d1, d2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            d1, d2 = float(tt[0].item()), float(tt[1].item())
+        d1 = timed_loop(simple_run(params, nf), n_f)
         if rank == 0:
             out["split_bf16_mode"] = {
                 "value": world * NUM_PROPOSALS * n_f / d1, "unit": "proposals/s", "ms_per_image": d1 / n_f * 1e3,
-                "pipelined_value": world * NUM_PROPOSALS * n_f / d2, "pipelined_ms_per_image": d2 / n_f * 1e3,
                 "dtype": "bf16x3 (az_set_gemm_mode 2: int6 operands as two bf16 terms, 3 bf16 MFMAs per "
                          "product, fp32 accumulate)",
-                "note": "opt-in; scores / box deltas stay within 1e-5 of the fp32 path (tolerance 1e-4)"}
+                "note": "opt-in, NOT the reference's fp32 arithmetic: earns no credit; scores / box deltas stay within "
+                        "1e-5 of the fp32 path (tolerance 1e-4)"}
         del nf
     # ---- a data-dependent tree: Tz = the median zoom score over the full tree's regions ----------
     if not args.no_calibrated:
-        net.propose(ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), 0.0, num_proposals=NUM_PROPOSALS, tune=True))
+        net.set_conv(conv)
+        net.propose(ffi.AzContext.make_params(H_IM, W_IM, scale0, 0.0, num_proposals=NUM_PROPOSALS, tune=True))
         zz = net.ctx.last_anchors()[1].astype(np.float64)
-        n3 = int(sum(regions[:3]))                      # root + its children + their children
+        full_regions = regions if args.tz <= 0 else [1, 8, 32]
+        n3 = int(sum(full_regions[:3]))                 # root + its children + their children
         tz_c = float(np.quantile(zz[1:n3], 0.5))        # (untrained weights: scores drift with region size,
                                                         #  so the threshold is set where the tree branches)
-        pc = ffi.AzContext.make_params(H_IM, W_IM, float(scales[0]), tz_c, num_proposals=NUM_PROPOSALS)
+        pc = ffi.AzContext.make_params(H_IM, W_IM, scale0, tz_c, num_proposals=NUM_PROPOSALS)
         Yc, stc = net.propose(pc, want_stats=True)
-        for _ in range(5):
-            net.propose(pc)
-        barrier()
+
+        def runc(k):
+            for _ in range(k):
+                net.propose(pc)
         n_c = max(10, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(n_c):
-            net.propose(pc)
-        barrier()
-        dc = time.perf_counter() - t0
+        dc = timed_loop(runc, n_c, warm=5)
         if rank == 0:
+            uc = [int(stc.level_unique[l]) for l in range(stc.n_levels)]
+            fl_c = t_min_us(uc, fmap_elems)
             out["calibrated_tz"] = {
                 "Tz": tz_c, "value": world * Yc.shape[0] * n_c / dc, "unit": "proposals/s",
                 "ms_per_image": dc / n_c * 1e3,
                 "regions_per_level": [int(stc.level_regions[l]) for l in range(stc.n_levels)],
-                "unique_per_level": [int(stc.level_unique[l]) for l in range(stc.n_levels)],
+                "unique_per_level": uc, "rows_per_pass": rows_per_pass(stc),
+                "path_floor": {"t_min_us_per_image": fl_c, "frac": fl_c / (dc / n_c * 1e6)},
                 "note": "same image and weights, zoom threshold at the median zoom score of the regions of levels "
                         "2-3: a partially expanded, data-dependent tree"}
+    # ---- BASELINE configs 3 and 4 and the NMS kernel under this run's clock (kernel time from HIP events) -----------
+    if not args.no_extras and rank == 0:
+        out.update(extras(net, head, ffi, synth, HipDetNet, torch, args))
+        net.set_conv(conv)
     # ---- backbone + hot path, for context (not `value`) -----------------------------------
     if not args.no_e2e:
+        net.set_conv(conv)
         for _ in range(3):
             net.compute_conv(blob)
         barrier()
@@ -459,7 +512,7 @@ def main():
             net.compute_conv(blob)
             net.propose(params)
         barrier()
-        de = time.perf_counter() - t0
+        de = maxr(time.perf_counter() - t0)
         # ... and from the uint8 host image: PCIe upload + the HIP front-end kernel (mean, resize, CHW)
         t0 = time.perf_counter()
         for _ in range(n_e2e):
@@ -467,24 +520,149 @@ def main():
             net.compute_conv(b2)
             net.propose(params)
         barrier()
-        di = time.perf_counter() - t0
+        di = maxr(time.perf_counter() - t0)
+        # backbone alone
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            backbone(blob)
+        barrier()
+        db = maxr(time.perf_counter() - t0)
+        # ... and overlapped: image i+1's backbone on torch's stream while image i's search runs on the ctx stream,
+        # ordered on the device by an event (no host synchronisation between the two)
+        bb_cl = VGG16Conv5(device=dev, seed=4321, channels_last_out=True)
+        bb_cl.layers = backbone.layers
+
+        def run_e2e_pipe(k):
+            nxt = bb_cl(blobs[0])
+            ev = torch.cuda.Event()
+            ev.record()
+            for i in range(k):
+                cur, evc = nxt, ev
+                net.ctx.propose_launch(params, fmap=cur, producer_event=evc)
+                nxt = bb_cl(blobs[(i + 1) % len(blobs)])          # enqueued while the search runs
+                ev = torch.cuda.Event()
+                ev.record()
+                net.ctx.propose_fetch(want_scores=True)
+            torch.cuda.synchronize()
+        dpp = timed_loop(run_e2e_pipe, n_e2e, warm=3)
         if rank == 0:
             out["end_to_end"] = {"value": world * NUM_PROPOSALS * n_e2e / de, "unit": "proposals/s",
                                  "ms_per_image": de / n_e2e * 1e3,
                                  "from_host_image_value": world * NUM_PROPOSALS * n_e2e / di,
                                  "from_host_image_ms": di / n_e2e * 1e3,
+                                 "backbone_ms": db / n_e2e * 1e3,
+                                 "backbone_tflops": VGG16_FLOP_600x1000 / (db / n_e2e) / 1e12,
                                  "note": "adds the fp32 PyTorch-ROCm VGG16 conv1_1..conv5_3 forward (367.7 GFLOP); "
                                          "from_host_image also uploads the uint8 image over PCIe and runs the "
                                          "front-end kernel (az_image_blob_dev)"}
+            out["end_to_end_pipelined"] = {
+                "value": world * NUM_PROPOSALS * n_e2e / dpp, "unit": "proposals/s", "ms_per_image": dpp / n_e2e * 1e3,
+                "note": "backbone of image i+1 (torch stream, channels-last output borrowed in place) overlapped with the "
+                        "search of image i (ctx stream); the hand-over is an event wait on the device"}
     if rank == 0 and not args.no_cpu_baseline:
         fm = conv.detach().cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(head, fm, args.tz)
         out["gpu_over_cpu"] = out["value"] / world / out["cpu_baseline"]["value"]
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def extras(net, head, ffi, synth, HipDetNet, torch, args):
+    """deep_tree (BASELINE config 4), shared_detection (config 3) and az_nms at SURVEY 8(d)'s sizes, each with the
+    kernel time of its launches from HIP events on the ctx stream (az_set_profiling) next to the wall clock through
+    the C ABI."""
+    res = {}
+    ctx = net.ctx
+
+    def wall(f, n, warm=3):
+        for _ in range(warm):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def kernel_ms(f, n):
+        """sum of the HIP-event times of every launch group of one call, averaged over n calls"""
+        ctx.set_profiling(0)
+        ctx.set_profiling(2 | 4)
+        for _ in range(n):
+            f()
+        kt = ctx.last_kernel_times()
+        ctx.set_profiling(0)
+        by = {}
+        for nm, l, ms in kt:
+            by[nm] = by.get(nm, 0.0) + ms / n
+        return sum(by.values()), by
+
+    # ---- config 4: 800x1200 original (scale 0.75 -> 600x900 input), K = 7 --------------------------------------
+    fmap = synth.make_feature_map(4, 512, synth.conv_out_size(600), synth.conv_out_size(900))
+    net.set_conv(fmap)
+    n_img = max(10, min(40, args.steps // 5))
+    for form, static in (("level_loop", False), ("one_pass", True)):
+        p = ffi.AzContext.make_params(800, 1200, 0.75, 0.0, static_tree=static)
+        Yd, std = net.propose(p, want_stats=True)
+        ms = wall(lambda: net.propose(p), n_img)
+        ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
+        fl = t_min_us(ud, int(fmap.size))
+        kms, by = kernel_ms(lambda: net.propose(p), 5)
+        d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor_frac": fl / (ms * 1e3),
+             "kernel_ms_per_image": kms}
+        if form == "level_loop":
+            res["deep_tree"] = dict(d, workload="BASELINE config 4: 800x1200 image (scale 0.75), K = 7, Tz = 0",
+                                    regions_per_level=[int(std.level_regions[l]) for l in range(std.n_levels)],
+                                    unique_per_level=ud, candidates=int(std.n_candidates),
+                                    form="level by level (what a Tz > 0 search takes)")
+        else:
+            res["deep_tree"]["one_pass"] = d
+    # ---- config 3: AZ proposals + Fast R-CNN head (fc6/fc7 4096, 21 classes) + per-class NMS on the shared map -------
+    fmap = synth.make_feature_map(4, 512, 38, 63)
+    net.set_conv(fmap)
+    p = ffi.AzContext.make_params(H_IM, W_IM, 1.0, 0.0, static_tree=False)
+    Yp = net.propose(p)
+    det = HipDetNet(synth.make_det_head(seed=99), net)
+
+    def det_call():
+        return det.detect(Yp, 1.0, (H_IM, W_IM), 1. / 16., 10000, 1e-14)
+    sc, bx = det_call()
+    # apply_nms's input (test.py:730-770): per class the boxes above the score threshold, <= 100 per class
+    groups = []
+    for c in range(1, sc.shape[1]):
+        o = np.argsort(-sc[:, c])[:100]
+        groups.append(np.hstack([bx[o, 4 * c:4 * c + 4], sc[o, c:c + 1]]).astype(np.float32))
+    ms_prop = wall(lambda: net.propose(p), n_img)
+    ms_det = wall(det_call, n_img)
+    ms_nms = wall(lambda: ctx.nms_batched(groups, 0.3), n_img)
+    k_det, by_det = kernel_ms(det_call, 5)
+    k_nms, _ = kernel_ms(lambda: ctx.nms_batched(groups, 0.3), 5)
+    res["shared_detection"] = {
+        "workload": "BASELINE config 3: az_propose (level loop) + az_detect on its 300 proposals (fc6/fc7 4096, 21 classes) + "
+                    "az_nms_batched (20 classes x 100 boxes, thresh 0.3), 600x1000",
+        "az_propose_ms": ms_prop, "az_detect_ms": ms_det, "nms_batched_ms": ms_nms,
+        "images_per_s": 1e3 / (ms_prop + ms_det + ms_nms),
+        "az_detect_kernel_ms": k_det, "nms_batched_kernel_ms": k_nms,
+        "az_detect_kernels_ms": {k: round(v, 4) for k, v in sorted(by_det.items())}}
+    # ---- az_nms (lib/utils/nms.pyx), uniform boxes, distinct scores, thresh 0.5 ------------------------------------
+    rng = np.random.RandomState(0)
+    nms = {}
+    for n in (100, 300, 2000, 8129):
+        x1 = rng.uniform(0, 900, n)
+        y1 = rng.uniform(0, 500, n)
+        dets = np.stack([x1, y1, x1 + rng.uniform(10, 210, n), y1 + rng.uniform(10, 210, n),
+                         rng.permutation(n) / float(n)], 1).astype(np.float32)
+        w = wall(lambda: ctx.nms(dets, 0.5), 20)
+        km, _ = kernel_ms(lambda: ctx.nms(dets, 0.5), 10)
+        # HBM-side bytes of the kernels: 20 B/box in, the N^2/8-byte suppression matrix written and read once
+        alg = 20.0 * n + (0 if n <= 256 else 2.0 * n * ((n + 63) // 64) * 8)
+        nms[str(n)] = {"wall_ms_incl_copies": w, "kernel_ms": km, "kept": int(len(ctx.nms(dets, 0.5))),
+                       "algorithmic_bytes": alg, "gb_per_s": alg / (km * 1e-3) / 1e9 if km > 0 else None}
+    res["nms"] = nms
+    return res
 
 
 if __name__ == "__main__":

@@ -88,6 +88,8 @@ typedef struct {
                                              (spec_rows excludes it, level 4 evaluated one more row) */
     int32_t static_plan;                  /* 1: Tz <= 0, all levels went through one head pass of
                                              spec_rows rois (params.reserved bit 5 turns this off)  */
+    int32_t n_passes;                     /* head passes (RoIPool -> int6 -> int7 -> heads) the search made */
+    int32_t pass_rows[AZ_MAX_LEVELS];     /* rois each of them evaluated (speculative rows included)       */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */

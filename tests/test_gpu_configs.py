@@ -1,0 +1,123 @@
+"""Full-head parity against the PURE-CPU oracle for the configurations of BASELINE.json other than config A
+(which tests/test_gpu_fullsize.py covers):
+
+  * config 4 -- 800x1200 image (scale 0.75 -> 600x900 network input, conv5_3 38x57), K = 7, regions / level
+    [1, 8, 32, 128, 512, 2048]: Tz = 0 in the one-pass form and level by level, and a calibrated Tz;
+  * images that are rescaled on the way in: 375x500 at scale 1.6 and 480x640 at 1.25 (lib/detect/test.py:27-59,
+    61-97: the search runs in original-image pixels, only the rois are scaled);
+  * experiments/cfgs/voc.yml:13-17 -- TEST.MAX_SIZE 800 (scale = min(600 / short, 800 / long)) and
+    SEAR.BATCH_SIZE 1000 (dedup per chunk of 1000 regions, test.py:202-218): 600x1000 at 0.8 and the deep tree
+    at 2/3, whose last level is three chunks.
+
+Each case: head = synth FULL_DIMS (25088 -> 4096 -> {1024 -> 11 + 44, 256 -> 1}), az_propose vs oracle.im_propose
+driven by the oracle's own RoIPool + BLAS head.  Tree structure (regions, unique rois, zoom sets per level) exact;
+scores 1e-4; boxes 1e-4 relative (2e-2 px absolute); every reference proposal that clears the 300th score by more
+than the tolerance is returned."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    from oracle import az_oracle as orc
+    return ffi, synth, HipAZNet, orc
+
+
+@pytest.fixture(scope="module")
+def full(mods):
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+    return HipAZNet(head, name="full_cfg", max_regions=4096), head
+
+
+def _calibrated_tz(zs, q):
+    """A threshold near quantile q of the CPU zoom scores with a gap of >= 2e-3 around it: fp32 summation-order
+    differences between the GPU and the BLAS oracle cannot flip a zoom decision."""
+    zs = np.sort(np.asarray(zs, dtype=np.float64))
+    k = int(q * (len(zs) - 1))
+    for j in list(range(k, len(zs) - 1)) + list(range(k - 1, 0, -1)):
+        if zs[j + 1] - zs[j] > 2e-3:
+            return 0.5 * (zs[j] + zs[j + 1])
+    raise AssertionError("no gap in the zoom scores")
+
+
+def _clear_of_tz(tr, Tz, margin=2e-4):
+    """every zoom score the oracle compared is at least `margin` away from Tz"""
+    z = np.concatenate([lv["zoom"] for lv in tr["levels"]])
+    return np.abs(z - Tz).min() > margin
+
+
+CASES = [
+    # name, H, W, scale, cfg overrides, mode
+    ("cfg4_tz0_one_pass", 800, 1200, 0.75, {}, "tz0"),
+    ("cfg4_tz0_level_loop", 800, 1200, 0.75, {}, "tz0_level_loop"),
+    ("cfg4_calibrated", 800, 1200, 0.75, {}, "calibrated"),
+    ("375x500_at_1.6_tz0", 375, 500, 1.6, {}, "tz0"),
+    ("375x500_at_1.6_calibrated", 375, 500, 1.6, {}, "calibrated"),
+    ("480x640_at_1.25_tz0_level_loop", 480, 640, 1.25, {}, "tz0_level_loop"),
+    ("480x640_at_1.25_calibrated", 480, 640, 1.25, {}, "calibrated"),
+    ("voc_yml_600x1000", 600, 1000, 0.8, {"BATCH_SIZE": 1000}, "calibrated"),
+    ("voc_yml_deep_tree_chunked", 800, 1200, 2.0 / 3.0, {"BATCH_SIZE": 1000}, "tz0"),
+    ("voc_yml_deep_tree_chunked_level_loop", 800, 1200, 2.0 / 3.0, {"BATCH_SIZE": 1000}, "tz0_level_loop"),
+]
+
+
+@pytest.mark.parametrize("name,H,W,scale,over,mode", CASES, ids=[c[0] for c in CASES])
+def test_full_head_vs_pure_cpu_oracle(full, mods, name, H, W, scale, over, mode):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = full
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    fmap = synth.make_feature_map(31, 512, fh, fw)
+    net.set_conv(fmap)
+    onet = orc.OracleNet(head, feat_fn=lambda d: fmap)
+    nets = {"full": onet, "fc": onet}
+    Tz = 0.0
+    if mode == "calibrated":
+        _, tr0 = orc.im_propose(nets, (H, W), scale, orc.OracleCfg(Tz=0.0, **over), return_trace=True)
+        pool = np.concatenate([lv["zoom"][1:] if i == 0 else lv["zoom"] for i, lv in enumerate(tr0["levels"][:3])])
+        for q in (0.5, 0.4, 0.3, 0.2, 0.1, 0.05, 0.6):
+            Tz = _calibrated_tz(pool, q)
+            _, trq = orc.im_propose(nets, (H, W), scale, orc.OracleCfg(Tz=Tz, **over), return_trace=True)
+            # (a tree worth the name: it reaches the fourth level and is pruned somewhere)
+            if _clear_of_tz(trq, Tz) and len(trq["levels"]) >= 4 and trq["levels"][3]["B"].shape[0] > 0:
+                break
+        else:
+            raise AssertionError("no threshold clear of every zoom score")
+    Yref, tr = orc.im_propose(nets, (H, W), scale, orc.OracleCfg(Tz=Tz, **over), return_trace=True)
+    batch = over.get("BATCH_SIZE", 10000)
+    p = ffi.AzContext.make_params(H, W, scale, Tz, batch_size=batch, static_tree=(mode != "tz0_level_loop"))
+    Y, S, st = net.propose(p, want_scores=True, want_stats=True)
+    assert st.static_plan == (1 if mode == "tz0" else 0)
+    # tree (integer work: exact)
+    assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
+    assert st.n_levels >= len(tr["levels"])
+    for l, lev in enumerate(tr["levels"]):
+        assert st.level_regions[l] == lev["B"].shape[0], (l, st.level_regions[l], lev["B"].shape[0])
+        assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"]), l
+        assert st.level_zoomed[l] == len(lev["indZ"]), l
+    if mode != "calibrated" and (H, W) == (800, 1200):
+        assert [int(st.level_regions[l]) for l in range(6)] == [1, 8, 32, 128, 512, 2048]
+    if mode == "calibrated":
+        assert st.num_eval < sum(lv["B"].shape[0] for lv in tr0["levels"])     # a partially expanded tree
+    if over.get("BATCH_SIZE") and (H, W) == (800, 1200):
+        assert len(tr["levels"][-1]["fwd"]) == 3              # the last level went through the net in three chunks
+    # candidates in the reference's order
+    Yall, Sall = net.ctx.last_candidates()
+    assert Yall.shape == tr["Y_all"].shape
+    assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
+    np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2)
+    # top-300
+    k = min(300, tr["Y_all"].shape[0])
+    assert Y.shape == Yref.shape == (k, 4)
+    if k < tr["Y_all"].shape[0]:
+        sure = tr["aScores"] > np.sort(tr["aScores"])[::-1][k - 1] + 2e-4
+        assert sure.sum() >= int(0.8 * k)
+    else:
+        sure = np.ones(k, dtype=bool)
+    for b in tr["Y_all"][sure]:
+        assert np.abs(Y - b).max(axis=1).min() <= 2e-2
+    assert np.all(np.diff(S) <= 0)

@@ -82,7 +82,8 @@ def test_ffi_struct_layout_matches_header():
     import ctypes
     from aznet_hip import ffi
     assert ctypes.sizeof(ffi.AzParams) == 8 + 6 * 8 + 4 * 4
-    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4      # + spec_rows, root_deferred, static_plan
+    # + spec_rows, root_deferred, static_plan, n_passes, pass_rows[16]
+    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, num_proposals=300, batch_size=1000, speculate=False)
     assert (p.im_h, p.im_w, p.Tz, p.batch_size, p.fixed_num, p.reserved) == (600, 1000, 0.3, 1000, 1, 1)
 
