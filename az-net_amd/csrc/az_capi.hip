@@ -16,7 +16,7 @@
 
 struct AzEventRec { std::string name; int level; hipEvent_t a, b; };
 
-constexpr size_t RES_HDR = 512;     // AzCounts, padded, at the head of the result block
+constexpr size_t RES_HDR = 1024;    // AzCounts, padded, at the head of the result block
 static_assert(sizeof(AzCounts) <= RES_HDR, "AzCounts outgrew its slot");
 
 struct az_ctx {
@@ -79,7 +79,19 @@ struct az_ctx {
     int static_env = -1;                      // AZ_STATIC_TREE=0: always run the level loop (measurements)
     int last_static = 0;
     int final_env = 1;                        // AZ_FINAL_FUSED=0: separate candidate / selection kernels at the last level
-    int hint_rows[AZ_MAX_LEVELS] = {0};       // unique rois per level of the last fetched level-loop search (kernel choice)
+    int hint_rows[AZ_MAX_LEVELS] = {0};       // rows of the head pass launched at each level in the last fetched level-loop search (kernel choice)
+    // the last fetched level-loop search, per level: regions, zoomed regions, unique rois, pair-speculation rows (-1: none)
+    int hint_P[AZ_MAX_LEVELS] = {0}, hint_PZ[AZ_MAX_LEVELS] = {0}, hint_U[AZ_MAX_LEVELS] = {0}, hint_SPN[AZ_MAX_LEVELS] = {0};
+    int hint_h = -1, hint_w = -1, hint_nlev = 0;
+    int pair_env = -1;                        // AZ_PAIR_SPEC: 0 never, 1 by history (default), 2 always
+    std::vector<std::pair<int, int>> nopair;  // image shapes whose pair-speculation rows outgrew the tables
+    int last_pair_mask = 0;                   // levels whose head pass carried pair-speculation rows (search in flight / last)
+    // pair speculation: all-children offsets / child -> row of the level whose pass carries the rows; looked-up outputs
+    int *choff_pair = nullptr, *crow = nullptr;
+    double *pred_v = nullptr;
+    float *score_v = nullptr, *zoom_v = nullptr;
+    unsigned char *keep_v = nullptr;
+    unsigned *key_v = nullptr;
     int gemm12_env = -1;
     int gemm12_min_rows = 161;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN;
                                               // measured crossover with k_fc_splitk: 160 rows)
@@ -214,6 +226,8 @@ int ensure_geom(az_ctx *c)
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
     A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
     A(key_u, R * AZ_NSUB);
+    A(choff_pair, R); A(crow, CH > 8192 ? CH : 8192);
+    A(pred_v, R * AZ_NSUB * 4); A(score_v, R * AZ_NSUB); A(zoom_v, R); A(keep_v, R * AZ_NSUB); A(key_v, R * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -570,7 +584,44 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
 }
 
 // Which form of the search a call takes.
-struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; };
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; };
+
+// Cost model of one head pass on the int6 GEMM (us), from the measured launch shapes (profiles/): weight-streaming
+// bound up to ~40 rows, then ~1.45 us per row; and what a head pass costs besides int6 (RoIPool, reduce, int7, heads,
+// the level's geometry kernel).
+static double pass_us(double rows) { const double t = 60.0 + 1.4 * rows; return t < 92.0 ? 92.0 : t; }
+constexpr double PASS_OVERHEAD_US = 90.0, LOOKUP_US = 8.0;
+
+// Pair speculation: the head pass of level l also evaluates one row per distinct RoIPool window among ALL children of
+// its regions, so that level l+1 needs no pass of its own (az_level.hip).  Worth it when most regions zoom: the extra
+// rows are then few more than level l+1 would have forwarded anyway, and a whole pass (one stream of the 411 MB int6
+// weights for small levels, the reduce / int7 / heads / geometry chain always) disappears.  The decision comes from
+// the previous search of this context on the same image shape (what a dataset run looks like); without history
+// nothing is speculated.  params.reserved bit 6 / AZ_PAIR_SPEC=0: never; bit 7 / AZ_PAIR_SPEC=2: at every eligible
+// level (tests).  Results are bit-identical either way.
+static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool fused_lv)
+{
+    if (c->pair_env < 0) { const char *e = getenv("AZ_PAIR_SPEC"); c->pair_env = e ? atoi(e) : 1; }
+    if (!fused_lv || (p->reserved & 64) || c->pair_env == 0) return 0;
+    for (const auto &hw : c->nopair)
+        if (hw.first == p->im_h && hw.second == p->im_w) return 0;
+    const bool force = (p->reserved & 128) || c->pair_env == 2;
+    const bool hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
+    int mask = 0;
+    for (int l = n_spec; l + 1 < nlev; ++l) {
+        bool want = force;
+        if (!want && hist && c->hint_P[l] > 0 && c->hint_U[l + 1] > 0) {
+            // rows the speculation adds: what it added last time, else level l+1's unique rois scaled by parents / zoomed parents
+            const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
+                                                 : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
+            const double with = pass_us(c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
+            const double without = pass_us(c->hint_U[l]) + pass_us(c->hint_U[l + 1]) + 2 * PASS_OVERHEAD_US;
+            want = with < without && c->hint_U[l] + S + 2 < c->maxR;
+        }
+        if (want) { mask |= 1 << l; ++l; }          // level l+1 is looked up: it has no pass to carry rows
+    }
+    return mask;
+}
 
 static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune)
 {
@@ -590,6 +641,7 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
     if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
     q.defer_root = q.fused_lv && q.n_spec == 3 && nlev >= q.n_spec + 2 && c->defer_root_env;
+    q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv);
     return q;
 }
 
@@ -782,7 +834,7 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 static int many_rows_expected(const az_ctx *c, int l)
 {
     return (l >= 0 && l < AZ_MAX_LEVELS && c->hint_rows[l] >= c->gemm12_dual_rows &&
-            c->gemm12_min_rows < 0x7fffffff) ? -1 : 0;
+            c->gemm12_min_rows < 0x7fffffff) ? -1 : 0;        // (hint_rows: rows of the PASS at that level, speculative rows included)
 }
 
 // --------------------------------------------------------------------------------------
@@ -842,30 +894,42 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
         a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
         a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0; a.defer_root = defer_root ? 1 : 0;
+        a.spec_next = (plan.pair_mask >> n_spec) & 1; a.choff_next = c->choff_pair; a.crow = c->crow;
+        a.spatial_scale = c->spatial_scale;
         azk_spec_levels(s, a);
     }
+    bool have_v = false;              // this level's head outputs were looked up among the previous pass's rows (*_v arrays)
     for (int l = fused ? n_spec : 0; l < nlev; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
         const bool lv_here = fused_lv && l + 1 < nlev;           // (the last level's copy + top-k stay chip-wide)
+        const bool pair_here = fused_lv && ((plan.pair_mask >> l) & 1) && !have_v;   // this pass carries level l+1's rows
         if (lv_here) {
-            // this level's rois were projected and deduplicated by the previous geometry kernel
-            // (the first fused level's head pass also carries the deferred root: row count from spec_levels)
-            launch_head(c, l == n_spec ? &c->cnt->scratch[4] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u,
-                        c->delta_u, p->min_side, true, (defer_root && l == n_spec) ? 1 : 0, nullptr, nullptr,
-                        many_rows_expected(c, l));
+            // this level's rois were projected and deduplicated by the previous geometry kernel, which also left the
+            // pass's row count (its unique rois + pair-speculation rows + the deferred root's) in cnt->PR[l]
+            if (!have_v)
+                launch_head(c, &c->cnt->PR[l], l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u,
+                            c->delta_u, p->min_side, true, (defer_root && l == n_spec) ? 1 : 0, nullptr, nullptr,
+                            many_rows_expected(c, l));
             Timed t(c, "level_geom", l);
             AzLevelArgs a;
             a.cnt = c->cnt; a.level = l; a.nlev = nlev;
             a.B = c->B[cur]; a.Bnext = c->B[cur ^ 1];
-            a.pred_u = c->pred_u; a.score_u = c->score_u; a.zoom_u = c->zoom_u; a.keep_u = c->keep_u; a.Uptr = Uptr;
+            a.pred_u = have_v ? c->pred_v : c->pred_u; a.score_u = have_v ? c->score_v : c->score_u;
+            a.zoom_u = have_v ? c->zoom_v : c->zoom_u; a.keep_u = have_v ? c->keep_v : c->keep_u; a.Uptr = Uptr;
             a.urois = c->urois; a.index = c->index; a.inv = c->inv; a.ubox = c->ubox;
             a.Yall = c->Yall; a.Sall = c->Sall;
             a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
             a.batch = p->batch_size; a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
-            a.force_root = 1; a.root_row = (defer_root && l == n_spec) ? 1 : 0;
+            a.force_root = 1; a.root_row = (defer_root && l == n_spec && !have_v) ? 1 : 0;
+            a.lookup_next = pair_here ? 1 : 0;
+            a.spec_next = (!pair_here && ((plan.pair_mask >> (l + 1)) & 1)) ? 1 : 0;
+            a.delta_u = c->delta_u; a.choff_all = c->choff_pair; a.choff_next = c->choff_pair; a.crow = c->crow;
+            a.pred_v = c->pred_v; a.score_v = c->score_v; a.zoom_v = c->zoom_v; a.keep_v = c->keep_v; a.key_v = c->key_v;
+            a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = c->spatial_scale;
             azk_level_geom(s, a);
+            have_v = pair_here;
             continue;
         }
         if (!fused_lv) {          // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
@@ -882,15 +946,17 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             Timed t(c, "spec_lookup", l);
             azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
                             p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
-        } else {
-            launch_head(c, Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, p->min_side, final_fused,
-                        0, nullptr, nullptr, many_rows_expected(c, l), final_fused);
+        } else if (!have_v) {
+            launch_head(c, fused_lv ? &c->cnt->PR[l] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u,
+                        p->min_side, final_fused, 0, nullptr, nullptr, many_rows_expected(c, l), final_fused);
         }
         if (final_fused) {
             Timed t(c, "final_select", l);
             AzFinalArgs a;
-            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = c->key_u; a.pred_u = c->pred_u;
-            a.score_u = c->score_u; a.zoom_u = c->zoom_u; a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
+            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = have_v ? c->key_v : c->key_u;
+            a.pred_u = have_v ? c->pred_v : c->pred_u;
+            a.score_u = have_v ? c->score_v : c->score_u; a.zoom_u = have_v ? c->zoom_v : c->zoom_u;
+            a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
             a.force_root = (l == 0) ? 1 : 0; a.capCand = c->maxCand; a.k = k;
             a.Yout = (double *)((unsigned char *)c->cnt + RES_HDR);
             a.Sout = (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32);
@@ -903,8 +969,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                                &c->cnt->nhis, &c->cnt->err);
         }
         { Timed t(c, "flags_compact", l);
-          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, c->pred_u, c->score_u,
-                            c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
+          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, have_v ? c->pred_v : c->pred_u,
+                            have_v ? c->score_v : c->score_u,
+                            have_v ? c->zoom_v : c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
                             c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z, c->zr); }
         if (l + 1 < nlev) {      // the reference also divides after the last level but never uses it
             const bool track = (n_spec && l == 1);       // level-3 regions remember their speculative row
@@ -959,6 +1026,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     c->last_static = stat ? 1 : 0;
     if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
+    c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
     hipStream_t s = c->stream;
     auto enqueue = [&]() { c->npass = 0; return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
@@ -981,6 +1049,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->nofuse_lv_h, sizeof(int));
         key.append((const char *)&c->nofuse_lv_w, sizeof(int));
         key.append((const char *)&c->last_static, sizeof(int));
+        key.append((const char *)&c->last_pair_mask, sizeof(int));
         for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
         const void *pp = stat ? (const void *)c->plan : nullptr;
         key.append((const char *)&pp, sizeof(pp));
@@ -1105,6 +1174,19 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;
         return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
     }
+    if ((h.err & 64) && !(c->last.reserved & 64)) {
+        // the pair-speculation rows of a level outgrew the tables: this image shape runs without them from now on
+        if (c->nopair.size() >= 32) c->nopair.erase(c->nopair.begin());
+        c->nopair.emplace_back(c->last.im_h, c->last.im_w);
+        az_params p2 = c->last;
+        p2.reserved = (p2.reserved | 64) & ~128;
+        void *sd = c->stage_dst;
+        const size_t sc = c->stage_cap;
+        int rc2 = az_propose_launch(c, &p2);
+        if (rc2) return rc2;
+        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;
+        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+    }
     if ((h.err & 8) && !(c->last.reserved & 2)) {
         // a fused level outgrew its LDS tables: rerun with the multi-launch kernels and remember
         // the image shape so that later calls skip the fused attempt -- first only for the levels after the
@@ -1125,8 +1207,18 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         return fail(c, AZ_ERR_CAPACITY,
                     std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
                         "): raise az_set_limits");
-    if (!c->last_static)
-        for (int l = 0; l < AZ_MAX_LEVELS; ++l) c->hint_rows[l] = l < nlev ? h.U[l] : 0;
+    if (!c->last_static && !(c->last.reserved & 4)) {
+        for (int l = 0; l < AZ_MAX_LEVELS; ++l) {
+            const bool in = l < nlev;
+            // rows of the pass at that level (fused level loop: PR; multi-launch forms: the level's unique rois)
+            c->hint_rows[l] = in ? (h.PR[l] > 0 ? h.PR[l] : (((c->last_pair_mask >> (l > 0 ? l - 1 : 0)) & 1) && l > 0 ? 0 : h.U[l])) : 0;
+            c->hint_P[l] = in ? h.P[l] : 0;
+            c->hint_PZ[l] = in ? h.PZ[l] : 0;
+            c->hint_U[l] = in ? h.U[l] : 0;
+            c->hint_SPN[l] = (in && ((c->last_pair_mask >> l) & 1)) ? h.SPN[l] : -1;
+        }
+        c->hint_h = c->last.im_h; c->hint_w = c->last.im_w; c->hint_nlev = nlev;
+    }
     const int n = h.nsel;
     c->cand_n = h.ytot[nlev];
     c->his_n = h.nhis;

@@ -24,6 +24,10 @@ struct AzCounts {
     int specP1, specCH, specU, specPad;
     // tuner's search (lib/detect/tune.py:256-316): rows of the anchor history written so far
     int nhis, hisPad[3];
+    // head passes of the fused level loop (az_capi.hip): PR[l] = rois the pass launched at level l evaluates (its own
+    // unique rois, then -- "pair speculation" -- SPN[l] rows for ALL children of all of its regions, a superset of level
+    // l+1's rois, starting at row SPB[l], then the deferred root's row if it rides here); 0 = no pass at that level
+    int PR[AZ_MAX_LEVELS], SPB[AZ_MAX_LEVELS], SPN[AZ_MAX_LEVELS];
 };
 
 // Geometry of one launch of the head on `U` rois (all device pointers).
@@ -160,6 +164,9 @@ struct AzFusedArgs {
     int *index, *inv, *zr, *choff, *csrc;
     float *rois, *urois;          // (next_dedup) roi projection + dedup of the first level after the fused ones
     int next_dedup, defer_root;
+    int spec_next;                // (next_dedup) that level's head pass also carries rows for all children of its regions
+    int *choff_next, *crow;       // (spec_next) first child of every region in the all-children list; child -> spec row
+    float spatial_scale;
     const double *specB1;         // the pre-pass's B1 (children of the root after _sift_dup)
     int reset, specP1, specCH, specU;   // reset: clear the counters here and restore the (cached) pre-pass's
     const int *choff_all;
@@ -189,7 +196,16 @@ struct AzLevelArgs {
     int *index, *inv;              // this level's inv_index on entry; the next level's index / inv_index on exit
     const unsigned char *keep_u;   // MIN_SIDE filter of this level's decoded boxes (tail kernel)
     const int *Uptr;               // unique rois of this level
-    int root_row;                  // 1: row *Uptr of the head outputs is the deferred root (az_fused.hip)
+    int root_row;                  // 1: the LAST row of this level's head pass (cnt->PR[level] - 1) is the deferred root (az_fused.hip)
+    // pair speculation (az_capi.hip): this level's head pass also evaluated rows for all children of its regions
+    // (lookup_next) -> level l+1's outputs are looked up and decoded here into the *_v arrays instead of a head pass;
+    // or the NEXT level's pass shall carry such rows (spec_next): they are appended behind its unique rois here
+    int lookup_next, spec_next;
+    const float *delta_u;          // raw box deltas of this level's pass (lookup_next)
+    const int *choff_all;          // (lookup_next) written by the previous geometry kernel; (spec_next) written here
+    int *choff_next, *crow;        // all-children offsets of the next level's regions; child -> spec row (read / written)
+    double *pred_v; float *score_v, *zoom_v; unsigned char *keep_v; unsigned *key_v;
+    int im_h, im_w; double eps; float spatial_scale;
     double *ubox;                  // next level: anchor boxes of the unique rois
     double *Yall; float *Sall;     // candidates of the whole search
     double scale, Tz, min_side;

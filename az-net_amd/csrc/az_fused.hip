@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     __shared__ unsigned char sfirst[FL_C];
     __shared__ int sslot[FL_C];
     __shared__ int sczi[FL_C];
-    __shared__ int sidx[FL_R], szr[FL_R], schoff[FL_R];
+    __shared__ int sidx[FL_R], szr[FL_R], schoff[FL_R + 1];
+    __shared__ unsigned long long stmpC[FL_C];      // (spec_next) sort scratch of the next level's all-children window keys
     __shared__ unsigned long long ssort[2 * FL_R];
     __shared__ unsigned sbins[SORT_NB + 1];
     __shared__ unsigned smm[2];
@@ -354,19 +355,32 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         __syncthreads();
         const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, nullptr,
                                        a.index, a.inv, a.urois, a.ubox);
+        // pair speculation: that level's head pass also evaluates one row per distinct RoIPool window among ALL
+        // children of its regions (a superset of the level after it), behind its own unique rois
+        int S = 0;
+        if (a.spec_next && a.n_fused + 1 < a.nlev && P > 0) {
+            __syncthreads();
+            S = spec_children_rows(sB[nxt], P, a.scale, a.min_side, a.spatial_scale,
+                                   reinterpret_cast<unsigned long long *>(skeyC), stmpC, sbins, smm, wsum, schoff, FL_C,
+                                   a.choff_next, a.crow, a.urois, a.ubox, U, a.capR - 1);
+            if (S < 0) { if (tid == 0) atomicOr(&cnt->err, 8 | 64); return; }
+        }
         if (tid == 0) {
             cnt->U[a.n_fused] = U;
-            cnt->scratch[4] = U;                       // rows the head evaluates at that level
+            int rows = U + S;                          // rows the head evaluates at that level
+            cnt->SPB[a.n_fused] = U;
+            cnt->SPN[a.n_fused] = S;
             if (a.defer_root) {
-                // the deferred root rides as one more row behind the level's unique rois
+                // the deferred root rides as the LAST row (RoIPool treats the tail of a launch cooperatively)
                 const double rootb[4] = {0.0, 0.0, a.im_w - 1.0, a.im_h - 1.0};
-                a.urois[5 * (size_t)U] = 0.0f;
+                a.urois[5 * (size_t)rows] = 0.0f;
                 for (int q = 0; q < 4; ++q) {
-                    a.urois[5 * (size_t)U + 1 + q] = (float)(rootb[q] * a.scale);
-                    a.ubox[4 * (size_t)U + q] = rootb[q];
+                    a.urois[5 * (size_t)rows + 1 + q] = (float)(rootb[q] * a.scale);
+                    a.ubox[4 * (size_t)rows + q] = rootb[q];
                 }
-                cnt->scratch[4] = U + 1;
+                ++rows;
             }
+            cnt->PR[a.n_fused] = rows;
         }
     }
 }

@@ -181,7 +181,7 @@ static __device__ __forceinline__ int next_pow2(int v)
 // Pn <= 16384 and Pn <= batch (one dedup chunk: keys < 1000^5 < 2^50); `ssort` / `stmp` hold Pn words each.
 static __device__ int roi_dedup_sorted(const double *Bn, int Pn, double scale, float dedup, unsigned long long *ssort,
                                        unsigned long long *stmp, unsigned *bins, unsigned *mm, int *wsum, float *rois,
-                                       int *index, int *inv, float *urois, double *ubox)
+                                       int *index, int *inv, float *urois, double *ubox, int *sidx = nullptr)
 {
     const int tid = threadIdx.x, nt = (int)blockDim.x;
     for (int r = tid; r < Pn; r += nt) {
@@ -211,6 +211,7 @@ static __device__ int roi_dedup_sorted(const double *Bn, int Pn, double scale, f
             inv[r] = slot;
             if (head) {
                 index[slot] = r;
+                if (sidx) sidx[slot] = r;                                // (LDS copy for the caller's next stage)
                 float roi5[5];
                 roi_and_key(Bn + 4 * r, scale, dedup, roi5, r);          // (recomputed: cheaper than a memory round trip)
 #pragma unroll
@@ -222,4 +223,105 @@ static __device__ int roi_dedup_sorted(const double *Bn, int Pn, double scale, f
         U += tot;
     }
     return U;
+}
+
+// ----------------------------------------------------------------------------------------
+// Pair speculation (az_capi.hip): rows for ALL children of all P regions `Bn` of a level, appended to that level's
+// head pass.  The next level's regions are _sift_dup(divide_region(Z)) with Z a SUBSET of these parents
+// (test.py:386-390), so every region the next level can hold is one of these children, bit for bit (a child is a
+// function of its parent alone).  The head's outputs for a roi (zoom, scores, raw deltas) depend on the roi only
+// through RoIPool's integer window -- C round() of coordinate * spatial_scale (ROIPooling, test_fc.prototxt:14-25) --,
+// so children are deduplicated by those four integers: one row per distinct window, whichever child supplies the
+// coordinates.  Which child REPRESENTS a roi in the reference's own np.round dedup, and the anchor box its deltas are
+// decoded against, are decided later from the real tree (az_level.hip: lookup stage); here only: child ci -> row.
+//   choff_all_g[r]  first child of region r in the all-children list (global, P ints; also `schoff` in LDS, P ints)
+//   crow_g[ci]      spec row (0-based among the spec rows) of child ci (global)
+//   urois / ubox    the spec rows' rois (f32, scaled) and, as a placeholder anchor, the supplying child's box, written at
+//                   rows row_base .. row_base + S
+// Returns S, or -1 if the children outgrow maxC / the rows outgrow capRows / a coordinate leaves the key's range.
+static __device__ __forceinline__ bool pool_key(const float *roi5, float ss, unsigned long long *key)
+{
+    unsigned long long k = 0;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int v = (int)roundf(roi5[1 + q] * ss) + 2048;          // k_roi_pool's own expression
+        ok = ok && v >= 0 && v < 4096;
+        k |= (unsigned long long)(v & 4095) << (12 * q);
+    }
+    *key = k;
+    return ok;
+}
+
+static __device__ int spec_children_rows(const double *Bn, int P, double scale, double min_side, float ss,
+                                         unsigned long long *ssort, unsigned long long *stmp, unsigned *bins,
+                                         unsigned *mm, int *wsum, int *schoff, int maxC, int *choff_all_g, int *crow_g,
+                                         float *urois, double *ubox, int row_base, int capRows)
+{
+    const int tid = threadIdx.x, nt = (int)blockDim.x;
+    int CH = 0, bad = 0;
+    for (int base = 0; base < P; base += nt) {
+        const int z = base + tid;
+        DivPlan p{};
+        int n = 0;
+        if (z < P) { p = div_plan(Bn + 4 * z); n = div_nchildren(p); }
+        int tot;
+        const int o = CH + block_excl_scan(n, &tot, wsum);
+        if (z < P) {
+            schoff[z] = o;
+            choff_all_g[z] = o;
+            if (o + n <= maxC && o + n <= 8192) {
+                for (int bi = 0; bi < n; ++bi) {
+                    double c[4];
+                    div_child(Bn + 4 * z, p, bi, min_side, c);
+                    float roi5[5];
+                    roi5[0] = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(c[q] * scale);       // test.py:61-97
+                    unsigned long long key;
+                    if (!pool_key(roi5, ss, &key)) bad = 1;
+                    ssort[o + bi] = (key << 13) | (unsigned)(o + bi);
+                }
+            }
+        }
+        CH += tot;
+    }
+    if (__syncthreads_or(bad) || CH > maxC || CH > 8192) return -1;
+    block_bucket_sort(ssort, CH, stmp, bins, 29, wsum, mm);            // high part = the window key's upper 32 bits
+    int S = 0;
+    for (int base = 0; base < CH; base += nt) {
+        const int i = base + tid;
+        int head = 0;
+        unsigned long long w = 0;
+        if (i < CH) {
+            w = ssort[i];
+            head = (i == 0) || ((ssort[i - 1] >> 13) != (w >> 13));
+        }
+        int tot;
+        const int ex = block_excl_scan(head, &tot, wsum);
+        if (i < CH) {
+            const int run = S + ex + head - 1;
+            const int ci = (int)(w & 0x1FFFu);
+            crow_g[ci] = run;
+            if (head && row_base + run < capRows) {
+                int lo = 0, hi = P - 1;                                  // parent of child ci: schoff[r] <= ci < schoff[r + 1]
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (schoff[mid] <= ci) lo = mid; else hi = mid - 1;
+                }
+                double c[4];
+                div_child(Bn + 4 * lo, div_plan(Bn + 4 * lo), ci - schoff[lo], min_side, c);
+                const size_t row = (size_t)(row_base + run);
+                urois[5 * row] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    urois[5 * row + 1 + q] = (float)(c[q] * scale);
+                    ubox[4 * row + q] = c[q];
+                }
+            }
+        }
+        S += tot;
+    }
+    if (row_base + S > capRows) return -1;
+    return S;
 }

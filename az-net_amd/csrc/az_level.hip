@@ -27,12 +27,18 @@ constexpr int LV_R = 1024;         // regions per level handled here
 constexpr int LV_C = 4096;         // children per level (before _sift_dup)
 
 // LDS carve-up in 8-byte words (one buffer; stages that share a region never overlap in time):
-//   [0, 4096) sort words   [4096, 6144) sczi   [6144, 7168) szr, schoff
-//   [7168, 11264) sort scratch, then the next level's regions (f64 x 4 x 1024)
-//   [11264, 11776) inv   [11776, 12288) zoom scores   [12288, 13696) keep flags   [13696, 15745) sort buckets
-constexpr int W_SORT = 0, W_SCZI = 4096, W_SZR = 6144, W_BN = 7168, W_INV = 11264, W_ZOOM = 11776, W_KEEP = 12288,
-              W_BINS = 13696;
+//   [0, 4096) sort words   [4096, 6144) sczi   [6144, 6656) szr   [6656, 7168) zoom scores   [7168, 8576) keep flags
+//     ([4096, 8192): dead once the next level's regions exist -- the sort scratch of the pair-speculation stage)
+//   [8576, 9088) schoff (divide) / all-children offsets (pair speculation)
+//   [9088, 9600) inv, then the provenance (all-children index) of the next level's regions
+//   [9600, 13696) sort scratch, then the next level's regions (f64 x 4 x 1024)
+//   [13696, 15745) sort buckets
+constexpr int W_SORT = 0, W_SCZI = 4096, W_SZR = 6144, W_ZOOM = 6656, W_KEEP = 7168, W_CHOFF = 8576, W_INV = 9088,
+              W_BN = 9600, W_BINS = 13696;
+constexpr int W_TMP2 = 4096;
 constexpr int LDS_WORDS = W_BINS + (SORT_NB + 2) / 2 + 1;
+static_assert(W_KEEP + (LV_R * AZ_NSUB + 7) / 8 <= W_CHOFF, "keep flags overlap the next region");
+static_assert(W_TMP2 + LV_C <= W_CHOFF, "pair-speculation sort scratch overlaps live data");
 
 #ifdef AZ_LEVEL_TIMING
 #define TSTAMP() do { __syncthreads(); if (tid == 0 && tsn < 32) ts[tsn++] = wall_clock64(); } while (0)
@@ -59,6 +65,9 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     const int ybase = cnt->ytot[l];
     if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
     if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    // the deferred root is the LAST row of this level's head pass (behind any pair-speculation rows)
+    const int root_u = a.root_row ? cnt->PR[l] - 1 : 0;
+    const int spec_base = cnt->SPB[l];                     // (lookup_next) first pair-speculation row of this level's pass
     TSTAMP();
 
     // ---- one round trip: this level's inv_index, zoom scores and keep flags -> LDS; its regions -> cache ----
@@ -70,7 +79,8 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         double warm = 0.0;
         for (int r = tid; r < P; r += NT) { sinv[r] = a.inv[r]; warm += B[4 * (size_t)r]; }
         for (int u = tid; u < U; u += NT) szoom[u] = a.zoom_u[u];
-        for (int i = tid; i < (U + a.root_row) * AZ_NSUB; i += NT) skeep[i] = a.keep_u[i];
+        for (int i = tid; i < U * AZ_NSUB; i += NT) skeep[i] = a.keep_u[i];
+        if (a.root_row && tid < AZ_NSUB) skeep[U * AZ_NSUB + tid] = a.keep_u[(size_t)root_u * AZ_NSUB + tid];
         if (warm == -1.2345e300) szoom[0] = 0.f;           // (never true; keeps the region loads alive: they warm this CU's caches)
     }
     __syncthreads();
@@ -132,7 +142,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         if (tid == 0) wsum[0] = __popcll(m);
         if (tid < AZ_NSUB && kp) {
             const int dst = __popcll(m & ((1ull << tid) - 1ull));
-            const size_t src = (size_t)U * AZ_NSUB + tid;
+            const size_t src = (size_t)root_u * AZ_NSUB + tid;
 #pragma unroll
             for (int q = 0; q < 4; ++q) a.Yall[(size_t)dst * 4 + q] = a.pred_u[src * 4 + q];
             a.Sall[dst] = a.score_u[src];
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     TSTAMP();
 
     // ---- zoom selection (test.py:383-387) -----------------------------------------------------------
-    int *szr = reinterpret_cast<int *>(sbuf + W_SZR), *schoff = szr + LV_R;
+    int *szr = reinterpret_cast<int *>(sbuf + W_SZR), *schoff = reinterpret_cast<int *>(sbuf + W_CHOFF);
     int PZ = 0;
     for (int base = 0; base < P; base += NT) {
         const int r = base + tid;
@@ -219,6 +229,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     block_bucket_sort(ssort, CH, stmp, sbins, 40, wsum, s_mm);              // high part = hash >> 20
     TSTAMP();
     double *sBn = reinterpret_cast<double *>(sbuf + W_BN);                  // (the sort is done with its scratch)
+    int *sprov = sinv;                                                      // (inv_index of this level is no longer needed)
     int Pn = 0;
     for (int base = 0; base < CH; base += NT) {
         const int i = base + tid;
@@ -239,6 +250,9 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
                 div_child(r, div_plan(r), ci & 0xFFFF, a.min_side, c);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { sBn[4 * slot + q] = c[q]; a.Bnext[4 * (size_t)slot + q] = c[q]; }
+                // which child of which region of THIS level it is, as an index into the all-children list the previous
+                // geometry kernel laid out: finds the region's row among this level's pair-speculation rows
+                if (a.lookup_next) sprov[slot] = a.choff_all[szr[ci >> 16]] + (ci & 0xFFFF);
             }
         }
         Pn += tot;
@@ -249,9 +263,51 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     TSTAMP();
     // ---- level l+1: roi projection + feature-space dedup (test.py:61-97, 210-218) ---------------------
     if (Pn > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
+    int *sidx = reinterpret_cast<int *>(sbuf + W_SZR);                      // (szr is done) index[] of level l+1, in LDS
     const int Un = roi_dedup_sorted(sBn, Pn, a.scale, a.dedup, ssort, ssort + LV_R, sbins, s_mm, wsum, nullptr, a.index,
-                                    a.inv, a.urois, a.ubox);
+                                    a.inv, a.urois, a.ubox, sidx);
     if (tid == 0) cnt->U[l + 1] = Un;
+    __syncthreads();
+    TSTAMP();
+    if (a.lookup_next) {
+        // ---- level l+1's head outputs without a head pass: every one of its regions is a child of a region of this
+        //      level, and this level's pass evaluated one row per distinct RoIPool window among all such children
+        //      (az_geom_dev.h: spec_children_rows).  For each unique roi of level l+1: the row of its REPRESENTATIVE
+        //      (np.unique's first occurrence, test.py:214-217), raw deltas decoded against the representative's own
+        //      box (test.py:241-242: `boxes = boxes[index]`), scores / zoom copied: what the tail kernel would have
+        //      written for that roi, bit for bit (a roi's outputs do not depend on the launch it sits in).
+        for (int i = tid; i < Un * AZ_NSUB; i += NT) {
+            const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+            const int rpos = sidx[slot];
+            const size_t srow = (size_t)spec_base + a.crow[sprov[rpos]];
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d4[q] = a.delta_u[srow * 4 * AZ_NSUB + 4 * sub + q];
+            double bx[4];
+            az_decode_box(sBn + 4 * rpos, d4, a.im_h, a.im_w, a.eps, bx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.pred_v[(size_t)i * 4 + q] = bx[q];
+            const float sc = a.score_u[srow * AZ_NSUB + sub];
+            a.score_v[i] = sc;
+            const bool kp = cand_keep(bx, a.min_side);
+            a.keep_v[i] = kp ? 1 : 0;
+            const unsigned kk = score_key(sc);
+            a.key_v[i] = kp ? (kk ? kk : 1u) : 0u;
+        }
+        for (int slot = tid; slot < Un; slot += NT)
+            a.zoom_v[slot] = a.zoom_u[(size_t)spec_base + a.crow[sprov[sidx[slot]]]];
+        if (tid == 0) cnt->PR[l + 1] = 0;
+    } else {
+        // ---- the next head pass: level l+1's unique rois, then (spec_next) one row per distinct RoIPool window among ALL
+        //      children of its regions -- level l+2's outputs will be looked up there
+        int S = 0;
+        if (a.spec_next && l + 2 < a.nlev && Pn > 0) {
+            S = spec_children_rows(sBn, Pn, a.scale, a.min_side, a.spatial_scale, ssort, sbuf + W_TMP2, sbins, s_mm, wsum,
+                                   schoff, LV_C, a.choff_next, a.crow, a.urois, a.ubox, Un, a.capR);
+            if (S < 0) { if (tid == 0) atomicOr(&cnt->err, 8 | 64); return; }
+        }
+        if (tid == 0) { cnt->PR[l + 1] = Un + S; cnt->SPB[l + 1] = Un; cnt->SPN[l + 1] = S; }
+    }
     TSTAMP();
     TREPORT();
 }

@@ -150,6 +150,47 @@ class DeviceGather(object):
         assert 0 <= j < self.rows
         self.ctx.stage_result(self.send.data_ptr() + j * self.rec_bytes, self.rec_bytes)
 
+    # ---- the same exchange without stalling the searches -------------------------------------------------------
+    def gather_begin(self, n_local):
+        """Start the exchange of the batch just staged and return a handle; the searches of the NEXT batch may be
+        launched (and staged: the send buffer is double-buffered) before `gather_end(handle)` collects the result.
+        Call after the last propose_fetch of the batch, like gather().  The collective and the device-to-host copy
+        run on a side stream; nothing here blocks the host."""
+        import torch
+        import torch.distributed as dist
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device)
+            self._bufs = [(self.send, self.recv)]
+            self._bufs.append((torch.zeros_like(self.send), torch.empty_like(self.recv)))
+            self._host = [torch.empty(self.recv.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._turn = 0
+        send, recv = self._bufs[self._turn]
+        host = self._host[self._turn]
+        assert send.data_ptr() == self.send.data_ptr()
+        ev = torch.cuda.Event()
+        # (the staged copies ran on the ctx stream and are complete: propose_fetch synchronised it)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._side):
+            if n_local < self.rows:
+                send[n_local:] = self._pad
+            if self.world > 1 or self.collective:
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                src = recv
+            else:
+                src = send
+            host[:src.shape[0]].copy_(src, non_blocking=True)
+            ev.record(self._side)
+        # the next batch stages into the other buffer
+        self._turn ^= 1
+        self.send, self.recv = self._bufs[self._turn]
+        return (ev, host, self.world if (self.world > 1 or self.collective) else 1)
+
+    def gather_end(self, handle):
+        ev, host, w = handle
+        ev.synchronize()
+        raw = host.numpy()[:w * self.rows].reshape(w, self.rows, self.rec_bytes)
+        return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))
+
     def gather(self, n_local, to_host=True):
         """After the last propose_fetch of the batch (the ctx stream is idle then)."""
         import torch

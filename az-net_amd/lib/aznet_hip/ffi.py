@@ -268,7 +268,7 @@ class AzContext(object):
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
                     dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True,
-                    tune=False, radix_select=False, fused_levels=True, static_tree=True):
+                    tune=False, radix_select=False, fused_levels=True, static_tree=True, pair_spec=None):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
         slower); fused=False keeps the geometry of those levels as separate launches;
         fused_levels=False does the same for the levels after them (az_level.hip).  All
@@ -276,12 +276,16 @@ class AzContext(object):
         (lib/detect/tune.py:256-316) and keeps the anchor history (last_anchors).  radix_select=True
         does the final top-k with the single-workgroup radix select (same result, for tests).
         static_tree=False: with Tz <= 0 (every zoom test passes, the tree depends on the image shape only) still
-        walk the tree level by level instead of forwarding all levels' rois in one head pass (same bits)."""
+        walk the tree level by level instead of forwarding all levels' rois in one head pass (same bits).
+        pair_spec: None = let the context decide from its previous search whether a level's head pass also carries the
+        rows of ALL children of its regions (so that the next level needs no pass); False = never; True = at every
+        eligible level (same bits in all three)."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
                         1 if fixed_num else 0,
                         (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0) |
-                        (8 if radix_select else 0) | (0 if fused_levels else 16) | (0 if static_tree else 32))
+                        (8 if radix_select else 0) | (0 if fused_levels else 16) | (0 if static_tree else 32) |
+                        (0 if pair_spec is None else (128 if pair_spec else 64)))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates

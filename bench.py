@@ -146,6 +146,12 @@ def main():
         # process touches the GPU, relay rank 0's JSON line and exit with the launcher's code.
         sys.exit(self_launch(args.gpus))
 
+    # The contract is ONE line on stdout.  Libraries below us (RCCL prints its version banner from C) write to file
+    # descriptor 1 too: from here on fd 1 is stderr, and the result line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from aznet_hip import ffi, synth
@@ -223,16 +229,27 @@ def main():
     for n in nets[1:]:
         n.set_conv(conv)
 
+    inflight_gather = []
+
     def finish(last):
         """One image done; every gather_every images per rank (and at the end): ONE RCCL all-gather of the
-        records staged device-to-device by the searches, then the host copy of all ranks' proposals."""
+        records staged device-to-device by the searches, then the host copy of all ranks' proposals.  The exchange of
+        batch b runs on a side stream while the searches of batch b+1 run (double-buffered send buffer); every batch's
+        proposals are collected on the host inside the timed region."""
         if gat is not None:
             pending[0] += 1
             if pending[0] == args.gather_every or last:
-                res = gat.gather(pending[0])
-                assert len(res) == world * pending[0]
+                h = (gat.gather_begin(pending[0]), pending[0])
+                if inflight_gather:
+                    hp, npend = inflight_gather.pop(0)
+                    assert len(gat.gather_end(hp)) == world * npend
+                inflight_gather.append(h)
                 pending[0] = 0
                 rccl["collectives"] += 1
+            if last:
+                while inflight_gather:
+                    hp, npend = inflight_gather.pop(0)
+                    assert len(gat.gather_end(hp)) == world * npend
 
     def run(nsteps, prm):
         if args.inflight == 1:
@@ -567,7 +584,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
 
 
 def extras(net, head, ffi, synth, HipDetNet, torch, args):

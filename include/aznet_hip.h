@@ -69,7 +69,11 @@ typedef struct {
                                  bit 5: with Tz <= 0 still walk the tree level by level (by default such a
                                  search -- every finite zoom score passes `zoom >= Tz`, test.py:386, so the
                                  tree depends on the image shape only -- forwards the rois of ALL levels in
-                                 ONE head pass; same bits)                                          */
+                                 ONE head pass; same bits);
+                                 bit 6: no pair speculation; bit 7: pair speculation at every eligible level (by
+                                 default the context decides from its previous search whether the head pass of a
+                                 level also evaluates the rois of ALL children of its regions, a superset of the next
+                                 level's, which then needs no pass of its own; same bits in all three)            */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
