@@ -158,12 +158,14 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     __shared__ double sB[2][FL_R * 4];
     __shared__ int ssrc[2][FL_R];
     __shared__ long long skey[FL_R];
-    __shared__ long long skeyC[FL_C];
+    // (child keys of the level being divided; behind them the scratch that, together, is the window table of the
+    //  pair-speculation stage: 2 * FL_C contiguous words)
+    __shared__ unsigned long long stable[2 * FL_C];
+    long long *skeyC = reinterpret_cast<long long *>(stable);
     __shared__ unsigned char sfirst[FL_C];
     __shared__ int sslot[FL_C];
     __shared__ int sczi[FL_C];
     __shared__ int sidx[FL_R], szr[FL_R], schoff[FL_R + 1];
-    __shared__ unsigned long long stmpC[FL_C];      // (spec_next) sort scratch of the next level's all-children window keys
     __shared__ unsigned long long ssort[2 * FL_R];
     __shared__ unsigned sbins[SORT_NB + 1];
     __shared__ unsigned smm[2];
@@ -347,6 +349,10 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 #endif
     // hand the next level's regions to the multi-workgroup kernels
     const int nxt = a.n_fused & 1;
+#ifdef AZ_SPEC_TIMING
+    __syncthreads();
+    const unsigned long long tc0 = wall_clock64();
+#endif
     for (int i = tid; i < P * 4; i += NTL) a.B[nxt][i] = sB[nxt][i];
     if (tid == 0) cnt->P[a.n_fused] = P;
     if (a.next_dedup && a.n_fused < a.nlev) {
@@ -355,14 +361,17 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         __syncthreads();
         const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, nullptr,
                                        a.index, a.inv, a.urois, a.ubox);
+#ifdef AZ_SPEC_TIMING
+        __syncthreads();
+        if (tid == 0) printf("closing: handover + roi dedup %llu (x10ns)\n", wall_clock64() - tc0);
+#endif
         // pair speculation: that level's head pass also evaluates one row per distinct RoIPool window among ALL
         // children of its regions (a superset of the level after it), behind its own unique rois
         int S = 0;
         if (a.spec_next && a.n_fused + 1 < a.nlev && P > 0) {
             __syncthreads();
-            S = spec_children_rows(sB[nxt], P, a.scale, a.min_side, a.spatial_scale,
-                                   reinterpret_cast<unsigned long long *>(skeyC), stmpC, sbins, smm, wsum, schoff, FL_C,
-                                   a.choff_next, a.crow, a.urois, a.ubox, U, a.capR - 1);
+            S = spec_children_rows<FL_C / NTL>(sB[nxt], P, a.scale, a.min_side, a.spatial_scale, stable, 2 * FL_C, wsum,
+                                               schoff, FL_C, a.choff_next, a.crow, a.urois, a.ubox, U, a.capR - 1);
             if (S < 0) { if (tid == 0) atomicOr(&cnt->err, 8 | 64); return; }
         }
         if (tid == 0) {

@@ -115,9 +115,13 @@ static __device__ void block_bucket_sort(unsigned long long *w, int N, unsigned 
                                          int S, int *wsum, unsigned *mm)
 {
     const int tid = threadIdx.x, nt = (int)blockDim.x;
+    // buckets in use: ~4 per word (a power of two, at most SORT_NB) -- clearing and scanning 4096 counters for a few
+    // hundred words was most of the sort's time
+    int NB = 256;
+    while (NB < 4 * N && NB < SORT_NB) NB <<= 1;
     __syncthreads();
     if (tid == 0) { mm[0] = 0xFFFFFFFFu; mm[1] = 0u; }
-    for (int b = tid; b <= SORT_NB; b += nt) bins[b] = 0u;
+    for (int b = tid; b <= NB; b += nt) bins[b] = 0u;
     __syncthreads();
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
     for (int i = tid; i < N; i += nt) {
@@ -136,13 +140,13 @@ static __device__ void block_bucket_sort(unsigned long long *w, int N, unsigned 
     const unsigned base_h = mm[0];
     const unsigned long long range = (unsigned long long)(mm[1] - mm[0]) + 1ull;
     auto bucket = [&](unsigned long long x) {
-        return (int)(((unsigned long long)((unsigned)(x >> S) - base_h) * (unsigned long long)SORT_NB) / range);
+        return (int)(((unsigned long long)((unsigned)(x >> S) - base_h) * (unsigned long long)NB) / range);
     };
     for (int i = tid; i < N; i += nt) atomicAdd(&bins[bucket(w[i])], 1u);
     __syncthreads();
     {   // exclusive scan of the bucket counts, in place
-        const int per = (SORT_NB + nt - 1) / nt;
-        const int b0 = tid * per, b1 = min(SORT_NB, b0 + per);
+        const int per = (NB + nt - 1) / nt;
+        const int b0 = min(NB, tid * per), b1 = min(NB, b0 + per);
         int sum = 0;
         for (int b = b0; b < b1; ++b) sum += (int)bins[b];
         int tot;
@@ -253,75 +257,138 @@ static __device__ __forceinline__ bool pool_key(const float *roi5, float ss, uns
     return ok;
 }
 
-static __device__ int spec_children_rows(const double *Bn, int P, double scale, double min_side, float ss,
-                                         unsigned long long *ssort, unsigned long long *stmp, unsigned *bins,
-                                         unsigned *mm, int *wsum, int *schoff, int maxC, int *choff_all_g, int *crow_g,
-                                         float *urois, double *ubox, int row_base, int capRows)
+// one child's box without its _sift_dup hash (the hash costs four f64 divisions nobody needs here)
+static __device__ __forceinline__ void div_child_box(const double *r, const DivPlan &p, int bi, double *c)
 {
+    const double h_short = p.l_short / 2, h_long = p.l_long / 2;   // div.pyx:58-59
+    double s_lo, s_hi, l_lo, l_hi;
+    if (bi < (int)(2 * p.num_long)) {
+        const unsigned k = (unsigned)bi / p.num_long, j = (unsigned)bi - k * p.num_long;
+        s_lo = k * p.l_short; s_hi = (k + 1) * p.l_short;
+        l_lo = j * p.l_long;  l_hi = (j + 1) * p.l_long;
+    } else {
+        const unsigned j = (unsigned)bi - 2 * p.num_long;
+        s_lo = 0 * p.l_short + h_short; s_hi = (0 + 1) * p.l_short + h_short;
+        l_lo = j * p.l_long + h_long;   l_hi = (j + 1) * p.l_long + h_long;
+    }
+    if (p.min_ind == 0) { c[0] = s_lo; c[1] = l_lo; c[2] = s_hi; c[3] = l_hi; }
+    else                { c[0] = l_lo; c[1] = s_lo; c[2] = l_hi; c[3] = s_hi; }
+    c[0] += r[0]; c[2] += r[0]; c[1] += r[1]; c[3] += r[1];        // div.pyx:71-72
+}
+
+// Dedup by RoIPool window = an open-addressing table in LDS, one 64-bit word per entry: (window key << 13) | child.
+// A slot is claimed for a key by compare-and-swap on the empty word and then keeps the SMALLEST child index of that
+// key (atomicMin on the whole word: same key, so the order is the child's) -- the representative is therefore the first
+// child of the window in all-children order, whatever the order the threads arrive in.  Rows are numbered in that
+// order too (a block scan over the head flags), so the row layout is deterministic.
+//   buf: W words of LDS: the table (3W/4 words) and, behind it, one int per child (its slot; W/2 ints >= maxC)
+//   MAXIT >= ceil(maxC / blockDim): each thread keeps the boxes of its children in registers between the two phases
+template <int MAXIT>
+static __device__ int spec_children_rows(const double *Bn, int P, double scale, double min_side, float ss,
+                                         unsigned long long *buf, int W, int *wsum, int *schoff, int maxC,
+                                         int *choff_all_g, int *crow_g, float *urois, double *ubox, int row_base,
+                                         int capRows)
+{
+    (void)min_side;
     const int tid = threadIdx.x, nt = (int)blockDim.x;
-    int CH = 0, bad = 0;
+    constexpr unsigned long long EMPTY = ~0ull;
+    const unsigned T = (unsigned)(W / 4 * 3);
+    unsigned long long *tab = buf;
+    int *sslot = reinterpret_cast<int *>(buf + T);
+#ifdef AZ_SPEC_TIMING
+    unsigned long long tq[8]; int tqn = 0;
+#define SPEC_T() do { __syncthreads(); if (tqn < 8) tq[tqn++] = wall_clock64(); } while (0)
+#else
+#define SPEC_T() do { } while (0)
+#endif
+    SPEC_T();
+    for (unsigned i = tid; i < T; i += nt) tab[i] = EMPTY;
+    int CH = 0;
     for (int base = 0; base < P; base += nt) {
         const int z = base + tid;
-        DivPlan p{};
-        int n = 0;
-        if (z < P) { p = div_plan(Bn + 4 * z); n = div_nchildren(p); }
+        const int n = z < P ? div_nchildren(div_plan(Bn + 4 * z)) : 0;
         int tot;
         const int o = CH + block_excl_scan(n, &tot, wsum);
-        if (z < P) {
-            schoff[z] = o;
-            choff_all_g[z] = o;
-            if (o + n <= maxC && o + n <= 8192) {
-                for (int bi = 0; bi < n; ++bi) {
-                    double c[4];
-                    div_child(Bn + 4 * z, p, bi, min_side, c);
-                    float roi5[5];
-                    roi5[0] = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(c[q] * scale);       // test.py:61-97
-                    unsigned long long key;
-                    if (!pool_key(roi5, ss, &key)) bad = 1;
-                    ssort[o + bi] = (key << 13) | (unsigned)(o + bi);
-                }
-            }
-        }
+        if (z < P) { schoff[z] = o; choff_all_g[z] = o; }
         CH += tot;
     }
-    if (__syncthreads_or(bad) || CH > maxC || CH > 8192) return -1;
-    block_bucket_sort(ssort, CH, stmp, bins, 29, wsum, mm);            // high part = the window key's upper 32 bits
+    if (CH > maxC || CH > 8192 || CH > W / 2 || CH > MAXIT * nt) return -1;
+    __syncthreads();
+    SPEC_T();
+    // parent of child ci: schoff[r] <= ci < schoff[r + 1]
+    auto parent_of = [&](int ci) {
+        int lo = 0, hi = P - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (schoff[mid] <= ci) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    int bad = 0;
+    double cb[MAXIT][4];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int ci = tid + it * nt;                                    // one thread per child
+        if (ci < CH) {
+            const int r = parent_of(ci);
+            div_child_box(Bn + 4 * r, div_plan(Bn + 4 * r), ci - schoff[r], cb[it]);
+            float roi5[5];
+            roi5[0] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(cb[it][q] * scale);   // test.py:61-97
+            unsigned long long key;
+            if (!pool_key(roi5, ss, &key)) bad = 1;
+            const unsigned long long word = (key << 13) | (unsigned)ci;
+            // multiplicative hash of the 48-bit key onto [0, T)
+            unsigned slot = (unsigned)((((key * 0x9E3779B97F4A7C15ull) >> 32) * (unsigned long long)T) >> 32);
+            for (;;) {
+                unsigned long long old = tab[slot];
+                if (old == EMPTY) {
+                    old = atomicCAS(&tab[slot], EMPTY, word);
+                    if (old == EMPTY) break;                             // claimed for this key
+                }
+                if ((old >> 13) == key) { atomicMin(&tab[slot], word); break; }
+                slot = slot + 1 == T ? 0u : slot + 1;
+            }
+            sslot[ci] = (int)slot;
+        }
+    }
+    if (__syncthreads_or(bad)) return -1;
+    SPEC_T();
     int S = 0;
-    for (int base = 0; base < CH; base += nt) {
-        const int i = base + tid;
-        int head = 0;
-        unsigned long long w = 0;
-        if (i < CH) {
-            w = ssort[i];
-            head = (i == 0) || ((ssort[i - 1] >> 13) != (w >> 13));
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        if (it * nt >= CH) break;                                        // (uniform)
+        const int ci = tid + it * nt;
+        int head = 0, slot = 0;
+        if (ci < CH) {
+            slot = sslot[ci];
+            head = (int)(tab[slot] & 0x1FFFu) == ci;
         }
         int tot;
-        const int ex = block_excl_scan(head, &tot, wsum);
-        if (i < CH) {
-            const int run = S + ex + head - 1;
-            const int ci = (int)(w & 0x1FFFu);
-            crow_g[ci] = run;
-            if (head && row_base + run < capRows) {
-                int lo = 0, hi = P - 1;                                  // parent of child ci: schoff[r] <= ci < schoff[r + 1]
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (schoff[mid] <= ci) lo = mid; else hi = mid - 1;
-                }
-                double c[4];
-                div_child(Bn + 4 * lo, div_plan(Bn + 4 * lo), ci - schoff[lo], min_side, c);
+        const int ex = block_excl_scan(head, &tot, wsum);               // (also fences the reads above from the writes below)
+        if (head) {
+            const int run = S + ex;
+            tab[slot] = (tab[slot] & ~0x1FFFull) | (unsigned)run;       // the window's row, for its other children
+            if (row_base + run < capRows) {
                 const size_t row = (size_t)(row_base + run);
                 urois[5 * row] = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    urois[5 * row + 1 + q] = (float)(c[q] * scale);
-                    ubox[4 * row + q] = c[q];
+                    urois[5 * row + 1 + q] = (float)(cb[it][q] * scale);
+                    ubox[4 * row + q] = cb[it][q];
                 }
             }
         }
         S += tot;
     }
+    __syncthreads();
+    SPEC_T();
+    for (int ci = tid; ci < CH; ci += nt) crow_g[ci] = (int)(tab[sslot[ci]] & 0x1FFFu);
+    SPEC_T();
+#ifdef AZ_SPEC_TIMING
+    if (tid == 0) { printf("spec stage P=%d CH=%d S=%d (x10ns):", P, CH, S); for (int i = 1; i < tqn; ++i) printf(" %llu", tq[i] - tq[i - 1]); printf("\n"); }
+#endif
     if (row_base + S > capRows) return -1;
     return S;
 }

@@ -302,8 +302,9 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         //      children of its regions -- level l+2's outputs will be looked up there
         int S = 0;
         if (a.spec_next && l + 2 < a.nlev && Pn > 0) {
-            S = spec_children_rows(sBn, Pn, a.scale, a.min_side, a.spatial_scale, ssort, sbuf + W_TMP2, sbins, s_mm, wsum,
-                                   schoff, LV_C, a.choff_next, a.crow, a.urois, a.ubox, Un, a.capR);
+            static_assert(W_TMP2 == W_SORT + LV_C, "the window table spans the sort words and the scratch behind them");
+            S = spec_children_rows<LV_C / NT>(sBn, Pn, a.scale, a.min_side, a.spatial_scale, sbuf + W_SORT, 2 * LV_C, wsum,
+                                              schoff, LV_C, a.choff_next, a.crow, a.urois, a.ubox, Un, a.capR);
             if (S < 0) { if (tid == 0) atomicOr(&cnt->err, 8 | 64); return; }
         }
         if (tid == 0) { cnt->PR[l + 1] = Un + S; cnt->SPB[l + 1] = Un; cnt->SPN[l + 1] = S; }
