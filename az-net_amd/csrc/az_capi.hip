@@ -149,6 +149,7 @@ struct az_ctx {
     int profiling = 0;
     int event_errors = 0;              // hipEvent* calls that failed while profiling
     std::vector<AzEventRec> events;
+    std::vector<hipEvent_t> event_pool;   // recycled events
     std::vector<void *> allocs;        // head-sized buffers (az_load_head)
     std::vector<void *> allocs_geom;   // geometry buffers (first use)
     bool geom_ready = false;
@@ -238,13 +239,19 @@ int ensure_geom(az_ctx *c)
 // launch group, bit 2 = keep events across az_propose calls (read them once at the end).
 struct Timed {
     az_ctx *c; bool on; hipEvent_t a{}, b{}; const char *name; int level;
+    // (events are recycled through c->event_pool: creating one costs about as much as recording it)
+    static bool grab(az_ctx *c, hipEvent_t *e)
+    {
+        if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return true; }
+        return hipEventCreate(e) == hipSuccess;
+    }
     Timed(az_ctx *c_, const char *n, int l, int cls = 2) : c(c_), name(n), level(l)
     {
         on = (c_->profiling & 2) || ((c_->profiling & 1) && cls == 1);
         if (!on) return;
         // a failed event call drops this measurement (and is reported by az_last_kernel_times), never the search
-        if (hipEventCreate(&a) != hipSuccess) { on = false; ++c->event_errors; return; }
-        if (hipEventCreate(&b) != hipSuccess) { hipEventDestroy(a); on = false; ++c->event_errors; return; }
+        if (!grab(c, &a)) { on = false; ++c->event_errors; return; }
+        if (!grab(c, &b)) { hipEventDestroy(a); on = false; ++c->event_errors; return; }
         if (hipEventRecord(a, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); on = false; ++c->event_errors; }
     }
     ~Timed()
@@ -257,7 +264,11 @@ struct Timed {
 
 void clear_events(az_ctx *c)
 {
-    for (auto &e : c->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto &e : c->events) {
+        for (hipEvent_t ev : {e.a, e.b}) {
+            if (c->event_pool.size() < 4096) c->event_pool.push_back(ev); else hipEventDestroy(ev);
+        }
+    }
     c->events.clear();
 }
 
@@ -407,6 +418,8 @@ int az_destroy(az_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     clear_events(c);
+    for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
+    c->event_pool.clear();
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second.exec);
     c->graphs.clear();
     free_all(c);

@@ -151,6 +151,7 @@ constexpr int FL_C = 2048;        // children per fused level
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
+constexpr int SPEC_PRE = 64;     // rows of the speculative pass whose outputs are staged in LDS up front
 constexpr int NTL = 256;         // threads of the fused-levels workgroup: levels 1-3 hold <= a few hundred elements per stage,
                                  // and every stage boundary costs a barrier across all waves
 __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
@@ -189,10 +190,27 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     if (tid == 0) {                                  // lib/detect/test.py:355
         sB[0][0] = 0.0; sB[0][1] = 0.0; sB[0][2] = a.im_w - 1.0; sB[0][3] = a.im_h - 1.0;
     }
+    // The speculative pass's outputs (a few dozen rows) and the pre-pass's child offsets come in with ONE round trip:
+    // every stage below then reads LDS instead of paying a dependent global load (~1-2 us each, a dozen times).
+    __shared__ float s_zs[SPEC_PRE], s_ss[SPEC_PRE * AZ_NSUB], s_ds[SPEC_PRE * 4 * AZ_NSUB];
+    __shared__ int s_choff[SPEC_PRE];
+    const int specU_h = a.reset ? a.specU : cnt->specU;
+    const int P1spec = a.reset ? a.specP1 : cnt->specP1;
+    const bool pre = specU_h <= SPEC_PRE && P1spec <= SPEC_PRE;
+    if (pre) {
+        for (int i = tid; i < specU_h; i += NTL) s_zs[i] = a.zoom_s[i];
+        for (int i = tid; i < specU_h * AZ_NSUB; i += NTL) s_ss[i] = a.score_s[i];
+        for (int i = tid; i < specU_h * 4 * AZ_NSUB; i += NTL) s_ds[i] = a.delta_s[i];
+        for (int i = tid; i < P1spec; i += NTL) s_choff[i] = a.choff_all[i];
+    }
+    // (deferred root: level 2's regions are the pre-pass's B1 -- same round trip)
+    if (a.defer_root && P1spec <= FL_R)
+        for (int i = tid; i < P1spec * 4; i += NTL) sB[1][i] = a.specB1[i];
+    const float *zoom_s = pre ? s_zs : a.zoom_s, *score_s = pre ? s_ss : a.score_s, *delta_s = pre ? s_ds : a.delta_s;
+    const int *choff_all = pre ? s_choff : a.choff_all;
     __syncthreads();
     int P = 1;
     int ybase = 0;
-    const int P1spec = a.reset ? a.specP1 : cnt->specP1;
     int l0 = 0;
     if (a.defer_root) {
         // Level 1 needs no head output here: the root's zoom is forced (test.py:383-384), its candidates arrive
@@ -200,7 +218,6 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         const bool rz = (1.0 >= a.Tz);                  // zoom[0] = 1, then indZ = where(zoom >= Tz)
         P = rz ? P1spec : 0;
         if (P > FL_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
-        for (int i = tid; i < P * 4; i += NTL) sB[1][i] = a.specB1[i];
         if (tid == 0) {
             cnt->P[0] = 1; cnt->U[0] = 1; cnt->NC[0] = AZ_NSUB; cnt->ytot[0] = 0; cnt->PZ[0] = rz ? 1 : 0;
             cnt->CH[0] = rz ? div_nchildren(div_plan(sB[0])) : 0;
@@ -256,10 +273,10 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
                 const int srow = spec_row(r, rep);
                 float d4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) d4[q] = a.delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * s + q];
+                for (int q = 0; q < 4; ++q) d4[q] = delta_s[(size_t)srow * 4 * AZ_NSUB + 4 * s + q];
                 az_decode_box(B + 4 * rep, d4, a.im_h, a.im_w, a.eps, bx);
                 fl = cand_keep(bx, a.min_side);
-                sc = a.score_s[(size_t)srow * AZ_NSUB + s];
+                sc = score_s[(size_t)srow * AZ_NSUB + s];
             }
             int tot;
             const int off = block_excl_scan(fl, &tot, wsum);
@@ -282,7 +299,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
             if (r < P) {
                 int rep;
                 float z = 1.0f;                                   // test.py:383-384: zoom[0] = 1 at level 1
-                if (!(l == 0 && r == 0)) z = a.zoom_s[spec_row(r, rep)];
+                if (!(l == 0 && r == 0)) z = zoom_s[spec_row(r, rep)];
                 zf = ((double)z >= a.Tz);
             }
             int tot;
@@ -333,7 +350,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
                 const double *r = B + 4 * pr;
                 div_child(r, div_plan(r), bi, a.min_side, &sB[cur ^ 1][4 * slot]);
                 // level-3 regions remember their row in the speculative pass: (parent in B1, child)
-                ssrc[cur ^ 1][slot] = (l == 1) ? rb + P1spec + a.choff_all[pr] + bi : 0;
+                ssrc[cur ^ 1][slot] = (l == 1) ? rb + P1spec + choff_all[pr] + bi : 0;
             }
         if (tid == 0) cnt->CH[l] = CH;
         P = Pn;

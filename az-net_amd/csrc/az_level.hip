@@ -19,6 +19,7 @@
 // integers as the O(N^2) rank kernels.  Same device helpers (az_geom_dev.h) for the f64 arithmetic, built with
 // -ffp-contract=off.
 #include "az_geom_dev.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,11 +61,16 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     const int tid = threadIdx.x;
     AzCounts *cnt = a.cnt;
     const int l = a.level;
+    // Two workgroups: workgroup 0 walks the critical chain (zoom selection, divide_region, _sift_dup, the next level's
+    // rois, ...) and writes every counter; workgroup 1 copies this level's candidates to Y / aScores, which nothing
+    // before the final selection reads -- ~10 us of dependent global round trips off the path to the next head pass.
+    // Both read the same inputs; neither reads anything the other writes.
+    const bool copier = gridDim.x == 1 || blockIdx.x == 1, chain = blockIdx.x == 0;
     const int P = cnt->P[l];
     const int U = *a.Uptr;
     const int ybase = cnt->ytot[l];
     if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
-    if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0 && chain) atomicOr(&cnt->err, 8); return; }
     // the deferred root is the LAST row of this level's head pass (behind any pair-speculation rows)
     const int root_u = a.root_row ? cnt->PR[l] - 1 : 0;
     const int spec_base = cnt->SPB[l];                     // (lookup_next) first pair-speculation row of this level's pass
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         // the copy, in two batches of independent loads (the boxes of 12 candidates do not fit the registers
         // of a 1024-thread workgroup)
 #pragma unroll
-        for (int h = 0; h < 2 && 6 * h < per; ++h) {
+        for (int h = 0; h < 2 && 6 * h < per && copier; ++h) {
             double bx[6][4];
             float sc[6];
 #pragma unroll
@@ -130,9 +136,18 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         }
         nc = tot;
     }
-    if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0) atomicOr(&cnt->err, 2); }
+    if (ybase + nc > a.capCand) { nc = a.capCand - ybase; if (tid == 0 && chain) atomicOr(&cnt->err, 2); }
     int shift = 0;
-    if (a.root_row) {
+    if (a.root_row && !copier) {
+        // (the chain workgroup only needs the number of root candidates the MIN_SIDE filter kept)
+        const int kp = (tid < AZ_NSUB) ? (int)skeep[U * AZ_NSUB + tid] : 0;
+        const unsigned long long m = __ballot(kp);
+        if (tid == 0) wsum[0] = __popcll(m);
+        __syncthreads();
+        shift = AZ_NSUB - wsum[0];
+        __syncthreads();
+        if (tid == 0) cnt->NC[0] = AZ_NSUB - shift;
+    } else if (a.root_row) {
         // The root's row rode on this level's head pass (az_fused.hip: its candidates are the first of Y, and the
         // 11 slots at the head of Y / aScores were reserved for them): the kept ones go there in order, and if
         // the MIN_SIDE filter dropped some, everything behind closes the gap.
@@ -171,11 +186,11 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
                 __syncthreads();
             }
         }
-        if (tid == 0) {
-            cnt->NC[0] = nc0;
-            for (int ll = 1; ll <= l; ++ll) cnt->ytot[ll] -= shift;
-        }
+        // (ytot[1 .. l] keep the layout with the 11 reserved slots: nothing reads them again; ytot[l + 1] below is
+        //  the closed-up count)
+        if (tid == 0 && chain) cnt->NC[0] = nc0;
     }
+    if (!chain) return;
     TSTAMP();
 
     // ---- zoom selection (test.py:383-387) -----------------------------------------------------------
@@ -317,5 +332,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
 
 void azk_level_geom(hipStream_t s, const AzLevelArgs &a)
 {
-    hipLaunchKernelGGL(k_level_geom, dim3(1), dim3(NT), 0, s, a);
+    static int two = -1;                 // AZ_LEVEL_WGS=1: one workgroup does both roles (measurements)
+    if (two < 0) { const char *e = getenv("AZ_LEVEL_WGS"); two = (e && atoi(e) == 1) ? 0 : 1; }
+    hipLaunchKernelGGL(k_level_geom, dim3(two ? 2 : 1), dim3(NT), 0, s, a);
 }

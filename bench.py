@@ -138,6 +138,8 @@ def main():
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--no-extras", action="store_true", help="skip deep_tree / shared_detection / nms")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="HIP events around the fc GEMM launches of every n-th timed step (1: every step, ~30 us/step of stream time)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
     args = ap.parse_args()
 
@@ -229,31 +231,26 @@ def main():
     for n in nets[1:]:
         n.set_conv(conv)
 
-    inflight_gather = []
-
     def finish(last):
         """One image done; every gather_every images per rank (and at the end): ONE RCCL all-gather of the
-        records staged device-to-device by the searches, then the host copy of all ranks' proposals.  The exchange of
-        batch b runs on a side stream while the searches of batch b+1 run (double-buffered send buffer); every batch's
-        proposals are collected on the host inside the timed region."""
+        records staged device-to-device by the searches, then the host copy of all ranks' proposals."""
         if gat is not None:
             pending[0] += 1
             if pending[0] == args.gather_every or last:
-                h = (gat.gather_begin(pending[0]), pending[0])
-                if inflight_gather:
-                    hp, npend = inflight_gather.pop(0)
-                    assert len(gat.gather_end(hp)) == world * npend
-                inflight_gather.append(h)
+                res = gat.gather(pending[0])
+                assert len(res) == world * pending[0]
                 pending[0] = 0
                 rccl["collectives"] += 1
-            if last:
-                while inflight_gather:
-                    hp, npend = inflight_gather.pop(0)
-                    assert len(gat.gather_end(hp)) == world * npend
+
+    ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
 
     def run(nsteps, prm):
         if args.inflight == 1:
             for i in range(nsteps):
+                if ev_every[0]:
+                    # (an event pair costs ~7 us of stream time: the launches of every 5th step are timed (a stride coprime to the 4 rotated maps), spread over
+                    #  the whole timed region)
+                    net.ctx.set_profiling(((2 if args.profile_all else 1) | 4) if i % ev_every[0] == 0 else 4)
                 # this step's image: its map is handed over with the launch
                 net.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
                 if gat is not None:
@@ -290,11 +287,14 @@ def main():
     for n in nets:
         n.ctx.set_profiling(0)
         n.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
+    ev_every[0] = args.event_every if args.inflight == 1 else 0
     barrier()
     t0 = time.perf_counter()
     run(args.steps, params)
     barrier()
     dt = maxr(time.perf_counter() - t0)
+    ev_every[0] = 0
+    n_timed_steps = len(range(0, args.steps, args.event_every)) if args.inflight == 1 else args.steps
     ktimes = []
     for n in nets:
         ktimes += n.ctx.last_kernel_times()
@@ -321,7 +321,7 @@ def main():
         gemm_ms_total = sum(ms for _, _, ms in gemm)
         n_launch = max(len(gemm), 1)
         flops_per_image = sum(uniq) * GEMM_FLOP_PER_ROI
-        achieved = flops_per_image * args.steps / (gemm_ms_total * 1e-3) / 1e12 if gemm_ms_total > 0 else 0.0
+        achieved = flops_per_image * n_timed_steps / (gemm_ms_total * 1e-3) / 1e12 if gemm_ms_total > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate runs); cannot be collected live, so it is read from the committed summary.
         traffic, traffic_source = None, None
@@ -384,9 +384,10 @@ def main():
                                    "(int6 below, int7_1|int7_2); v_mfma_f32_32x32x2_f32",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "flops_per_launch": flops_per_image / (n_launch / max(args.steps, 1)),
+                         "flops_per_launch": flops_per_image / (n_launch / max(n_timed_steps, 1)),
                          "avg_launch_ms": gemm_ms_total / n_launch,
-                         "launches_per_step": n_launch / max(args.steps, 1), "traffic": traffic,
+                         "launches_per_step": n_launch / max(n_timed_steps, 1),
+                         "steps_with_events": n_timed_steps, "traffic": traffic,
                          "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes,
                          "note": "achieved = ALGORITHMIC flops (unique RoIs of the tree x 216 006 656) / time inside the "
                                  "fc GEMM launches (HIP events on the ctx stream); speculative rows that the tree did "
@@ -397,7 +398,7 @@ def main():
             "plan_build_ms": {"first_call_ms": first_ms, "steady_call_ms": steady_ms, "one_time_ms": max(first_ms - steady_ms, 0.0),
                               "note": "one-time work per image shape (shape-dependent pre-pass / plan, first-use allocations), "
                                       "done before the warm-up and not part of `value`"},
-            "kernel_ms_per_step": {k: float(np.sum(v)) / args.steps for k, v in sorted(per_level.items())},
+            "kernel_ms_per_step": {k: float(np.sum(v)) / n_timed_steps for k, v in sorted(per_level.items())},
         }
 
     def timed_loop(fn, n, warm=10):

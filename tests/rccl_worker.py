@@ -90,7 +90,12 @@ def main():
                     net.ctx.propose_launch(params_of(i, ffi, synth, k))
                     gats[hk].stage(j)
                     net.ctx.propose_fetch()
-                res = gats[hk].gather(len(batch))           # all ranks' rows of this batch, rank-interleaved
+                # all ranks' rows of this batch, rank-interleaved; odd batches through the non-blocking form
+                # (side stream, double-buffered send buffer, pinned host copy)
+                if b % 2:
+                    res = gats[hk].gather_end(gats[hk].gather_begin(len(batch)))
+                else:
+                    res = gats[hk].gather(len(batch))
                 got.append(res)
             # global order of this head's images: batch b holds ids[b*rows*world : ...] interleaved by rank
             flat = [x for res in got for x in res]
