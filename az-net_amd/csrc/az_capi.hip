@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -24,7 +25,7 @@ struct az_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int maxR = 16384, maxCand = 16384 * AZ_NSUB, maxCh = 65536;
-    bool head_loaded = false, launched = false;
+    bool head_loaded = false;
     AzHeadDims d{};
     int S6 = 1, S7 = 1;
     // int6 on the bf16 matrix cores for launches of > 64 rows: 0 = off (fp32 MFMA everywhere),
@@ -36,7 +37,11 @@ struct az_ctx {
     float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
     // feature map
     const float *feat = nullptr;        // channel-last copy of the current map (what RoIPool reads)
-    float *feat_owned = nullptr;        // [H][W][C]
+    // [H][W][C] copies of NCHW maps, two of them used in turn: the map of a search that is still queued (and might have to
+    // be run again in another form) survives the hand-over of the next image's map
+    float *feat_owned[2] = {nullptr, nullptr};
+    int feat_turn = 0;
+    unsigned feat_gen = 0;              // bumped when the copies are reallocated
     float *feat_stage = nullptr;        // NCHW staging for host uploads
     size_t feat_owned_elems = 0;
     // level-loop buffers (HBM)
@@ -126,7 +131,28 @@ struct az_ctx {
     double *h_Y = nullptr;
     float *h_S = nullptr;
     int h_cap = 0;
-    // last launch
+    // Searches launched and not yet fetched, oldest first (at most two: the host may enqueue the next image's launch
+    // sequence while the GPU still works on the current one -- same stream, so the searches never overlap on the GPU).
+    // With a fixed proposal count the result block's device-to-host copy is enqueued right behind the search's kernels,
+    // into a pinned slot of its own; az_propose_fetch then only waits for that copy's event.
+    struct PendingSearch {
+        az_params p{};
+        int nlev = 0, is_static = 0, defer = 0, pair_mask = 0, npass = 0;
+        int pass_src[AZ_MAX_LEVELS + 2] = {0};
+        void *stage_dst = nullptr;          // az_propose_stage_result_dev target
+        size_t stage_cap = 0;
+        int slot = 0;
+        bool copied = false;                // result block already on its way to h_res[slot]
+        const float *feat = nullptr;        // the map the search reads (a rerun in another form needs it again)
+        int fH = 0, fW = 0;
+        unsigned feat_gen = 0;
+        bool feat_is_copy = false;          // `feat` is one of the ctx's own channel-last copies (gone if they are reallocated)
+    };
+    std::deque<PendingSearch> pend;
+    unsigned char *h_res[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_res[3] = {nullptr, nullptr, nullptr};
+    bool slot_busy[3] = {false, false, false};
+    // parameters of the last FETCHED search
     az_params last{};
     int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels 1-3 overflowed
     int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which a later level outgrew the fused level kernel
@@ -135,14 +161,11 @@ struct az_ctx {
     struct GraphEntry { hipGraphExec_t exec; int npass; int pass_src[AZ_MAX_LEVELS + 2]; };
     std::map<std::string, GraphEntry> graphs;        // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
-    int last_nlev = 0;
     int last_defer = 0;
     // head passes of the search being enqueued / last launched: where each one's row count lives
     // (>= 0: int index into AzCounts; < 0: -(rows + 1), a count the host knows)
     int npass = 0;
     int pass_src[AZ_MAX_LEVELS + 2] = {0};
-    void *stage_dst = nullptr;          // az_propose_stage_result_dev target of the search in flight
-    size_t stage_cap = 0;
     int his_n = 0;                      // rows of the anchor history of the last fetched tuner search
     int cand_n = -1;                    // candidates of the last fetched search still in Yall/Sall (-1: overwritten)
     // profiling
@@ -408,6 +431,9 @@ int az_create(int device, az_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AZ_ERR_HIP; }
     if (hipHostMalloc((void **)&c->h_cnt, RES_HDR + (size_t)AZ_TOPK_MAX * 36) != hipSuccess) { delete c; return AZ_ERR_HIP; }
+    for (int i = 0; i < 3; ++i)
+        if (hipHostMalloc((void **)&c->h_res[i], RES_HDR + (size_t)AZ_TOPK_MAX * 36) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_res[i], hipEventDisableTiming) != hipSuccess) { az_destroy(c); return AZ_ERR_HIP; }
     *out = c;
     return AZ_OK;
 }
@@ -429,12 +455,16 @@ int az_destroy(az_ctx *c)
     c->allocs_det.clear();
     for (auto *q : c->plans) { free_plan(q); delete q; }
     c->plans.clear();
-    if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
+    if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
     for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
                     (void *)c->hisZ, (void *)c->pool, (void *)c->pool_tmp, (void *)c->pool_n, (void *)c->pool_hist})
         if (p) hipFree(p);
     if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
+    for (int i = 0; i < 3; ++i) {
+        if (c->h_res[i]) hipHostFree(c->h_res[i]);
+        if (c->ev_res[i]) hipEventDestroy(c->ev_res[i]);
+    }
     if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
     if (c->stream) hipStreamDestroy(c->stream);
@@ -562,9 +592,11 @@ static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host,
     const size_t n = (size_t)C * H * W;
     if (n > c->feat_owned_elems) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->feat_owned) { hipFree(c->feat_owned); hipFree(c->feat_stage); }
-        c->feat_owned = c->feat_stage = nullptr; c->feat_owned_elems = 0;
-        HIPCHK(c, hipMalloc((void **)&c->feat_owned, n * 4));
+        if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
+        c->feat_owned[0] = c->feat_owned[1] = c->feat_stage = nullptr; c->feat_owned_elems = 0;
+        ++c->feat_gen;
+        HIPCHK(c, hipMalloc((void **)&c->feat_owned[0], n * 4));
+        HIPCHK(c, hipMalloc((void **)&c->feat_owned[1], n * 4));
         HIPCHK(c, hipMalloc((void **)&c->feat_stage, n * 4));
         c->feat_owned_elems = n;
     }
@@ -574,9 +606,10 @@ static int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host,
         nchw = c->feat_stage;
     }
     // RoIPool reads the map channel-last: one transpose per image, outside the level loop.
-    azk_nchw_to_nhwc(c->stream, nchw, c->feat_owned, C, H * W);
+    c->feat_turn ^= 1;
+    azk_nchw_to_nhwc(c->stream, nchw, c->feat_owned[c->feat_turn], C, H * W);
     if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may now reuse / free `src`
-    c->feat = c->feat_owned;
+    c->feat = c->feat_owned[c->feat_turn];
     c->d.H = H; c->d.W = W;
     return AZ_OK;
 }
@@ -1028,6 +1061,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         if (k <= 0) return fail(c, AZ_ERR_INVALID, "az_propose: num_proposals must be positive");
         if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
     }
+    if (c->pend.size() >= 2) return fail(c, AZ_ERR_STATE, "az_propose_launch: two searches are already queued, fetch one first");
+    if (!c->pend.empty() && !(p->fixed_num && c->pend.back().copied))
+        return fail(c, AZ_ERR_STATE, "az_propose_launch: queueing a search behind another needs a fixed proposal count for both");
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
@@ -1097,10 +1133,22 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         if ((rc = enqueue()) != AZ_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
-    c->last = *p;
-    c->last_nlev = nlev;
-    c->launched = true;
-    c->stage_dst = nullptr;
+    az_ctx::PendingSearch q;
+    q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
+    q.npass = c->npass;
+    q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
+    q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
+    std::memcpy(q.pass_src, c->pass_src, sizeof(q.pass_src));
+    for (q.slot = 0; q.slot < 2 && c->slot_busy[q.slot]; ++q.slot) { }
+    if (p->fixed_num) {
+        // the result block follows the search's kernels in stream order: whatever is enqueued next (the next image's
+        // search, a unit call) finds it already on its way to the host
+        HIPCHK(c, hipMemcpyAsync(c->h_res[q.slot], c->cnt, RES_HDR + (size_t)k * 36, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_res[q.slot], s));
+        q.copied = true;
+    }
+    c->slot_busy[q.slot] = true;
+    c->pend.push_back(q);
     return AZ_OK;
 }
 
@@ -1123,27 +1171,32 @@ int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, in
     return az_propose_launch(c, p);
 }
 
-int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
+// Collect the result of the search at position `idx` of the pending queue (0 = the oldest; a fallback rerun sits at
+// the back) and remove it from the queue.
+static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
 {
-    if (!c || !c->launched) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");
-    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_propose_fetch: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int nlev = c->last_nlev;
-    // With a fixed proposal count the output size is bounded up front: one batched D2H, one sync.
-    const int want = c->last.fixed_num ? c->last.num_proposals : -1;
+    const az_ctx::PendingSearch q = c->pend[idx];
+    const int nlev = q.nlev;
+    // With a fixed proposal count the output size is bounded up front: one batched D2H (enqueued by the launch), one wait.
+    const int want = q.p.fixed_num ? q.p.num_proposals : -1;
     int rc;
     const double *hY = nullptr;
     const float *hS = nullptr;
-    if (want > 0) {
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, RES_HDR + (size_t)want * 36, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        hY = (const double *)((const unsigned char *)c->h_cnt + RES_HDR);
-        hS = (const float *)((const unsigned char *)c->h_cnt + RES_HDR + (size_t)want * 32);
+    unsigned char *blk = c->h_res[q.slot];
+    auto drop = [&]() { c->pend.erase(c->pend.begin() + (long)idx); c->slot_busy[q.slot] = false; };
+    if (q.copied) {
+        const hipError_t e = hipEventSynchronize(c->ev_res[q.slot]);
+        if (e != hipSuccess) { drop(); return fail(c, AZ_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e)); }
+        hY = (const double *)(blk + RES_HDR);
+        hS = (const float *)(blk + RES_HDR + (size_t)want * 32);
     } else {
-        HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+        // (variable proposal count: nothing is queued behind this search)
+        drop();
+        HIPCHK(c, hipMemcpyAsync(blk, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
-        int n = c->h_cnt->nsel;
+        int n = ((const AzCounts *)blk)->nsel;
         if (n > c->maxCand) n = c->maxCand;
         if ((rc = ensure_host(c, n > 0 ? n : 1)) != AZ_OK) return rc;
         if (n > 0) {
@@ -1154,18 +1207,19 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
         hY = c->h_Y;              // (ensure_host may have moved them)
         hS = c->h_S;
     }
-    c->launched = false;
-    const AzCounts &h = *c->h_cnt;
+    if (q.copied) drop();
+    c->last = q.p;
+    const AzCounts &h = *(const AzCounts *)blk;
     if (st) {
         std::memset(st, 0, sizeof(*st));
         st->n_levels = nlev;
         st->n_candidates = h.ytot[nlev];
         st->spec_rows = h.specU;
-        st->root_deferred = c->last_defer;
-        st->static_plan = c->last_static;
+        st->root_deferred = q.defer;
+        st->static_plan = q.is_static;
         const int *hc = reinterpret_cast<const int *>(&h);
-        for (int i = 0; i < c->npass && i < AZ_MAX_LEVELS; ++i) {
-            const int r = c->pass_src[i] >= 0 ? hc[c->pass_src[i]] : -c->pass_src[i] - 1;
+        for (int i = 0; i < q.npass && i < AZ_MAX_LEVELS; ++i) {
+            const int r = q.pass_src[i] >= 0 ? hc[q.pass_src[i]] : -q.pass_src[i] - 1;
             if (r > 0) st->pass_rows[st->n_passes++] = r;
         }
         for (int l = 0; l < nlev; ++l) {
@@ -1173,67 +1227,74 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
             st->level_unique[l] = h.U[l];
             st->level_zoomed[l] = h.PZ[l];
             st->num_eval += h.P[l];
-            if (h.P[l] > 0) st->depth = (c->last.reserved & 4) ? l : l + 1;   // tune.py counts k from 0
+            if (h.P[l] > 0) st->depth = (q.p.reserved & 4) ? l : l + 1;   // tune.py counts k from 0
         }
     }
-    if ((h.err & 32) && c->last_static) {
-        // a zoom score of the tree is not >= Tz (NaN): the one-pass plan's premise fails for this image -> level loop
-        az_params p2 = c->last;
-        p2.reserved |= 32;
-        void *sd = c->stage_dst;
-        const size_t sc = c->stage_cap;
+    // A search that has to be run again in another form is launched now (behind whatever is queued), its record staged
+    // where the failed run's was, and collected from the back of the queue.
+    auto rerun = [&](az_params p2) {
+        const int err = h.err;
+        (void)err;
+        // (a queue that is full cannot take the rerun: the caller queued ahead, so the oldest other search is collected
+        //  only after this one -- make room by running this rerun with the queue drained)
+        if (c->pend.size() >= 2) return fail(c, AZ_ERR_STATE, "az_propose_fetch: no room to rerun a search in another form");
+        // the rerun reads THIS search's map (a later one may have been handed over since)
+        if (q.feat_is_copy && q.feat_gen != c->feat_gen)
+            return fail(c, AZ_ERR_STATE, "az_propose_fetch: the queued search has to be rerun but its feature map copy was reallocated");
+        const float *cur_feat = c->feat;
+        const int cur_H = c->d.H, cur_W = c->d.W;
+        c->feat = q.feat; c->d.H = q.fH; c->d.W = q.fW;
         int rc2 = az_propose_launch(c, &p2);
+        c->feat = cur_feat; c->d.H = cur_H; c->d.W = cur_W;
         if (rc2) return rc2;
-        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;
-        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+        c->pend.back().feat = q.feat; c->pend.back().fH = q.fH; c->pend.back().fW = q.fW;
+        if (q.stage_dst && (rc2 = az_propose_stage_result_dev(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
+        return fetch_entry(c, c->pend.size() - 1, boxes_out, scores_out, cap, n_out, st);
+    };
+    if ((h.err & 32) && q.is_static) {
+        // a zoom score of the tree is not >= Tz (NaN): the one-pass plan's premise fails for this image -> level loop
+        az_params p2 = q.p;
+        p2.reserved |= 32;
+        return rerun(p2);
     }
-    if ((h.err & 64) && !(c->last.reserved & 64)) {
+    if ((h.err & 64) && !(q.p.reserved & 64)) {
         // the pair-speculation rows of a level outgrew the tables: this image shape runs without them from now on
         if (c->nopair.size() >= 32) c->nopair.erase(c->nopair.begin());
-        c->nopair.emplace_back(c->last.im_h, c->last.im_w);
-        az_params p2 = c->last;
+        c->nopair.emplace_back(q.p.im_h, q.p.im_w);
+        az_params p2 = q.p;
         p2.reserved = (p2.reserved | 64) & ~128;
-        void *sd = c->stage_dst;
-        const size_t sc = c->stage_cap;
-        int rc2 = az_propose_launch(c, &p2);
-        if (rc2) return rc2;
-        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;
-        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+        return rerun(p2);
     }
-    if ((h.err & 8) && !(c->last.reserved & 2)) {
+    if ((h.err & 8) && !(q.p.reserved & 2)) {
         // a fused level outgrew its LDS tables: rerun with the multi-launch kernels and remember
         // the image shape so that later calls skip the fused attempt -- first only for the levels after the
         // speculative ones (az_level.hip), then, if levels 1-3 themselves overflow, for everything
-        const bool lv_was_on = !(c->last.reserved & 16) && c->level_fused_env != 0 &&
-                               !(c->last.im_h == c->nofuse_lv_h && c->last.im_w == c->nofuse_lv_w);
-        az_params p2 = c->last;
-        if (lv_was_on) { c->nofuse_lv_h = c->last.im_h; c->nofuse_lv_w = c->last.im_w; p2.reserved |= 16; }
-        else { c->nofuse_h = c->last.im_h; c->nofuse_w = c->last.im_w; p2.reserved |= 2; }
-        void *sd = c->stage_dst;
-        const size_t sc = c->stage_cap;
-        int rc2 = az_propose_launch(c, &p2);
-        if (rc2) return rc2;
-        if (sd && (rc2 = az_propose_stage_result_dev(c, sd, sc)) != AZ_OK) return rc2;   // the staged record was the failed run's
-        return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+        const bool lv_was_on = !(q.p.reserved & 16) && c->level_fused_env != 0 &&
+                               !(q.p.im_h == c->nofuse_lv_h && q.p.im_w == c->nofuse_lv_w);
+        az_params p2 = q.p;
+        if (lv_was_on) { c->nofuse_lv_h = q.p.im_h; c->nofuse_lv_w = q.p.im_w; p2.reserved |= 16; }
+        else { c->nofuse_h = q.p.im_h; c->nofuse_w = q.p.im_w; p2.reserved |= 2; }
+        return rerun(p2);
     }
     if (h.err)
         return fail(c, AZ_ERR_CAPACITY,
                     std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
                         "): raise az_set_limits");
-    if (!c->last_static && !(c->last.reserved & 4)) {
+    if (!q.is_static && !(q.p.reserved & 4)) {
         for (int l = 0; l < AZ_MAX_LEVELS; ++l) {
             const bool in = l < nlev;
             // rows of the pass at that level (fused level loop: PR; multi-launch forms: the level's unique rois)
-            c->hint_rows[l] = in ? (h.PR[l] > 0 ? h.PR[l] : (((c->last_pair_mask >> (l > 0 ? l - 1 : 0)) & 1) && l > 0 ? 0 : h.U[l])) : 0;
+            c->hint_rows[l] = in ? (h.PR[l] > 0 ? h.PR[l] : (((q.pair_mask >> (l > 0 ? l - 1 : 0)) & 1) && l > 0 ? 0 : h.U[l])) : 0;
             c->hint_P[l] = in ? h.P[l] : 0;
             c->hint_PZ[l] = in ? h.PZ[l] : 0;
             c->hint_U[l] = in ? h.U[l] : 0;
-            c->hint_SPN[l] = (in && ((c->last_pair_mask >> l) & 1)) ? h.SPN[l] : -1;
+            c->hint_SPN[l] = (in && ((q.pair_mask >> l) & 1)) ? h.SPN[l] : -1;
         }
-        c->hint_h = c->last.im_h; c->hint_w = c->last.im_w; c->hint_nlev = nlev;
+        c->hint_h = q.p.im_h; c->hint_w = q.p.im_w; c->hint_nlev = nlev;
     }
     const int n = h.nsel;
-    c->cand_n = h.ytot[nlev];
+    // (the candidate list stays readable only while no later search has been queued: it would be overwriting it)
+    c->cand_n = c->pend.empty() ? h.ytot[nlev] : -1;
     c->his_n = h.nhis;
     if (st) st->n_proposals = n;
     *n_out = n;
@@ -1241,6 +1302,13 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
     std::memcpy(boxes_out, hY, (size_t)n * 4 * sizeof(double));
     if (scores_out) std::memcpy(scores_out, hS, (size_t)n * sizeof(float));
     return AZ_OK;
+}
+
+int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
+{
+    if (!c || c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");
+    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_propose_fetch: bad arguments");
+    return fetch_entry(c, 0, boxes_out, scores_out, cap, n_out, st);
 }
 
 int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_out, int cap, int *n_out,
@@ -1263,13 +1331,15 @@ int az_result_record_layout(int k, size_t *bytes, size_t *n_off, size_t *boxes_o
 
 int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
 {
-    if (!c || !c->launched) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev without az_propose_launch");
-    if (!c->last.fixed_num) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev: fixed proposal count only");
-    const size_t bytes = RES_HDR + (size_t)c->last.num_proposals * 36;
+    // (applies to the search launched last: call it right behind az_propose_launch)
+    if (!c || c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev without az_propose_launch");
+    az_ctx::PendingSearch &q = c->pend.back();
+    if (!q.p.fixed_num) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev: fixed proposal count only");
+    const size_t bytes = RES_HDR + (size_t)q.p.num_proposals * 36;
     if (!dst_dev || cap_bytes < bytes) return fail(c, AZ_ERR_INVALID, "az_propose_stage_result_dev: destination too small");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->cnt, bytes, hipMemcpyDeviceToDevice, c->stream));
-    c->stage_dst = dst_dev; c->stage_cap = cap_bytes;
+    q.stage_dst = dst_dev; q.stage_cap = cap_bytes;
     return AZ_OK;
 }
 

@@ -325,16 +325,14 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         }
         if (CH > FL_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
         __syncthreads();
-        for (int z = tid; z < PZ; z += NTL) {
+        // (one thread per CHILD: a parent's children one after the other are ~35 dependent f64 divisions)
+        for (int ci = tid; ci < CH; ci += NTL) {
+            const int z = seg_of(schoff, PZ, ci);
             const double *r = B + 4 * szr[z];
-            const DivPlan p = div_plan(r);
-            const int nb = div_nchildren(p);
-            const int o = schoff[z];
-            for (int bi = 0; bi < nb; ++bi) {
-                double c[4];
-                skeyC[o + bi] = div_child(r, p, bi, a.min_side, c);
-                sczi[o + bi] = (z << 16) | bi;
-            }
+            const int bi = ci - schoff[z];
+            double c[4];
+            skeyC[ci] = div_child(r, div_plan(r), bi, a.min_side, c);
+            sczi[ci] = (z << 16) | bi;
         }
         __syncthreads();
         TSTAMP(tsn++);

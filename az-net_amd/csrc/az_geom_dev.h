@@ -171,6 +171,17 @@ static __device__ void block_bucket_sort(unsigned long long *w, int N, unsigned 
     __syncthreads();
 }
 
+// Segment of position i in an ascending offset table off[0 .. n): the last s with off[s] <= i.
+static __device__ __forceinline__ int seg_of(const int *off, int n, int i)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 static __device__ __forceinline__ int next_pow2(int v)
 {
     int n = 2;

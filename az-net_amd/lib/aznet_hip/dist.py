@@ -117,7 +117,7 @@ def unpack_device_record(raw, layout, k):
 
 
 class DeviceGather(object):
-    """Send buffer of `rows` result records in HBM + the all-gather over them.
+    """Send buffers of `rows` result records in HBM + the all-gather over them.
 
         g = DeviceGather(ctx, num_proposals, rows, device)
         for j in range(n_local):
@@ -125,8 +125,10 @@ class DeviceGather(object):
         everything = g.gather(n_local)       # all ranks' images, global image order
 
     stage(j) enqueues a device-to-device copy of the search's result record into row j on the ctx
-    stream (complete when propose_fetch returns); gather() marks the rows past n_local as padding,
-    runs ONE all_gather_into_tensor on the device buffers and unpacks on the host."""
+    stream (complete when that search's propose_fetch returns); gather() marks the rows past n_local as padding,
+    runs ONE all_gather_into_tensor on the device buffers and unpacks on the host.
+    There are TWO buffer pairs (`buf` = 0 / 1): a caller that launches the first search of the next batch before it
+    gathers the current one (propose_launch queues up to two searches) stages that search into the other pair."""
 
     def __init__(self, ctx, num_proposals, rows, device, group=None, always_collective=None):
         import torch
@@ -139,74 +141,62 @@ class DeviceGather(object):
         self.layout = ffi.AzContext.result_record_layout(self.k)
         self.rec_bytes = self.layout[0]
         self.device = device
-        self.send = torch.zeros((self.rows, self.rec_bytes), dtype=torch.uint8, device=device)
         self.world = _world(group)
-        self.recv = torch.empty((self.world * self.rows, self.rec_bytes), dtype=torch.uint8, device=device)
+        self.bufs = [(torch.zeros((self.rows, self.rec_bytes), dtype=torch.uint8, device=device),
+                      torch.empty((self.world * self.rows, self.rec_bytes), dtype=torch.uint8, device=device))
+                     for _ in range(2)]
+        self.send, self.recv = self.bufs[0]
         pad = np.zeros(self.rec_bytes, dtype=np.uint8)
         pad[self.layout[1]:self.layout[1] + 4] = np.array([-1], dtype=np.int32).view(np.uint8)
         self._pad = torch.from_numpy(pad).to(device)
 
-    def stage(self, j):
+    def stage(self, j, buf=0):
         assert 0 <= j < self.rows
-        self.ctx.stage_result(self.send.data_ptr() + j * self.rec_bytes, self.rec_bytes)
+        self.ctx.stage_result(self.bufs[buf][0].data_ptr() + j * self.rec_bytes, self.rec_bytes)
 
-    # ---- the same exchange without stalling the searches -------------------------------------------------------
-    def gather_begin(self, n_local):
-        """Start the exchange of the batch just staged and return a handle; the searches of the NEXT batch may be
-        launched (and staged: the send buffer is double-buffered) before `gather_end(handle)` collects the result.
-        Call after the last propose_fetch of the batch, like gather().  The collective and the device-to-host copy
+    def _exchange(self, n_local, buf):
+        import torch.distributed as dist
+        send, recv = self.bufs[buf]
+        if n_local < self.rows:
+            send[n_local:] = self._pad
+        if self.world > 1 or self.collective:
+            # stage() copies ran on the ctx stream and are complete (propose_fetch waited for the search behind which
+            # each was enqueued); the pad write above and the collective are ordered by torch's current stream, which
+            # all_gather_into_tensor joins with RCCL's stream on both sides (async_op=False)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            return recv, self.world
+        return send, 1
+
+    def gather(self, n_local, to_host=True, buf=0):
+        """After the propose_fetch of the batch's last search."""
+        import torch
+        got, w = self._exchange(n_local, buf)
+        if not to_host:
+            torch.cuda.current_stream(got.device).synchronize()
+            return None
+        raw = got.cpu().numpy().reshape(w, self.rows, self.rec_bytes)
+        return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))
+
+    # ---- the same exchange without stalling the host ----------------------------------------------------------
+    def gather_begin(self, n_local, buf=0):
+        """Start the exchange of the batch staged in pair `buf` and return a handle; `gather_end(handle)` collects the
+        result later (stage the next batch into the other pair meanwhile).  The collective and the device-to-host copy
         run on a side stream; nothing here blocks the host."""
         import torch
-        import torch.distributed as dist
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream(device=self.device)
-            self._bufs = [(self.send, self.recv)]
-            self._bufs.append((torch.zeros_like(self.send), torch.empty_like(self.recv)))
-            self._host = [torch.empty(self.recv.shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            self._turn = 0
-        send, recv = self._bufs[self._turn]
-        host = self._host[self._turn]
-        assert send.data_ptr() == self.send.data_ptr()
+            self._host = [torch.empty(self.bufs[0][1].shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        host = self._host[buf]
         ev = torch.cuda.Event()
-        # (the staged copies ran on the ctx stream and are complete: propose_fetch synchronised it)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
-            if n_local < self.rows:
-                send[n_local:] = self._pad
-            if self.world > 1 or self.collective:
-                dist.all_gather_into_tensor(recv, send, group=self.group)
-                src = recv
-            else:
-                src = send
+            src, w = self._exchange(n_local, buf)
             host[:src.shape[0]].copy_(src, non_blocking=True)
             ev.record(self._side)
-        # the next batch stages into the other buffer
-        self._turn ^= 1
-        self.send, self.recv = self._bufs[self._turn]
-        return (ev, host, self.world if (self.world > 1 or self.collective) else 1)
+        return (ev, host, w)
 
     def gather_end(self, handle):
         ev, host, w = handle
         ev.synchronize()
         raw = host.numpy()[:w * self.rows].reshape(w, self.rows, self.rec_bytes)
-        return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))
-
-    def gather(self, n_local, to_host=True):
-        """After the last propose_fetch of the batch (the ctx stream is idle then)."""
-        import torch
-        import torch.distributed as dist
-        if n_local < self.rows:
-            self.send[n_local:] = self._pad
-        if self.world > 1 or self.collective:
-            # stage() copies ran on the ctx stream and are complete (propose_fetch synchronised it); the pad write
-            # above and the collective are ordered by torch's current stream, which all_gather_into_tensor joins
-            # with RCCL's stream on both sides (async_op=False)
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            got = self.recv
-        else:
-            got = self.send
-        if not to_host:
-            torch.cuda.current_stream(self.send.device).synchronize()
-            return None
-        raw = got.cpu().numpy().reshape(self.world, self.rows, self.rec_bytes)
         return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))

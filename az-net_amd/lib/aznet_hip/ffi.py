@@ -316,25 +316,46 @@ class AzContext(object):
         (az_propose_launch_on); it must stay untouched until propose_fetch returns.  producer_done=True skips the
         synchronisation of torch's current stream (the caller knows the map is complete); producer_event (a
         torch.cuda.Event recorded behind the map's producer) orders the search behind it ON THE DEVICE instead, so the
-        host can go on and enqueue the next image's backbone while this search runs."""
+        host can go on and enqueue the next image's backbone while this search runs.
+        Up to two searches may be launched before the first is fetched (fixed proposal count): the host then enqueues
+        the next image's launch sequence while the GPU still works on the current one -- same stream, the searches do not
+        overlap on the GPU; propose_fetch returns them oldest first."""
         self._last_params = params
+        if not hasattr(self, "_queued"):
+            self._queued = []
         if fmap is None:
             self._chk(self.L.az_propose_launch(self.h, ctypes.byref(params)))
+            self._queued.append(params)
             return
-        t, cl = self._torch_map(fmap)
+        # (the layout checks of a tensor are remembered per tensor object: between two searches the GPU waits for
+        #  exactly this host code)
+        ck = getattr(self, "_map_cache", None)
+        if ck is None:
+            ck = self._map_cache = {}
+        ent = ck.get(id(fmap))
+        ptr = fmap.data_ptr()
+        if ent is None or ent[0] != ptr or ent[5]() is not fmap:
+            import weakref
+            t, cl = self._torch_map(fmap)
+            C, H, W = (int(x) for x in t.shape)
+            if len(ck) > 64:
+                ck.clear()
+            ent = ck[id(fmap)] = (ptr, C, H, W, 1 if cl else 0, weakref.ref(fmap), t.device)
+        _, C, H, W, cl, _, dev = ent
         if producer_event is not None:
             self.wait_event(producer_event)
         elif not producer_done:
             import torch
-            torch.cuda.current_stream(t.device).synchronize()
-        C, H, W = (int(x) for x in t.shape)
-        self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(t.data_ptr()), C, H, W,
-                                              1 if cl else 0))
+            torch.cuda.current_stream(dev).synchronize()
+        self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(ptr), C, H, W, cl))
+        self._queued.append(params)
+        # (two searches may be queued: the previous one's map stays referenced until its fetch)
+        self._feat_keepalive_prev = self._feat_keepalive
         self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
 
     def propose_fetch(self, want_scores=False, want_stats=False):
-        params = self._last_params
+        params = self._queued.pop(0) if getattr(self, "_queued", None) else self._last_params
         cap = params.num_proposals if params.fixed_num else self.max_candidates
         boxes = np.empty((cap, 4), dtype=np.float64)
         scores = np.empty((cap,), dtype=np.float32)

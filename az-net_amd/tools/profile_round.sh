@@ -1,38 +1,59 @@
 #!/bin/bash
-# One profiling pass of bench.py for profiles/: kernel stats, the kernel trace (gaps), and the three
-# separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ/GRBM), each summarised with the tools beside this file.
-# usage (on the GPU box, from the repo root):  bash az-net_amd/tools/profile_round.sh <tag>
-# writes gpurun_out/<tag>/{kernel_stats.csv,gaps.txt,pmc_hbm.csv,pmc_sq.csv,fc_*_by_launch.csv,bench_prof.json}
+# One profiling pass of bench.py for profiles/: kernel stats and the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
+# SQ/GRBM), each summarised with the tools beside this file, for three workloads:
+#   main     the level loop at Tz = 0 (bench.py's `value`)                      -> <tag>_*
+#   onepass  the Tz <= 0 one-pass form (`one_pass`)                             -> <tag>_onepass_*
+#   extras   calibrated Tz, deep tree (config 4), shared detection (config 3), az_nms at 100 / 300 / 2000 / 8129 boxes:
+#            the geometry / NMS / detection kernels (k_nms_*, k_divide, k_dedup_*, k_level_geom, k_spec_levels, ...)
+#                                                                               -> <tag>_extras_*
+# usage (on the GPU box, from the repo root):  bash az-net_amd/tools/profile_round.sh <tag> [main|onepass|extras ...]
+# writes gpurun_out/<tag>/...; raw traces are deleted, only the summaries stay.
 set -u
 tag=${1:-prof}
-period=${2:-2}      # k_fc_splitk launches per image: 2 = all levels in one head pass (Tz <= 0), 6 = level loop
-EXTRA=${3:-}       # e.g. "--level-loop" (with period 6)
+shift || true
+sets=${*:-main onepass extras}
 repo=$(pwd)
 out=$repo/gpurun_out/$tag
 tools=$repo/az-net_amd/tools
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
-args="bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-calibrated --no-level-loop $EXTRA"
+common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast"
 
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 $args > "$out/bench_prof.json" 2> "$out/kt.log"
-ks=$(find "$out/kt" -name '*kernel_stats.csv' | head -1)
-kt=$(find "$out/kt" -name '*kernel_trace.csv' | head -1)
-python3 "$tools/summarize_prof.py" "$ks" "$out/kernel_stats.csv" "rocprofv3 --kernel-trace --stats -- python3 $args"
-python3 "$tools/trace_gaps.py" "$kt" > "$out/gaps.txt" 2>&1
+run_set() {
+  name=$1; args=$2; pfx=$3; period=$4
+  d=$out/$name
+  mkdir -p "$d"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/kt" -- python3 bench.py $args > "$d/bench_prof.json" 2> "$d/kt.log"
+  ks=$(find "$d/kt" -name '*kernel_stats.csv' | head -1)
+  kt=$(find "$d/kt" -name '*kernel_trace.csv' | head -1)
+  python3 "$tools/summarize_prof.py" "$ks" "$out/${pfx}kernel_stats.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py $args"
+  python3 "$tools/trace_gaps.py" "$kt" > "$out/${pfx}gaps.txt" 2>&1
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$d/pmc_$ctr" -- python3 bench.py $args > /dev/null 2> "$d/pmc_$ctr.log"
+  done
+  timeout 900 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$d/pmc_SQ" -- python3 bench.py $args > /dev/null 2> "$d/pmc_SQ.log"
+  cf=$(find "$d/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
+  cw=$(find "$d/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
+  cs=$(find "$d/pmc_SQ" -name '*counter_collection.csv' | head -1)
+  python3 "$tools/summarize_pmc.py" "$out/${pfx}pmc_hbm.csv" "$cf" "$cw"
+  python3 "$tools/summarize_pmc.py" "$out/${pfx}pmc_sq.csv" "$cs"
+  if [ "$period" != "0" ]; then
+    python3 "$tools/pmc_by_launch.py" "$cf" k_fc_splitk $period > "$out/${pfx}fc_fetch_by_launch.csv"
+    python3 "$tools/pmc_by_launch.py" "$cw" k_fc_splitk $period > "$out/${pfx}fc_write_by_launch.csv"
+    python3 "$tools/pmc_by_launch.py" "$cs" k_fc_splitk $period > "$out/${pfx}fc_sq_by_launch.csv"
+  fi
+  cp "$d/bench_prof.json" "$out/${pfx}bench_under_profiler.json"
+  rm -rf "$d"
+}
 
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/pmc_$ctr" -- python3 $args > /dev/null 2> "$out/pmc_$ctr.log"
+for s in $sets; do
+  case $s in
+    # kernels whose name contains k_fc_splitk per image: int6 / int7 of the first pass, the idle k_fc_splitk launch of the
+    # second pass's int6, k_fc_splitk12 (owns it), its int7 = 5
+    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 5 ;;
+    # one pass: k_fc_splitk12 (int6, 688 rows), k_fc_splitk (int7) = 2
+    onepass) run_set onepass "--steps 100 --warmup 10 $common --no-calibrated --no-level-loop --no-extras --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
+    extras)  run_set extras "--steps 10 --warmup 2 $common --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;
+  esac
 done
-timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$out/pmc_SQ" -- python3 $args > /dev/null 2> "$out/pmc_SQ.log"
-
-cf=$(find "$out/pmc_FETCH_SIZE" -name '*counter_collection.csv' | head -1)
-cw=$(find "$out/pmc_WRITE_SIZE" -name '*counter_collection.csv' | head -1)
-cs=$(find "$out/pmc_SQ" -name '*counter_collection.csv' | head -1)
-python3 "$tools/summarize_pmc.py" "$out/pmc_hbm.csv" "$cf" "$cw"
-python3 "$tools/summarize_pmc.py" "$out/pmc_sq.csv" "$cs"
-python3 "$tools/pmc_by_launch.py" "$cf" k_fc_splitk $period > "$out/fc_fetch_by_launch.csv"
-python3 "$tools/pmc_by_launch.py" "$cw" k_fc_splitk $period > "$out/fc_write_by_launch.csv"
-python3 "$tools/pmc_by_launch.py" "$cs" k_fc_splitk $period > "$out/fc_sq_by_launch.csv"
-# raw traces are large: keep only the summaries
-rm -rf "$out/kt" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE" "$out/pmc_SQ"
 ls -la "$out"

@@ -138,6 +138,9 @@ def main():
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--no-extras", action="store_true", help="skip deep_tree / shared_detection / nms")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
+    ap.add_argument("--no-queue-ahead", action="store_true",
+                    help="launch image i+1 only after image i has been fetched (the GPU then idles ~40 us per image while "
+                         "the host turns around)")
     ap.add_argument("--event-every", type=int, default=5,
                     help="HIP events around the fc GEMM launches of every n-th timed step (1: every step, ~30 us/step of stream time)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
@@ -224,39 +227,49 @@ def main():
         return x
 
     gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev) if dist_on else None
-    pending = [0]
     # extra contexts for pipelining independent images on one GPU (same weights, same map)
     nets = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
                     for _ in range(args.inflight - 1)]
     for n in nets[1:]:
         n.set_conv(conv)
 
-    def finish(last):
-        """One image done; every gather_every images per rank (and at the end): ONE RCCL all-gather of the
-        records staged device-to-device by the searches, then the host copy of all ranks' proposals."""
-        if gat is not None:
-            pending[0] += 1
-            if pending[0] == args.gather_every or last:
-                res = gat.gather(pending[0])
-                assert len(res) == world * pending[0]
-                pending[0] = 0
+    def run(nsteps, prm):
+        """nsteps images, one after the other on the one ctx stream.  The host enqueues image i+1's launch sequence
+        (and the device-to-device staging of its record) while the GPU still works on image i, then waits for image i:
+        the searches never overlap on the GPU, but the GPU does not idle while Python turns around (--no-queue-ahead:
+        launch only after the previous fetch).  Every gather_every images per rank (and at the end): ONE RCCL
+        all-gather of the staged records, then the host copy of all ranks' proposals; consecutive batches use
+        alternating send buffers."""
+        ge = args.gather_every
+
+        def launch(i):
+            if ev_every[0]:
+                # (an event pair costs ~7 us of stream time: the launches of every 5th step are timed (a stride coprime
+                #  to the 4 rotated maps), spread over the whole timed region)
+                net.ctx.set_profiling(((2 if args.profile_all else 1) | 4) if i % ev_every[0] == 0 else 4)
+            # this step's image: its map is handed over with the launch
+            net.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
+            if gat is not None:
+                gat.stage(i % ge, buf=(i // ge) % 2)
+
+        def done(i):
+            if gat is not None and ((i + 1) % ge == 0 or i == nsteps - 1):
+                n_b = i % ge + 1
+                res = gat.gather(n_b, buf=(i // ge) % 2)
+                assert len(res) == world * n_b
                 rccl["collectives"] += 1
 
-    ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
-
-    def run(nsteps, prm):
         if args.inflight == 1:
+            ahead = not args.no_queue_ahead
+            if nsteps > 0:
+                launch(0)
             for i in range(nsteps):
-                if ev_every[0]:
-                    # (an event pair costs ~7 us of stream time: the launches of every 5th step are timed (a stride coprime to the 4 rotated maps), spread over
-                    #  the whole timed region)
-                    net.ctx.set_profiling(((2 if args.profile_all else 1) | 4) if i % ev_every[0] == 0 else 4)
-                # this step's image: its map is handed over with the launch
-                net.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
-                if gat is not None:
-                    gat.stage(pending[0])
+                if ahead and i + 1 < nsteps:
+                    launch(i + 1)
                 net.ctx.propose_fetch(want_scores=True)
-                finish(i == nsteps - 1)
+                done(i)
+                if not ahead and i + 1 < nsteps:
+                    launch(i + 1)
             return
         assert world == 1, "--inflight > 1 is a single-GPU measurement"
         q = []
@@ -268,6 +281,8 @@ def main():
             q.append(n)
         for m in q:
             m.ctx.propose_fetch(want_scores=True)
+
+    ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
 
     # one-time initialisation per image shape (the search's shape-dependent pre-pass / plan, first-use allocations): not
     # a step, but timed and reported (`plan_build_ms`)
@@ -282,7 +297,6 @@ def main():
     t0 = time.perf_counter()
     net.propose(params)
     steady_ms = (time.perf_counter() - t0) * 1e3
-    pending[0] = 0
     rccl["collectives"] = 0
     for n in nets:
         n.ctx.set_profiling(0)
@@ -374,6 +388,7 @@ def main():
                        "search_form": "one_pass" if st.static_plan else "level_loop",
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
+                       "host_queue_ahead": (0 if args.no_queue_ahead else 1),
                        "gather": ("RCCL all_gather every %d images/rank (in the timed loop)" % args.gather_every)
                                  if gat is not None else "none"},
             "rccl": dict(rccl, world=world,
@@ -413,9 +428,16 @@ def main():
         cn = ctxnet or net
 
         def f(k):
+            # (same host pattern as the main loop: image i+1 is enqueued while image i is being waited for)
+            ahead = not args.no_queue_ahead
+            if k > 0:
+                cn.ctx.propose_launch(prm, fmap=convs[0], producer_done=True)
             for i in range(k):
-                cn.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
+                if ahead and i + 1 < k:
+                    cn.ctx.propose_launch(prm, fmap=convs[(i + 1) % len(convs)], producer_done=True)
                 cn.ctx.propose_fetch(want_scores=True)
+                if not ahead and i + 1 < k:
+                    cn.ctx.propose_launch(prm, fmap=convs[(i + 1) % len(convs)], producer_done=True)
         return f
 
     # ---- the same search in its other form (bit-identical results are asserted) ------------------------------------
@@ -498,11 +520,12 @@ def main():
         pc = ffi.AzContext.make_params(H_IM, W_IM, scale0, tz_c, num_proposals=NUM_PROPOSALS)
         Yc, stc = net.propose(pc, want_stats=True)
 
-        def runc(k):
-            for _ in range(k):
-                net.propose(pc)
         n_c = max(10, args.steps // 2)
-        dc = timed_loop(runc, n_c, warm=5)
+        # (the calibrated threshold belongs to convs[0]'s image: that map only)
+        convs_keep = convs[:]
+        del convs[1:]
+        dc = timed_loop(simple_run(pc), n_c, warm=5)
+        convs[:] = convs_keep
         if rank == 0:
             uc = [int(stc.level_unique[l]) for l in range(stc.n_levels)]
             fl_c = t_min_us(uc, fmap_elems)

@@ -88,14 +88,14 @@ def main():
                 for j, i in enumerate(batch):
                     net.set_conv(fmap_of(i))
                     net.ctx.propose_launch(params_of(i, ffi, synth, k))
-                    gats[hk].stage(j)
+                    gats[hk].stage(j, buf=b % 2)
                     net.ctx.propose_fetch()
                 # all ranks' rows of this batch, rank-interleaved; odd batches through the non-blocking form
                 # (side stream, double-buffered send buffer, pinned host copy)
                 if b % 2:
-                    res = gats[hk].gather_end(gats[hk].gather_begin(len(batch)))
+                    res = gats[hk].gather_end(gats[hk].gather_begin(len(batch), buf=b % 2))
                 else:
-                    res = gats[hk].gather(len(batch))
+                    res = gats[hk].gather(len(batch), buf=b % 2)
                 got.append(res)
             # global order of this head's images: batch b holds ids[b*rows*world : ...] interleaved by rank
             flat = [x for res in got for x in res]
