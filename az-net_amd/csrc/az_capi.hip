@@ -100,7 +100,7 @@ struct az_ctx {
     int gemm12_env = -1;
     int gemm12_min_rows = 161;                // rows from which a host-known launch takes az_head12.hip (AZ_GEMM12_MIN;
                                               // measured crossover with k_fc_splitk: 160 rows)
-    int gemm12_dual_rows = 257;               // ... and from which a device-known one is worth the second (idle) launch
+    int gemm12_dual_rows = 161;               // ... and from which a launch whose row count only the device knows takes it, going by the previous search
     // Fast R-CNN head on the shared map (az_load_det_head)
     bool det_loaded = false;
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
@@ -355,14 +355,13 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
               // the caller knows the row count on the host (a one-pass plan): many rows -> one weight tile per 12 strips
               azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
                             azk_fc_chunk(d.K6, c->S6), c->part);
-          else if (can12 && rows_hint == -1) {
-              // only the device knows the row count, and the last search had many rows at this level: both kernels
-              // are launched and the one that does not own the row count leaves at once (~6 us for the idle launch)
-              azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part,
-                          (c->gemm12_dual_rows - 1) / 32);
+          else if (can12 && rows_hint == -1)
+              // only the device knows the row count, and the last search had many rows at this level: the many-row
+              // kernel takes the launch.  Both kernels are correct (and bit-identical) for any row count; a wrong guess
+              // costs efficiency, never a result.
               azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
-                            azk_fc_chunk(d.K6, c->S6), c->part, ((c->gemm12_dual_rows - 1) / 32) * 32 + 1);
-          } else
+                            azk_fc_chunk(d.K6, c->S6), c->part);
+          else
               azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part);
       } }
     { Timed t(c, "fc6_reduce", level);

@@ -268,6 +268,27 @@ def test_many_row_gemm_same_bits_as_the_tile_gemm(full, mods):
             assert np.array_equal(a, b[lo:]), n
 
 
+def test_many_row_gemm_is_right_for_any_row_count(full, mods, monkeypatch):
+    """In the level loop only the device knows a level's row count; a level that forwarded many rois in the previous
+    search is sent to the many-row GEMM whatever it holds this time.  That kernel must therefore be right -- and give
+    the tile GEMM's bits -- for ANY row count, down to one row (AZ_GEMM12_MIN=1 sends every launch there)."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = full
+    fmap = synth.make_feature_map(3, 512, 38, 63)
+    net.set_conv(fmap)
+    rois = _rand_rois(np.random.RandomState(12), 200, 1000, 600)
+    ref = net.ctx.head_forward(rois)                        # (200 rows: many-row kernel by default; checked above)
+    small = {n: net.ctx.head_forward(rois[:n]) for n in (1, 5, 16, 17, 31, 32, 33, 48, 49, 64, 100, 129, 160)}   # tile GEMM
+    monkeypatch.setenv("AZ_GEMM12_MIN", "1")
+    net12 = HipAZNet(head, name="all12", max_regions=4096)
+    net12.set_conv(fmap)
+    for n, want in small.items():
+        got = net12.ctx.head_forward(rois[:n])
+        for a, b, r in zip(got, want, ref):
+            assert np.array_equal(a, b), n
+            assert np.array_equal(a, r[:n]), n
+
+
 # ---------------------------------------------------------------- whole loop
 def _oracle_loop_on_gpu_head(orc, net, fmap, H, W, scale, cfg):
     """The oracle's level loop with the HIP head injected as the pycaffe-shaped net --
