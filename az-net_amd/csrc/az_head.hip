@@ -660,6 +660,8 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         strips = st2; mt = mt2; half_last = true;
     }
     const int nitems = mloop ? G : G * mt;
+    // (256 % mt != 0 in general: the rotation that makes tile(b + 256) = tile(b) + mt / 2)
+    const int pair_rot = (half_enabled & 8) ? 0 : (((mt >> 1) - (int)(gridDim.x / 2) % mt) % mt + mt) % mt;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int g = mloop ? item : item / mt;
@@ -668,7 +670,13 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         const int k0 = s * Kc;
         const int kend = min(K, k0 + Kc);
         float *slab = part + (size_t)s * capM * N;
-        const int t_lo = mloop ? 0 : item - g * mt, t_hi = mloop ? mt : t_lo + 1;
+        // (spread items: m-tiles differ by one strip -- front ones larger.  Workgroups b and b + gridDim / 2 tend to
+        //  share a CU (two resident per CU): the second half of the grid walks the m-tiles rotated by half a turn, so a
+        //  CU gets a larger and a smaller tile rather than two large ones.  AZ_GEMM_PAIR=0: plain order.)
+        int t_sp = item - g * mt;
+        // (a whole group rotates or not -- decided by where its first item falls --, so every m-tile is still visited once)
+        if (!mloop && pair_rot && (((g * mt) / ((int)gridDim.x / 2)) & 1)) t_sp = (t_sp + pair_rot) % mt;
+        const int t_lo = mloop ? 0 : t_sp, t_hi = mloop ? mt : t_lo + 1;
         for (int mtile = t_lo; mtile < t_hi; ++mtile) {
             int strip0, n_rt;                            // live 32-row strips (workgroup-uniform)
             if (!front) mtile_rows(strips, mt, mtile, strip0, n_rt);
@@ -696,6 +704,9 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
 }
 
 // y = act(sum_s part[s] + b): partial sums added in chunk order (fixed), then the bias.
+#ifndef AZ_REDUCE_BATCH
+#define AZ_REDUCE_BATCH 8       /* (16 in flight: 32.8 -> 34.4 us at 670 rows: the kernel runs at memory speed either way) */
+#endif
 __global__ void __launch_bounds__(256)
 k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, const int *Mptr, int capM,
             int N, int S, float *__restrict__ y, int ldy, int relu)
@@ -709,14 +720,15 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
         const int m = (int)(idx / N4);
         const int n = (int)(idx - (long long)m * N4) * 4;
         const float *p = part + (size_t)m * N + n;
-        // slabs in batches of 8 independent loads (one memory round trip per batch), added in chunk order
+        // slabs in batches of RB independent loads (one memory round trip per batch), added in chunk order
+        constexpr int RB = AZ_REDUCE_BATCH;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < S; s0 += 8) {
-            float4 t[8];
+        for (int s0 = 0; s0 < S; s0 += RB) {
+            float4 t[RB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S - 1) * slab);
+            for (int j = 0; j < RB; ++j) t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S - 1) * slab);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < RB; ++j)
                 if (s0 + j < S) {
                     if (s0 + j == 0) a = t[j];
                     else { a.x += t[j].x; a.y += t[j].y; a.z += t[j].z; a.w += t[j].w; }
@@ -995,8 +1007,8 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
 {
     static int half = -1;                  // AZ_GEMM_HALF=0: pad the last rows to a full strip instead (measurements)
     if (half < 0) {
-        const char *e = getenv("AZ_GEMM_HALF"), *f = getenv("AZ_GEMM_BALANCED");     // (bit 2: balanced tiles, measurements)
-        half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0);
+        const char *e = getenv("AZ_GEMM_HALF"), *f = getenv("AZ_GEMM_BALANCED"), *g = getenv("AZ_GEMM_PAIR");     // (bit 2: balanced tiles, bit 3: no pair rotation: measurements)
+        half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0) | ((g && !atoi(g)) ? 8 : 0);
     }
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
                        fc_chunk(K, S), part, max_strips, half);

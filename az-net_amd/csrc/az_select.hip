@@ -466,15 +466,48 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
         }
     }
     __syncthreads();
-    if (tid == 0) {                                         // greedy scan over <= 256 sorted boxes
-        unsigned long long removed[NMS_SMALL / 64] = {0ull, 0ull, 0ull, 0ull};
+    if (wave == 0) {
+        // greedy scan over <= 256 sorted boxes by ONE wave, 64 boxes at a time (as k_nms_scan): lane = box of the block,
+        // its diagonal word in registers, the 64 sequential decisions through readlane -- no memory access in the
+        // dependent chain (a single thread walking smask paid two LDS latencies per box: ~10 us for 100 boxes); then
+        // the block's kept rows are OR-ed into the later blocks' removed words with a butterfly.
+        static_assert(NMS_SMALL / 64 == 4, "the scan below is written for four 64-box blocks");
+        unsigned long long rem[4] = {0ull, 0ull, 0ull, 0ull};          // wave-uniform
         int nk = 0;
-        for (int r = 0; r < n; ++r) {
-            if ((removed[r >> 6] >> (r & 63)) & 1ull) continue;
-            keep[o + nk++] = sorder[r];
-            for (int w = r >> 6; w < W; ++w) removed[w] |= smask[r][w];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < W) {
+                const int row = c * 64 + lane;
+                const unsigned long long diag = row < n ? smask[row][c] : 0ull;
+                const int nvalid = min(64, n - c * 64);
+                unsigned long long alive = ~rem[c];
+                if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
+                unsigned long long kept = 0ull;
+                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+                for (int b = 0; b < nvalid; ++b) {
+                    const unsigned long long drow =
+                        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
+                    if ((alive >> b) & 1ull) { kept |= (1ull << b); alive &= ~drow; }
+                }
+                const bool mine = (kept >> lane) & 1ull;
+                if (mine) keep[o + nk + __popcll(kept & ((1ull << lane) - 1ull))] = sorder[row];
+                nk += __popcll(kept);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w > c && w < W) {
+                        unsigned long long v = mine ? smask[row][w] : 0ull;
+#pragma unroll
+                        for (int dd = 32; dd > 0; dd >>= 1) {
+                            const unsigned lo = __shfl_xor((unsigned)v, dd, 64), hi = __shfl_xor((unsigned)(v >> 32), dd, 64);
+                            v |= ((unsigned long long)hi << 32) | lo;
+                        }
+                        rem[w] |= v;
+                    }
+                }
+            }
         }
-        nkeep[g] = nk;
+        if (lane == 0) nkeep[g] = nk;
     }
 }
 
