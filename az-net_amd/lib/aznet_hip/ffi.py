@@ -72,7 +72,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("AZNET_HIP_LIB") or LIB_PATH      # (AZNET_HIP_LIB: an A/B build of the library, measurements)
     if not os.path.exists(p):
         raise ImportError("libaznet_hip.so not found at %s -- the HIP extension is required "
                           "(no CPU fallback); run make -C az-net_amd/csrc" % p)
