@@ -155,7 +155,11 @@ struct az_ctx {
     // parameters of the last FETCHED search
     az_params last{};
     int nofuse_h = -1, nofuse_w = -1;   // image shape for which the fused levels 1-3 overflowed
-    int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which a later level outgrew the fused level kernel
+    int nofuse_lv_h = -1, nofuse_lv_w = -1;   // ... for which the first level after the speculative ones outgrew the fused level kernel
+    // image shapes whose level `limit` (> the first fused level) outgrew the fused level kernel: the levels before it stay
+    // on it, the step from level `limit` on runs on the multi-launch kernels
+    struct LvLimit { int h, w, limit; };
+    std::vector<LvLimit> lv_limits;
     int defer_root_env = -1;            // AZ_DEFER_ROOT=0: keep the root's row in the speculative pass (measurements)
     int level_fused_env = -1;           // AZ_LEVEL_FUSED=0: keep levels >= 4 as separate launches (measurements)
     struct GraphEntry { hipGraphExec_t exec; int npass; int pass_src[AZ_MAX_LEVELS + 2]; };
@@ -629,7 +633,7 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
 }
 
 // Which form of the search a call takes.
-struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; };
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; };
 
 // Cost model of one head pass on the int6 GEMM (us), from the measured launch shapes (profiles/): weight-streaming
 // bound up to ~40 rows, then ~1.45 us per row; and what a head pass costs besides int6 (RoIPool, reduce, int7, heads,
@@ -644,7 +648,7 @@ constexpr double PASS_OVERHEAD_US = 90.0, LOOKUP_US = 8.0;
 // the previous search of this context on the same image shape (what a dataset run looks like); without history
 // nothing is speculated.  params.reserved bit 6 / AZ_PAIR_SPEC=0: never; bit 7 / AZ_PAIR_SPEC=2: at every eligible
 // level (tests).  Results are bit-identical either way.
-static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool fused_lv)
+static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool fused_lv, int lv_limit)
 {
     if (c->pair_env < 0) { const char *e = getenv("AZ_PAIR_SPEC"); c->pair_env = e ? atoi(e) : 1; }
     if (!fused_lv || (p->reserved & 64) || c->pair_env == 0) return 0;
@@ -653,7 +657,7 @@ static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool f
     const bool force = (p->reserved & 128) || c->pair_env == 2;
     const bool hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
     int mask = 0;
-    for (int l = n_spec; l + 1 < nlev; ++l) {
+    for (int l = n_spec; l + 1 < nlev && l < lv_limit; ++l) {      // (the lookup runs in level l's fused geometry kernel)
         bool want = force;
         if (!want && hist && c->hint_P[l] > 0 && c->hint_U[l + 1] > 0) {
             // rows the speculation adds: what it added last time, else level l+1's unique rois scaled by parents / zoomed parents
@@ -686,7 +690,10 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
     if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
     q.defer_root = q.fused_lv && q.n_spec == 3 && nlev >= q.n_spec + 2 && c->defer_root_env;
-    q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv);
+    q.lv_limit = AZ_MAX_LEVELS + 1;
+    for (const auto &e : c->lv_limits)
+        if (e.h == p->im_h && e.w == p->im_w) q.lv_limit = e.limit;
+    q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv, q.lv_limit);
     return q;
 }
 
@@ -948,7 +955,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
-        const bool lv_here = fused_lv && l + 1 < nlev;           // (the last level's copy + top-k stay chip-wide)
+        // (the last level's copy + top-k stay chip-wide; from plan.lv_limit on the levels outgrow the fused kernel)
+        const bool lv_here = fused_lv && l + 1 < nlev && l < plan.lv_limit;
         const bool pair_here = fused_lv && ((plan.pair_mask >> l) & 1) && !have_v;   // this pass carries level l+1's rows
         if (lv_here) {
             // this level's rois were projected and deduplicated by the previous geometry kernel, which also left the
@@ -977,7 +985,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             have_v = pair_here;
             continue;
         }
-        if (!fused_lv) {          // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
+        if (!fused_lv || l > plan.lv_limit) {   // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
           Timed t(c, "rois_dedup", l);
           azk_rois_dedup(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
                          c->grp, c->first, c->index, c->inv, c->urois, c->ubox, Uptr); }
@@ -992,7 +1000,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
                             p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
         } else if (!have_v) {
-            launch_head(c, fused_lv ? &c->cnt->PR[l] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u,
+            launch_head(c, (fused_lv && l <= plan.lv_limit) ? &c->cnt->PR[l] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u,
                         p->min_side, final_fused, 0, nullptr, nullptr, many_rows_expected(c, l), final_fused);
         }
         if (final_fused) {
@@ -1029,6 +1037,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                                 c->B[cur ^ 1], &c->cnt->P[l + 1], &c->cnt->err, track ? c->csrc : nullptr,
                                 c->srcB[cur ^ 1]); }
         }
+        have_v = false;           // (a level on the multi-launch kernels never looks the next one's outputs up)
     }
     enqueue_select(c, p, nlev, k);
     if (tune && c->pool) {
@@ -1096,6 +1105,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->nofuse_w, sizeof(int));
         key.append((const char *)&c->nofuse_lv_h, sizeof(int));
         key.append((const char *)&c->nofuse_lv_w, sizeof(int));
+        { const int lim = plan_search(c, p, nlev, tune).lv_limit; key.append((const char *)&lim, sizeof(int)); }
         key.append((const char *)&c->last_static, sizeof(int));
         key.append((const char *)&c->last_pair_mask, sizeof(int));
         for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
@@ -1271,7 +1281,22 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
         const bool lv_was_on = !(q.p.reserved & 16) && c->level_fused_env != 0 &&
                                !(q.p.im_h == c->nofuse_lv_h && q.p.im_w == c->nofuse_lv_w);
         az_params p2 = q.p;
-        if (lv_was_on) { c->nofuse_lv_h = q.p.im_h; c->nofuse_lv_w = q.p.im_w; p2.reserved |= 16; }
+        const int ovf = h.scratch[5] - 1;          // the level whose fused geometry kernel overflowed (-1: an earlier stage)
+        bool limited = false;
+        if (lv_was_on && ovf > 3) {
+            // a level behind the first fused one: the levels before it keep their fused kernels
+            for (auto &e : c->lv_limits)
+                if (e.h == q.p.im_h && e.w == q.p.im_w) { if (ovf < e.limit) { e.limit = ovf; limited = true; } }
+            bool known = false;
+            for (const auto &e : c->lv_limits) known = known || (e.h == q.p.im_h && e.w == q.p.im_w);
+            if (!known) {
+                if (c->lv_limits.size() >= 32) c->lv_limits.erase(c->lv_limits.begin());
+                c->lv_limits.push_back({q.p.im_h, q.p.im_w, ovf});
+                limited = true;
+            }
+        }
+        if (limited) { }
+        else if (lv_was_on) { c->nofuse_lv_h = q.p.im_h; c->nofuse_lv_w = q.p.im_w; p2.reserved |= 16; }
         else { c->nofuse_h = q.p.im_h; c->nofuse_w = q.p.im_w; p2.reserved |= 2; }
         return rerun(p2);
     }

@@ -152,7 +152,10 @@ constexpr int FL_C = 2048;        // children per fused level
 #define TSTAMP(i) do { } while (0)
 #endif
 constexpr int SPEC_PRE = 64;     // rows of the speculative pass whose outputs are staged in LDS up front
-constexpr int NTL = 256;         // threads of the fused-levels workgroup: levels 1-3 hold <= a few hundred elements per stage,
+#ifndef AZ_NTL
+#define AZ_NTL 512      /* (128: 61 us, 256: 43.5, 512: 40, 1024: 41 -- k_spec_levels at config A) */
+#endif
+constexpr int NTL = AZ_NTL;         // threads of the fused-levels workgroup: levels 1-3 hold <= a few hundred elements per stage,
                                  // and every stage boundary costs a barrier across all waves
 __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 {

@@ -762,10 +762,14 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
 // ======================================================================================
 constexpr int NOUT = AZ_NSUB * 5 + 1;   // 56
 constexpr int TAIL_ROWS = 4;
-constexpr int TAIL_WAVES = 16;
-#ifndef AZ_TAIL_KB
-#define AZ_TAIL_KB 16
+#ifndef AZ_TAIL_WAVES
+#define AZ_TAIL_WAVES 16
 #endif
+constexpr int TAIL_WAVES = AZ_TAIL_WAVES;
+#ifndef AZ_TAIL_KB
+#define AZ_TAIL_KB 8        /* (16: the k range of a wave is padded 80 -> 96, tail 12.8 / 16.0 us; 8 or 4: 10.5 / 13.2; 32: 25 / 34) */
+#endif
+
 constexpr int TAIL_KB = AZ_TAIL_KB;     // k values per register batch
 
 // Every wave walks the same number of k (a multiple of two register batches): the weight block

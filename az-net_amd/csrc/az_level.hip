@@ -23,7 +23,10 @@
 
 namespace {
 
-constexpr int NT = 1024;
+#ifndef AZ_LV_NT
+#define AZ_LV_NT 1024
+#endif
+constexpr int NT = AZ_LV_NT;
 constexpr int LV_R = 1024;         // regions per level handled here
 constexpr int LV_C = 4096;         // children per level (before _sift_dup)
 
@@ -70,7 +73,8 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     const int U = *a.Uptr;
     const int ybase = cnt->ytot[l];
     if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
-    if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0 && chain) atomicOr(&cnt->err, 8); return; }
+    // (an overflow also records the level: the host then keeps the levels before it on the fused kernels)
+    if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0 && chain) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }
     // the deferred root is the LAST row of this level's head pass (behind any pair-speculation rows)
     const int root_u = a.root_row ? cnt->PR[l] - 1 : 0;
     const int spec_base = cnt->SPB[l];                     // (lookup_next) first pair-speculation row of this level's pass
@@ -222,7 +226,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         if (z < PZ) schoff[z] = CH + ex;
         CH += tot;
     }
-    if (CH > LV_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
+    if (CH > LV_C || CH > a.capCh) { if (tid == 0) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }
     unsigned long long *ssort = sbuf + W_SORT, *stmp = sbuf + W_BN;
     unsigned *sbins = reinterpret_cast<unsigned *>(sbuf + W_BINS);
     int *sczi = reinterpret_cast<int *>(sbuf + W_SCZI);
@@ -270,12 +274,12 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         }
         Pn += tot;
     }
-    if (Pn > LV_R || Pn > a.capR) { if (tid == 0) atomicOr(&cnt->err, Pn > a.capR ? 1 : 8); return; }
+    if (Pn > LV_R || Pn > a.capR) { if (tid == 0) { atomicOr(&cnt->err, Pn > a.capR ? 1 : 8); cnt->scratch[5] = l + 1; } return; }
     if (tid == 0) { cnt->CH[l] = CH; cnt->P[l + 1] = Pn; }
     __syncthreads();
     TSTAMP();
     // ---- level l+1: roi projection + feature-space dedup (test.py:61-97, 210-218) ---------------------
-    if (Pn > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
+    if (Pn > a.batch) { if (tid == 0) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }      // chunked dedup: multi-launch path
     int *sidx = reinterpret_cast<int *>(sbuf + W_SZR);                      // (szr is done) index[] of level l+1, in LDS
     const int Un = roi_dedup_sorted(sBn, Pn, a.scale, a.dedup, ssort, ssort + LV_R, sbins, s_mm, wsum, nullptr, a.index,
                                     a.inv, a.urois, a.ubox, sidx);

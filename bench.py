@@ -654,7 +654,7 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
         fl = t_min_us(ud, int(fmap.size))
         kms, by = kernel_ms(lambda: net.propose(p), 5)
         d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor_frac": fl / (ms * 1e3),
-             "kernel_ms_per_image": kms}
+             "kernel_ms_per_image": kms, "rows_per_pass": [int(x) for x in list(std.pass_rows)[:int(std.n_passes)]]}
         if form == "level_loop":
             res["deep_tree"] = dict(d, workload="BASELINE config 4: 800x1200 image (scale 0.75), K = 7, Tz = 0",
                                     regions_per_level=[int(std.level_regions[l]) for l in range(std.n_levels)],
