@@ -276,8 +276,17 @@ __global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
     if ((int)blockIdx.x < nbC) {
         // ---- writers: the last level's kept candidates go behind the earlier levels' (test.py:380-381)
         for (int bid = blockIdx.x; bid * SC_NT < Ns; bid += nbC) {
+            // kept slots before this workgroup's range: the keys of 8 x 1024 slots per turn, their loads (inv, then the
+            // key: two dependent round trips) issued together -- one slot range per turn cost two round trips EACH, and
+            // the writer of the last range set the kernel's time
             int before = 0;
-            for (int c = tid; c < bid * SC_NT; c += SC_NT) before += final_key(a, 0, Ns, c) != 0u;
+            for (int m0 = 0; m0 < bid; m0 += SC_B) {
+                unsigned k8[SC_B];
+#pragma unroll
+                for (int j = 0; j < SC_B; ++j) k8[j] = final_key(a, 0, Ns, min((m0 + j) * SC_NT + tid, Ns - 1));
+#pragma unroll
+                for (int j = 0; j < SC_B; ++j) before += (m0 + j < bid && k8[j] != 0u) ? 1 : 0;
+            }
             const int base = block_sum(before, red);
             const int c = bid * SC_NT + tid;
             int fl = 0, src = 0;
