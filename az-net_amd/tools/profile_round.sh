@@ -48,9 +48,9 @@ run_set() {
 
 for s in $sets; do
   case $s in
-    # kernels whose name contains k_fc_splitk per image: int6 / int7 of the first pass, the idle k_fc_splitk launch of the
-    # second pass's int6, k_fc_splitk12 (owns it), its int7 = 5
-    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 5 ;;
+    # kernels whose name contains k_fc_splitk per image: int6 / int7 of the first pass (48 rows), k_fc_splitk12 (the second
+    # pass's int6: level 4 + all children of level 4), its int7 = 4
+    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 4 ;;
     # one pass: k_fc_splitk12 (int6, 688 rows), k_fc_splitk (int7) = 2
     onepass) run_set onepass "--steps 100 --warmup 10 $common --no-calibrated --no-level-loop --no-extras --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
     extras)  run_set extras "--steps 10 --warmup 2 $common --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;

@@ -650,6 +650,7 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
         p = ffi.AzContext.make_params(800, 1200, 0.75, 0.0, static_tree=static)
         Yd, std = net.propose(p, want_stats=True)
         ms = wall(lambda: net.propose(p), n_img)
+        Yd, std = net.propose(p, want_stats=True)          # (the passes of a search that has the context's history)
         ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
         fl = t_min_us(ud, int(fmap.size))
         kms, by = kernel_ms(lambda: net.propose(p), 5)
