@@ -1687,20 +1687,27 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
 }
 
 // the detection head on the `U` rois in ctx->urois / ctx->ubox
-static void launch_det_head(az_ctx *c, const int *Uptr, int im_h, int im_w, double eps)
+// (rows_bound: what the host knows about the row count -- the number of boxes before the 1/16 dedup)
+static void launch_det_head(az_ctx *c, const int *Uptr, int im_h, int im_w, double eps, int rows_bound)
 {
     AzHeadDims d = c->d;
     const int K6 = d.C * 49, NO = 5 * c->det_ncls;
     d.K6 = K6;
+    // many rows (the reference's 300 proposals per image): fc6 / fc7 on the many-row GEMM, as int6 (same bits either way)
+    auto gemm = [&](const float *x, int ldx, const float *W, int N, int K, int S, float *part) {
+        const bool can12 = (N / 128) * S >= 256 && N % 128 == 0 && K % 32 == 0 && azk_fc_chunk(K, S) * S == K &&
+                           azk_fc_chunk(K, S) >= 64 && c->gemm12_min_rows < 0x7fffffff && rows_bound >= c->gemm12_min_rows;
+        if (can12) azk_fc_gemm12(c->stream, x, ldx, W, K, Uptr, c->maxR, N, K, S, azk_fc_chunk(K, S), part);
+        else azk_fc_gemm(c->stream, x, ldx, W, K, Uptr, c->maxR, N, K, S, part);
+    };
     { Timed t(c, "det_roi_pool", 0);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, nullptr, 0, 0, 0); }
     { Timed t(c, "det_fc6_gemm", 0, 1);
-      azk_fc_gemm(c->stream, c->pool5, K6, c->dW6, K6, Uptr, c->maxR, c->det_n6, K6, c->det_S6, c->dpart); }
+      gemm(c->pool5, K6, c->dW6, c->det_n6, K6, c->det_S6, c->dpart); }
     { Timed t(c, "det_fc6_reduce", 0);
       azk_fc_reduce(c->stream, c->dpart, c->db6, Uptr, c->maxR, c->det_n6, c->det_S6, c->dh6, c->det_n6, 1); }
     { Timed t(c, "det_fc7_gemm", 0, 1);
-      azk_fc_gemm(c->stream, c->dh6, c->det_n6, c->dW7, c->det_n6, Uptr, c->maxR, c->det_n7, c->det_n6, c->det_S7,
-                  c->dpart); }
+      gemm(c->dh6, c->det_n6, c->dW7, c->det_n7, c->det_n6, c->det_S7, c->dpart); }
     { Timed t(c, "det_fc7_reduce", 0);
       azk_fc_reduce(c->stream, c->dpart, c->db7, Uptr, c->maxR, c->det_n7, c->det_S7, c->dh7, c->det_n7, 1); }
     { Timed t(c, "det_tail_gemm", 0, 1);
@@ -1725,7 +1732,7 @@ int az_det_forward(az_ctx *c, const float *rois, int R, float *cls_prob, float *
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!(c->profiling & 4)) clear_events(c);
-    launch_det_head(c, &c->cnt->U[0], 1, 1, 0.0);
+    launch_det_head(c, &c->cnt->U[0], 1, 1, 0.0, R);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     const size_t nc = (size_t)c->det_ncls;
@@ -1750,7 +1757,7 @@ int az_detect(az_ctx *c, const double *boxes, int P, double scale, double dedup,
     if ((rc = set_count(c, &c->cnt->P[0], P)) != AZ_OK) return rc;
     azk_rois_dedup(s, c->B[0], &c->cnt->P[0], c->maxR, scale, (float)dedup, batch_size, c->rois, c->key, c->grp,
                    c->first, c->index, c->inv, c->urois, c->ubox, &c->cnt->U[0]);
-    launch_det_head(c, &c->cnt->U[0], im_h, im_w, eps);
+    launch_det_head(c, &c->cnt->U[0], im_h, im_w, eps, P);
     azk_det_gather(s, &c->cnt->P[0], c->inv, c->det_ncls, c->dprob_u, c->dpred_u, c->dprob, c->dpred);
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipGetLastError());

@@ -192,7 +192,10 @@ def main():
     dist_on = rccl["backend"] is not None
 
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    backbone = VGG16Conv5(device=dev, seed=4321)
+    # (plumbing: conv5_3 comes out [H][W][C] and is borrowed in place; channels_last compute + MIOpen's benchmark search,
+    #  set before the first forward, is the fastest fp32 configuration found for the fixed 600x1000 shape)
+    torch.backends.cudnn.benchmark = True
+    backbone = VGG16Conv5(device=dev, seed=4321, channels_last_out=True, channels_last_compute=True)
     net = HipAZNet(head, backbone=backbone, device=local_rank, name="vgg16_az_net_hip", max_regions=4096)
     from detect.test import _get_image_blob
     # images owned by this rank: seeds rank, rank + world, ... (BASELINE config 5 is one image per GPU; the
@@ -570,8 +573,7 @@ def main():
         db = maxr(time.perf_counter() - t0)
         # ... and overlapped: image i+1's backbone on torch's stream while image i's search runs on the ctx stream,
         # ordered on the device by an event (no host synchronisation between the two)
-        bb_cl = VGG16Conv5(device=dev, seed=4321, channels_last_out=True)
-        bb_cl.layers = backbone.layers
+        bb_cl = backbone
 
         def run_e2e_pipe(k):
             nxt = bb_cl(blobs[0])
@@ -593,13 +595,17 @@ def main():
                                  "from_host_image_ms": di / n_e2e * 1e3,
                                  "backbone_ms": db / n_e2e * 1e3,
                                  "backbone_tflops": VGG16_FLOP_600x1000 / (db / n_e2e) / 1e12,
-                                 "note": "adds the fp32 PyTorch-ROCm VGG16 conv1_1..conv5_3 forward (367.7 GFLOP); "
+                                 "note": "adds the fp32 PyTorch-ROCm VGG16 conv1_1..conv5_3 forward (367.7 GFLOP, channels_last "
+                                         "weights and activations; its channels_last conv5_3 is borrowed in place); "
                                          "from_host_image also uploads the uint8 image over PCIe and runs the "
                                          "front-end kernel (az_image_blob_dev)"}
             out["end_to_end_pipelined"] = {
                 "value": world * NUM_PROPOSALS * n_e2e / dpp, "unit": "proposals/s", "ms_per_image": dpp / n_e2e * 1e3,
-                "note": "backbone of image i+1 (torch stream, channels-last output borrowed in place) overlapped with the "
-                        "search of image i (ctx stream); the hand-over is an event wait on the device"}
+                "vs_serial": (de / n_e2e) / (dpp / n_e2e),
+                "note": "backbone of image i+1 (torch stream, channels-last output borrowed in place) enqueued while the "
+                        "search of image i runs (ctx stream); the hand-over is an event wait on the device.  Measured for the "
+                        "record: both saturate the GPU, and the search's persistent one-workgroup-per-CU GEMM shares the "
+                        "CUs badly with MIOpen's kernels -- vs_serial < 1 means the serial order (end_to_end) is the faster one"}
     if rank == 0 and not args.no_cpu_baseline:
         fm = conv.detach().cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(head, fm, args.tz)
