@@ -59,6 +59,25 @@ def run_case(net, case):
         return False, desc, "fused-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d depth %d/%d" % (
             np.array_equal(a[0], b[0]), np.array_equal(a[1], b[1]), np.array_equal(Ya, Yb), np.array_equal(Sa, Sb),
             a[2].num_eval, b[2].num_eval, a[2].depth, b[2].depth)
+    # pair speculation forced at every eligible level (round 3), alone and as the second of two queued searches
+    pp = ffi.AzContext.make_params(H, W, scale, Tz, pair_spec=True, **kw)
+    c = net.propose(pp, want_scores=True, want_stats=True)
+    Yc, Sc = net.ctx.last_candidates()
+    ok = (np.array_equal(c[0], b[0]) and np.array_equal(c[1], b[1]) and np.array_equal(Yc, Yb) and
+          np.array_equal(Sc, Sb) and c[2].num_eval == b[2].num_eval and c[2].depth == b[2].depth and
+          list(c[2].level_unique) == list(b[2].level_unique) and list(c[2].level_zoomed) == list(b[2].level_zoomed))
+    if not ok:
+        return False, desc, "pair-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d passes %s" % (
+            np.array_equal(c[0], b[0]), np.array_equal(c[1], b[1]), np.array_equal(Yc, Yb), np.array_equal(Sc, Sb),
+            c[2].num_eval, b[2].num_eval, list(c[2].pass_rows[:c[2].n_passes]))
+    if fixed:
+        net.ctx.propose_launch(ffi.AzContext.make_params(H, W, scale, Tz, **kw))
+        net.ctx.propose_launch(pp)
+        q1 = net.ctx.propose_fetch(want_scores=True)
+        q2 = net.ctx.propose_fetch(want_scores=True)
+        if not (np.array_equal(q1[0], b[0]) and np.array_equal(q1[1], b[1]) and np.array_equal(q2[0], b[0]) and
+                np.array_equal(q2[1], b[1])):
+            return False, desc, "queued searches differ from the plain one"
     desc += " levels %d eval %d cand %d" % (a[2].n_levels, a[2].num_eval, Ya.shape[0])
     if case % 4:
         return True, desc, ""
