@@ -391,10 +391,20 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
         for (int w = c + 1 + threadIdx.x; w < W; w += blockDim.x) {
             unsigned long long acc = removed[w];
             unsigned long long kk = kept;
+            // the kept rows' words, eight loads in flight at a time (one at a time, ~24 kept rows per block made every
+            // block wait for ~24 dependent memory round trips: 1.2 of the 1.6 ms at 8129 boxes)
             while (kk) {
-                const int b = __ffsll((long long)kk) - 1;
-                kk &= kk - 1;
-                acc |= mask[(size_t)(c * 64 + b) * W + w];
+                int b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    b[j] = kk ? __ffsll((long long)kk) - 1 : -1;
+                    kk &= kk - 1;                               // (0 stays 0)
+                }
+                unsigned long long m[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = b[j] >= 0 ? mask[(size_t)(c * 64 + b[j]) * W + w] : 0ull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc |= m[j];
             }
             removed[w] = acc;
         }
