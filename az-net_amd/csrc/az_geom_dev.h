@@ -7,21 +7,42 @@
 
 static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// Exclusive prefix sum of one int per thread across the block (blockDim.x <= 1024).
-// (Measured alternative, round 3: every thread adding up the totals of the waves before it -- two barriers instead of
-//  three, no serial walk -- is SLOWER: k_spec_levels 44 -> 47 us, k_final_select 14 -> 16.7 us.)
-static __device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints of LDS */)
+// Inclusive prefix sum across the 64 lanes of a wave with DPP row shifts / row broadcasts (six VALU instructions with a
+// cross-lane modifier; the __shfl_up form is six dependent ds_bpermute round trips through the LDS crossbar).
+static __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    const int lane = lane_id(), wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    int inc = v;
+#ifdef AZ_SCAN_SHFL
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
     }
+    return v;
+#else
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8   (each row of 16 lanes scanned)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2 and 3
+    return v;
+#endif
+}
+
+// Exclusive prefix sum of one int per thread across the block (blockDim.x <= 1024).
+// Two barriers; every wave scans the (<= 16) wave totals itself with the same DPP scan -- no thread walks them one
+// dependent LDS access after the other.  (The single-workgroup geometry kernels make dozens of these calls per search:
+// at ~1 us each in the __shfl_up + serial-walk form they were most of those kernels' time.)
+static __device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints of LDS */)
+{
+    const int lane = lane_id(), nw = (blockDim.x + 63) >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int inc = wave_incl_scan(v);
     __syncthreads();                       // wsum may still be read from a previous call
     if (lane == 63) wsum[wid] = inc;
     __syncthreads();
+#ifdef AZ_SCAN_OLD
     if (threadIdx.x == 0) {
         int run = 0;
         for (int w = 0; w < nw; ++w) { int t = wsum[w]; wsum[w] = run; run += t; }
@@ -30,6 +51,12 @@ static __device__ int block_excl_scan(int v, int *total, int *wsum /* >= 17 ints
     __syncthreads();
     *total = wsum[16];
     return wsum[wid] + inc - v;
+#else
+    const int t = lane < nw ? wsum[lane] : 0;
+    const int tinc = wave_incl_scan(t);
+    *total = __builtin_amdgcn_readlane(tinc, 63);
+    return __builtin_amdgcn_readlane(tinc - t, wid) + inc - v;
+#endif
 }
 
 // lib/detect/test.py:61-97 (_get_rois_blob: f64 box * scale -> f32) and :212-214 (hash of
