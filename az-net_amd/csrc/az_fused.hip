@@ -323,19 +323,22 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
             const int n = z < PZ ? div_nchildren(div_plan(B + 4 * szr[z])) : 0;
             int tot;
             const int ex = block_excl_scan(n, &tot, wsum);
-            if (z < PZ) schoff[z] = CH + ex;
+            if (z < PZ) {
+                schoff[z] = CH + ex;
+                if (CH + ex + n <= FL_C)
+                    for (int bi = 0; bi < n; ++bi) sczi[CH + ex + bi] = (z << 16) | bi;      // (child -> parent, child number)
+            }
             CH += tot;
         }
         if (CH > FL_C || CH > a.capCh) { if (tid == 0) atomicOr(&cnt->err, 8); return; }
         __syncthreads();
         // (one thread per CHILD: a parent's children one after the other are ~35 dependent f64 divisions)
         for (int ci = tid; ci < CH; ci += NTL) {
-            const int z = seg_of(schoff, PZ, ci);
+            const int z = sczi[ci] >> 16;
             const double *r = B + 4 * szr[z];
-            const int bi = ci - schoff[z];
+            const int bi = sczi[ci] & 0xFFFF;
             double c[4];
             skeyC[ci] = div_child(r, div_plan(r), bi, a.min_side, c);
-            sczi[ci] = (z << 16) | bi;
         }
         __syncthreads();
         TSTAMP(tsn++);

@@ -30,6 +30,24 @@ static __device__ __forceinline__ int wave_incl_scan(int v)
 #endif
 }
 
+// min / max across a wave, same DPP ladder (the value of lane 63 is the wave's)
+static __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#define AZ_DPP_STEP(ctrl, rmask) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false); v = t < v ? t : v; }
+    AZ_DPP_STEP(0x111, 0xF) AZ_DPP_STEP(0x112, 0xF) AZ_DPP_STEP(0x114, 0xF) AZ_DPP_STEP(0x118, 0xF)
+    AZ_DPP_STEP(0x142, 0xA) AZ_DPP_STEP(0x143, 0xC)
+#undef AZ_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+static __device__ __forceinline__ unsigned wave_max_u32(unsigned v)
+{
+#define AZ_DPP_STEP(ctrl, rmask) { const unsigned t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false); v = t > v ? t : v; }
+    AZ_DPP_STEP(0x111, 0xF) AZ_DPP_STEP(0x112, 0xF) AZ_DPP_STEP(0x114, 0xF) AZ_DPP_STEP(0x118, 0xF)
+    AZ_DPP_STEP(0x142, 0xA) AZ_DPP_STEP(0x143, 0xC)
+#undef AZ_DPP_STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Exclusive prefix sum of one int per thread across the block (blockDim.x <= 1024).
 // Two barriers; every wave scans the (<= 16) wave totals itself with the same DPP scan -- no thread walks them one
 // dependent LDS access after the other.  (The single-workgroup geometry kernels make dozens of these calls per search:
@@ -158,12 +176,8 @@ static __device__ void block_bucket_sort(unsigned long long *w, int N, unsigned 
         lo = h < lo ? h : lo;
         hi = h > hi ? h : hi;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const unsigned l2 = __shfl_xor(lo, d, 64), h2 = __shfl_xor(hi, d, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
+    lo = wave_min_u32(lo);
+    hi = wave_max_u32(hi);
     if ((tid & 63) == 0 && N > 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
     __syncthreads();
     const unsigned base_h = mm[0];
@@ -349,28 +363,25 @@ static __device__ int spec_children_rows(const double *Bn, int P, double scale, 
         const int n = z < P ? div_nchildren(div_plan(Bn + 4 * z)) : 0;
         int tot;
         const int o = CH + block_excl_scan(n, &tot, wsum);
-        if (z < P) { schoff[z] = o; choff_all_g[z] = o; }
+        if (z < P) {
+            schoff[z] = o; choff_all_g[z] = o;
+            // (every child's parent, written by the parent's thread: the child threads below read it instead of
+            //  searching the offsets -- eight dependent LDS reads each)
+            if (o + n <= maxC && o + n <= W / 2)
+                for (int bi = 0; bi < n; ++bi) sslot[o + bi] = z;
+        }
         CH += tot;
     }
     if (CH > maxC || CH > 8192 || CH > W / 2 || CH > MAXIT * nt) return -1;
     __syncthreads();
     SPEC_T();
-    // parent of child ci: schoff[r] <= ci < schoff[r + 1]
-    auto parent_of = [&](int ci) {
-        int lo = 0, hi = P - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (schoff[mid] <= ci) lo = mid; else hi = mid - 1;
-        }
-        return lo;
-    };
     int bad = 0;
     double cb[MAXIT][4];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int ci = tid + it * nt;                                    // one thread per child
         if (ci < CH) {
-            const int r = parent_of(ci);
+            const int r = sslot[ci];
             div_child_box(Bn + 4 * r, div_plan(Bn + 4 * r), ci - schoff[r], cb[it]);
             float roi5[5];
             roi5[0] = 0.0f;

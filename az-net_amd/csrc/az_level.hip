@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
 
     // ---- zoom selection (test.py:383-387) -----------------------------------------------------------
     int *szr = reinterpret_cast<int *>(sbuf + W_SZR), *schoff = reinterpret_cast<int *>(sbuf + W_CHOFF);
+    int *sczi_w = reinterpret_cast<int *>(sbuf + W_SCZI);
     int PZ = 0;
     for (int base = 0; base < P; base += NT) {
         const int r = base + tid;
@@ -223,7 +224,11 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         const int n = z < PZ ? div_nchildren(div_plan(B + 4 * (size_t)szr[z])) : 0;
         int tot;
         const int ex = block_excl_scan(n, &tot, wsum);
-        if (z < PZ) schoff[z] = CH + ex;
+        if (z < PZ) {
+            schoff[z] = CH + ex;
+            if (CH + ex + n <= LV_C)
+                for (int bi = 0; bi < n; ++bi) sczi_w[CH + ex + bi] = (z << 16) | bi;        // (child -> parent, child number)
+        }
         CH += tot;
     }
     if (CH > LV_C || CH > a.capCh) { if (tid == 0) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }
@@ -233,13 +238,11 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     __syncthreads();
     // (one thread per CHILD: a parent's children one after the other are ~35 dependent f64 divisions)
     for (int ci = tid; ci < CH; ci += NT) {
-        const int z = seg_of(schoff, PZ, ci);
+        const int z = sczi[ci] >> 16, bi = sczi[ci] & 0xFFFF;
         const double *r = B + 4 * (size_t)szr[z];
-        const int bi = ci - schoff[z];
         double c[4];
         const long long key = div_child(r, div_plan(r), bi, a.min_side, c);
         ssort[ci] = ((unsigned long long)key << 20) | (unsigned)ci;                      // key < 1000^4 < 2^40
-        sczi[ci] = (z << 16) | bi;
     }
     TSTAMP();
     // ---- _sift_dup (div.pyx:78-89) ------------------------------------------------------------------
