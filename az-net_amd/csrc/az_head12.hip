@@ -58,7 +58,7 @@ __device__ __forceinline__ float4 zero_if(float4 v, bool ok)
 
 // One (m-tile, n-tile, K-chunk) work item.
 struct Item12 {
-    int m0, nst, n0, k0, kend;
+    int m0, nst, n0, k0, kend, t;       // t: which m-tile of the launch
     float *slab;
 };
 
@@ -331,7 +331,7 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
 
 __global__ void __launch_bounds__(W_NT)
 k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw, const int *Mptr, int capM,
-              int N, int K, int S, int Kc, float *__restrict__ part, int min_rows)
+              int N, int K, int S, int Kc, float *__restrict__ part, int min_rows, int pair_mode)
 {
     extern __shared__ __attribute__((aligned(16))) float lds12[];
     float *sA = lds12, *sB = lds12 + 2 * W_BM * W_LDT;
@@ -349,11 +349,24 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
     const int ngrp = ((int)blockIdx.x < G) ? (G - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nitems = ngrp * mt;
     const int tb = strips / mt, tr = strips - tb * mt;       // strips dealt evenly to the m-tiles
+    // Two m-tiles (the 350 - 768 row launches): the two readers of a group's weight panel are workgroups b and b + 8
+    // -- the same XCD, so the same L2 -- working on it AT THE SAME TIME (one takes m-tile 0, the other m-tile 1, roles
+    // swapping from group to group so that the 11- and the 10-strip tile do not let one drift ahead): the second read of
+    // a weight tile then finds it in L2 instead of going to memory again.  Same items, same bits; only who does which.
+    // (every workgroup then has G / (grid / 2) items -- the ngrp * mt it has anyway when the groups divide evenly)
+    const bool paired = pair_mode && mt == 2 && ((int)gridDim.x & 15) == 0 && G % (int)gridDim.x == 0;
+    const int pq = ((int)blockIdx.x / 16) * 8 + ((int)blockIdx.x & 7), prole = ((int)blockIdx.x >> 3) & 1;
     auto item_at = [&](int idx) {
-        const int gi = idx / mt, t = idx - gi * mt;
-        const int g = (int)blockIdx.x + gi * (int)gridDim.x;
+        int gi = idx / mt, t = idx - gi * mt;
+        int g = (int)blockIdx.x + gi * (int)gridDim.x;
+        if (paired) {
+            // the pair's groups pq, pq + grid/2, ...: one item of each per workgroup, the m-tile alternating
+            g = pq + idx * ((int)gridDim.x / 2);
+            t = (idx + prole) & 1;
+        }
         const int ntile = g / S, s = g - ntile * S;
         Item12 q;
+        q.t = t;
         q.m0 = (t * tb + (t < tr ? t : tr)) * 32;
         q.nst = tb + (t < tr ? 1 : 0);
         q.n0 = ntile * W_BN; q.k0 = s * Kc; q.kend = min(K, q.k0 + Kc);
@@ -370,7 +383,7 @@ k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt
         const int my0 = rg * rb_ + (rg < rr ? rg : rr);
         int nrt = rb_ + (rg < rr ? 1 : 0);
         // the half slot: last slot of the launch's last m-tile, i.e. of the row group that ends at the tile's end
-        const bool half = has_half && (idx % mt) == mt - 1 && nrt > 0 && my0 + nrt == it.nst;
+        const bool half = has_half && it.t == mt - 1 && nrt > 0 && my0 + nrt == it.nst;
         if (half) --nrt;
 #define TILE12(NRT_, HALF_) pb = tile12<NRT_, HALF_>(X, ldx, Wt, ldw, M, N, it, my0, nx, has_next, idx > 0, pb, sA, sB)
         if (half) {
@@ -410,7 +423,9 @@ int azk_fc_gemm12_prepare()
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
                    int K, int S, int Kc, float *part, int min_rows)
 {
-    static int grid = -1;               // AZ_GEMM12_GRID: an environment switch, the same for every device
+    static int grid = -1, pair = -1;    // AZ_GEMM12_GRID, AZ_GEMM12_PAIR=0: environment switches, the same for every device
     if (grid < 0) { const char *e = getenv("AZ_GEMM12_GRID"); grid = e ? atoi(e) : 256; }
-    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds12_bytes(), s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows);
+    if (pair < 0) { const char *e = getenv("AZ_GEMM12_PAIR"); pair = (e && !atoi(e)) ? 0 : 1; }
+    hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds12_bytes(), s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows,
+                       pair);
 }
