@@ -59,10 +59,12 @@ struct az_ctx {
     int *zr = nullptr, *csrc = nullptr, *choff_all = nullptr, *srcB[2] = {nullptr, nullptr};
     float *zoom_s = nullptr, *score_s = nullptr, *delta_s = nullptr;
     // the speculative pre-pass depends on the image shape only: its outputs are kept per shape (one entry)
-    float *spec_urois = nullptr;
-    double *specB1 = nullptr;
-    int *spec_choff = nullptr, *spec_U = nullptr;
-    struct { int h = -1, w = -1, defer = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc;
+    // (two entries: with the root's row in the pass [0] / deferred to level 4's pass [1] -- a context whose images
+    //  alternate between trees that reach level 4 and trees that do not keeps both)
+    float *spec_urois[2] = {nullptr, nullptr};
+    double *specB1[2] = {nullptr, nullptr};
+    int *spec_choff[2] = {nullptr, nullptr}, *spec_U[2] = {nullptr, nullptr};
+    struct SpecCache { int h = -1, w = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc[2];
     // Tz <= 0: the whole tree is a function of the image shape (az_static.hip); its rois / anchors / region -> row
     // map are kept per shape in exact-size HBM buffers (~100 B per roi: 70 KB for a 600x1000 image), least recently
     // used shapes are dropped beyond AZ_PLAN_CACHE entries; the per-level sizes stay on the host
@@ -252,7 +254,7 @@ int ensure_geom(az_ctx *c)
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
-    A(spec_urois, R * 5); A(specB1, R * 4); A(spec_choff, R); A(spec_U, 4);
+    for (int i = 0; i < 2; ++i) { A(spec_urois[i], R * 5); A(specB1[i], R * 4); A(spec_choff[i], R); A(spec_U[i], 4); }
     A(key_u, R * AZ_NSUB);
     A(choff_pair, R); A(crow, CH > 8192 ? CH : 8192);
     A(pred_v, R * AZ_NSUB * 4); A(score_v, R * AZ_NSUB); A(zoom_v, R); A(keep_v, R * AZ_NSUB); A(key_v, R * AZ_NSUB);
@@ -690,6 +692,10 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     // (AZ_DEFER_ROOT=0 keeps it in the speculative pass; same bits).  That level must be a mid-tree one.
     if (c->defer_root_env < 0) { const char *e = getenv("AZ_DEFER_ROOT"); c->defer_root_env = (e && !atoi(e)) ? 0 : 1; }
     q.defer_root = q.fused_lv && q.n_spec == 3 && nlev >= q.n_spec + 2 && c->defer_root_env;
+    // ... and must exist: a tree that ends before it would pay a whole head pass for the root's one row (measured: a
+    // [1, 8, 0, 0, 0] tree 0.43 ms deferred against 0.32).  The previous search of this image shape tells.
+    if (q.defer_root && c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev && c->hint_P[q.n_spec] == 0)
+        q.defer_root = false;
     q.lv_limit = AZ_MAX_LEVELS + 1;
     for (const auto &e : c->lv_limits)
         if (e.h == p->im_h && e.w == p->im_w) q.lv_limit = e.limit;
@@ -703,22 +709,22 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
 static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
 {
     if (!q.fused) return AZ_OK;
-    auto &k = c->spc;
     const int defer = q.defer_root ? 1 : 0;
-    if (k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side && k.defer == defer)
+    auto &k = c->spc[defer];
+    if (k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side)
         return AZ_OK;
     hipStream_t s = c->stream;
-    azk_spec_prepass(s, c->cnt, c->B[0], c->specB1, c->child, c->spec_choff, c->spec_urois, p->scale, p->min_side,
-                     c->maxR, c->maxCh, p->im_h, p->im_w, defer);
+    azk_spec_prepass(s, c->cnt, c->B[0], c->specB1[defer], c->child, c->spec_choff[defer], c->spec_urois[defer], p->scale,
+                     p->min_side, c->maxR, c->maxCh, p->im_h, p->im_w, defer);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->spec_U, &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->spec_U[defer], &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->h_cnt->err) {               // the speculative rows outgrow the context: take the multi-launch path
         c->nofuse_h = p->im_h; c->nofuse_w = p->im_w;
         k.h = -1;
         return AZ_OK;
     }
-    k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side; k.defer = defer;
+    k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side;
     k.P1 = c->h_cnt->specP1; k.CH = c->h_cnt->specCH; k.U = c->h_cnt->specU;
     return AZ_OK;
 }
@@ -927,8 +933,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
     }
     if (fused)
-        launch_head(c, c->spec_U, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 0,
-                    c->spec_urois, nullptr, c->spc.U);
+        launch_head(c, c->spec_U[defer_root ? 1 : 0], -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
+                    0, c->spec_urois[defer_root ? 1 : 0], nullptr, c->spc[defer_root ? 1 : 0].U);
     else if (n_spec)
         launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
     if (fused) {
@@ -937,8 +943,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.cnt = c->cnt;
         a.B[0] = c->B[0]; a.B[1] = c->B[1]; a.srcB[0] = c->srcB[0]; a.srcB[1] = c->srcB[1];
         a.index = c->index; a.inv = c->inv; a.zr = c->zr; a.choff = c->choff; a.csrc = c->csrc;
-        a.choff_all = c->spec_choff; a.specB1 = c->specB1;
-        a.reset = 1; a.specP1 = c->spc.P1; a.specCH = c->spc.CH; a.specU = c->spc.U;
+        const int dslot = defer_root ? 1 : 0;
+        a.choff_all = c->spec_choff[dslot]; a.specB1 = c->specB1[dslot];
+        a.reset = 1; a.specP1 = c->spc[dslot].P1; a.specCH = c->spc[dslot].CH; a.specU = c->spc[dslot].U;
         a.ubox = c->ubox; a.pred_u = c->pred_u; a.Yall = c->Yall; a.Z = c->Z; a.child = c->child;
         a.zoom_u = c->zoom_u; a.score_u = c->score_u; a.delta_u = c->delta_u; a.Sall = c->Sall;
         a.zoom_s = c->zoom_s; a.score_s = c->score_s; a.delta_s = c->delta_s;
@@ -1108,6 +1115,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         { const int lim = plan_search(c, p, nlev, tune).lv_limit; key.append((const char *)&lim, sizeof(int)); }
         key.append((const char *)&c->last_static, sizeof(int));
         key.append((const char *)&c->last_pair_mask, sizeof(int));
+        key.append((const char *)&c->last_defer, sizeof(int));
         for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
         const void *pp = stat ? (const void *)c->plan : nullptr;
         key.append((const char *)&pp, sizeof(pp));

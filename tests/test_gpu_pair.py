@@ -78,7 +78,10 @@ def test_pair_speculation_equals_plain_level_loop(small, mods, H, W, kw):
         a = _run(net, ffi, H, W, scale, Tz, True, **kw)
         b = _run(net, ffi, H, W, scale, Tz, False, **kw)
         _same(a, b)
-        assert b["st"].n_passes >= a["st"].n_passes
+        # (whether the root's row rides on a later pass is decided from the context's previous search: a tree that ended
+        #  early last time keeps it in the first pass, which can save a one-row pass)
+        extra = max(0, int(a["st"].root_deferred) - int(b["st"].root_deferred))
+        assert b["st"].n_passes + extra >= a["st"].n_passes
         some_pair = some_pair or a["st"].n_passes < b["st"].n_passes
         # ... and whatever the context decides by itself from the searches it has seen
         c = _run(net, ffi, H, W, scale, Tz, None, **kw)
