@@ -138,6 +138,7 @@ def main():
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
     ap.add_argument("--no-extras", action="store_true", help="skip deep_tree / shared_detection / nms")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
+    ap.add_argument("--sync-gather", action="store_true", help="blocking all-gather + host copy inside the loop")
     ap.add_argument("--no-queue-ahead", action="store_true",
                     help="launch image i+1 only after image i has been fetched (the GPU then idles ~40 us per image while "
                          "the host turns around)")
@@ -255,24 +256,44 @@ def main():
             if gat is not None:
                 gat.stage(i % ge, buf=(i // ge) % 2)
 
+        inflight = []
+
+        def collect():
+            h, n_b = inflight.pop(0)
+            assert len(gat.gather_end(h)) == world * n_b
+
         def done(i):
+            # The exchange of a finished batch is only STARTED here (collective + host copy on a side stream, pinned
+            # buffer); its proposals are collected one batch later, or at the end -- the host never sits in a
+            # synchronous wait for RCCL while the next image's kernels hold the CUs (--sync-gather: the blocking form).
             if gat is not None and ((i + 1) % ge == 0 or i == nsteps - 1):
                 n_b = i % ge + 1
-                res = gat.gather(n_b, buf=(i // ge) % 2)
-                assert len(res) == world * n_b
+                if args.sync_gather:
+                    assert len(gat.gather(n_b, buf=(i // ge) % 2)) == world * n_b
+                else:
+                    if inflight:
+                        collect()
+                    inflight.append((gat.gather_begin(n_b, buf=(i // ge) % 2), n_b))
                 rccl["collectives"] += 1
+            if i == nsteps - 1:
+                while inflight:
+                    collect()
 
         if args.inflight == 1:
             ahead = not args.no_queue_ahead
             if nsteps > 0:
                 launch(0)
+            trace = step_trace
             for i in range(nsteps):
+                t_i = time.perf_counter()
                 if ahead and i + 1 < nsteps:
                     launch(i + 1)
                 net.ctx.propose_fetch(want_scores=True)
                 done(i)
                 if not ahead and i + 1 < nsteps:
                     launch(i + 1)
+                if trace is not None:
+                    trace.append((time.perf_counter() - t_i) * 1e3)
             return
         assert world == 1, "--inflight > 1 is a single-GPU measurement"
         q = []
@@ -286,6 +307,7 @@ def main():
             m.ctx.propose_fetch(want_scores=True)
 
     ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
+    step_trace = []                    # host-side wall time of every step of the loop (diagnostics: median / tail in the line)
 
     # one-time initialisation per image shape (the search's shape-dependent pre-pass / plan, first-use allocations): not
     # a step, but timed and reported (`plan_build_ms`)
@@ -305,11 +327,19 @@ def main():
         n.ctx.set_profiling(0)
         n.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
     ev_every[0] = args.event_every if args.inflight == 1 else 0
+    # (no garbage-collector pause inside a timed region: a generation-2 collection of this process -- torch, numpy, the
+    #  411 MB of head arrays -- takes 30-50 ms, i.e. +0.17 ms per step when it lands among 200 timed steps)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
+    del step_trace[:]
     t0 = time.perf_counter()
     run(args.steps, params)
     barrier()
     dt = maxr(time.perf_counter() - t0)
+    gc.enable()
+    steps_ms = np.array(step_trace[:args.steps]) if step_trace else np.zeros(1)
     ev_every[0] = 0
     n_timed_steps = len(range(0, args.steps, args.event_every)) if args.inflight == 1 else args.steps
     ktimes = []
@@ -417,15 +447,23 @@ def main():
                               "note": "one-time work per image shape (shape-dependent pre-pass / plan, first-use allocations), "
                                       "done before the warm-up and not part of `value`"},
             "kernel_ms_per_step": {k: float(np.sum(v)) / n_timed_steps for k, v in sorted(per_level.items())},
+            "step_ms": {"median": float(np.median(steps_ms)), "p95": float(np.percentile(steps_ms, 95)),
+                        "max": float(steps_ms.max()), "over_1.5x_median": int((steps_ms > 1.5 * np.median(steps_ms)).sum()),
+                        "note": "host-side wall time per step of the timed loop (a step whose batch exchange is collected "
+                                "waits for the next image's kernels, so every gather_every-th step is long and the next short)"},
         }
 
     def timed_loop(fn, n, warm=10):
         fn(warm)
+        gc.collect()
+        gc.disable()
         barrier()
         t = time.perf_counter()
         fn(n)
         barrier()
-        return maxr(time.perf_counter() - t)
+        d_ = maxr(time.perf_counter() - t)
+        gc.enable()
+        return d_
 
     def simple_run(prm, ctxnet=None):
         cn = ctxnet or net
