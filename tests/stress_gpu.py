@@ -15,9 +15,14 @@ sys.path.insert(0, os.path.join(HERE, "..", "az-net_amd", "lib"))
 sys.path.insert(0, os.path.join(HERE, ".."))
 
 
+FULL = bool(int(os.environ.get("AZ_STRESS_FULL", "0")))     # the full-size head (25088 -> 4096 -> ...): many-row GEMM, big passes
+
+
 def make_net():
     from aznet_hip import synth
     from aznet_hip.net import HipAZNet
+    if FULL:
+        return HipAZNet(synth.make_head(seed=1234, **synth.FULL_DIMS), name="stress_full", max_regions=4096)
     return HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="stress")
 
 
@@ -34,7 +39,7 @@ def run_case(net, case):
     fh = synth.conv_out_size(int(round(H * scale))); fw = synth.conv_out_size(int(round(W * scale)))
     if orc.num_levels(H, W) - 1 < 1:
         return True, "case %d skipped (%dx%d: no level)" % (case, H, W), ""
-    fmap = synth.make_feature_map(100 + case, synth.SMALL_DIMS["C"], fh, fw)
+    fmap = synth.make_feature_map(100 + case, (synth.FULL_DIMS if FULL else synth.SMALL_DIMS)["C"], fh, fw)
     net.set_conv(fmap)
     batch = int(rng.choice([10000, 10000, 1000, 100, 37]))
     nprop = int(rng.choice([300, 300, 2000, 50]))
@@ -79,7 +84,7 @@ def run_case(net, case):
                 np.array_equal(q2[1], b[1])):
             return False, desc, "queued searches differ from the plain one"
     desc += " levels %d eval %d cand %d" % (a[2].n_levels, a[2].num_eval, Ya.shape[0])
-    if case % 4:
+    if case % (16 if FULL else 4):
         return True, desc, ""
 
     class Inj(object):
@@ -115,7 +120,14 @@ def main():
     net = make_net()
     bad = 0
     for case in range(first, first + n_cases):
-        ok, desc, why = run_case(net, case)
+        try:
+            ok, desc, why = run_case(net, case)
+        except Exception as e:                       # a tree that outgrows the context's limits is not a mismatch
+            if getattr(e, "code", None) == -3:
+                print("skipped case %d: %s" % (case, str(e)[:80]))
+                net = make_net()                     # (a failed search leaves nothing queued, but start clean)
+                continue
+            raise
         if not ok:
             bad += 1
             print("MISMATCH %s | %s" % (desc, why))
