@@ -32,6 +32,8 @@ struct az_ctx {
     // 2 = two bf16 terms / 3 MFMAs per product (~2^-16), 3 = three terms / 6 MFMAs (fp32-grade)
     int gemm_parts = 0;
     unsigned short *W6p = nullptr, *pool5p = nullptr;
+    float *gscale = nullptr;            // two-term (fp16) mode: {pool5 scale of this map, 1 / (sx * sw), scratch, scratch}
+    float w6_scale = 0.f;               // power-of-two scale of the fp16 weight terms
     float spatial_scale = 0.0625f;                 // test_fc.prototxt:22
     // weights (HBM)
     float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
@@ -329,6 +331,13 @@ int set_count(az_ctx *c, int *dptr, int v)
     return AZ_OK;
 }
 
+// Two-term (fp16) mode: the scale of this map's pool5 terms, once per enqueued search / head forward (one small launch).
+void prep_scale(az_ctx *c)
+{
+    if (c->gemm_parts == 2 && c->feat)
+        azk_feat_scale(c->stream, c->feat, (long long)c->d.C * c->d.H * c->d.W, c->gscale, c->w6_scale);
+}
+
 // One forward of the head on the `U` rois in ctx->urois (anchors in ctx->ubox); scores and
 // deltas go to the given arrays, decoded boxes to ctx->pred_u.
 void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, double eps, float *zoom, float *score,
@@ -348,11 +357,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     }
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
-                   (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail); }
+                   (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
     { Timed t(c, "fc6_gemm", level, 1);
       if (c->gemm_parts)
           azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
-                           c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part);
+                           c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part, c->gemm_parts, c->gscale);
       else {
           const bool can12 = (d.n6 / 128) * c->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
                              azk_fc_chunk(d.K6, c->S6) * c->S6 == d.K6 && azk_fc_chunk(d.K6, c->S6) >= 64 &&
@@ -493,7 +502,7 @@ int az_set_limits(az_ctx *c, int max_regions, int max_candidates)
 
 int az_set_gemm_mode(az_ctx *c, int parts)
 {
-    if (!c || !(parts == 0 || parts == 2)) return fail(c, AZ_ERR_INVALID, "az_set_gemm_mode: 0 or 2");
+    if (!c || !(parts == 0 || parts == 2 || parts == 3)) return fail(c, AZ_ERR_INVALID, "az_set_gemm_mode: 0, 2 or 3");
     if (c->head_loaded) return fail(c, AZ_ERR_STATE, "az_set_gemm_mode must precede az_load_head");
     c->gemm_parts = parts;
     return AZ_OK;
@@ -536,7 +545,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         A(part, pm > pw ? pm : pw);
     }
     A(h6, R * n6); A(h7, R * d.n7);
-    if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * n6 * d.K6); A(pool5p, (size_t)c->gemm_parts * R * d.K6); }
+    if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * n6 * d.K6); A(pool5p, (size_t)c->gemm_parts * R * d.K6); A(gscale, 4); }
 #undef A
     // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
     // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
@@ -552,8 +561,18 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     float *tmp = tg.p;
     HIPCHK(c, hipMemcpy(c->part, W6, (size_t)n6 * d.K6 * 4, hipMemcpyHostToDevice));
     azk_permute_k(c->stream, c->part, tmp, n6, C, 1);
-    if (c->gemm_parts)            // bf16 round-off planes of the (permuted, row-major) int6 weights
-        azk_split_planes(c->stream, tmp, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts);
+    if (c->gemm_parts) {          // 16-bit terms of the (permuted, row-major) int6 weights
+        c->w6_scale = 0.f;
+        if (c->gemm_parts == 2) {
+            // two fp16 terms: the weights are scaled by the power of two that brings max |w| into [2^14, 2^15)
+            float mx = 0.f;
+            for (size_t i = 0, n = (size_t)n6 * d.K6; i < n; ++i) { const float a = fabsf(W6[i]); if (a > mx) mx = a; }
+            c->w6_scale = 1.f;
+            if (mx > 0.f && mx < INFINITY) { int e; (void)frexpf(mx, &e); c->w6_scale = ldexpf(1.f, 15 - e); }
+            HIPCHK(c, hipMemsetAsync(c->gscale, 0, 4 * sizeof(float), c->stream));
+        }
+        azk_split_planes(c->stream, tmp, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts, c->w6_scale);
+    }
     azk_tile_weights(c->stream, tmp, c->W6, n6, d.K6);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(c->b6, b6, (size_t)n6 * 4, hipMemcpyHostToDevice));
@@ -640,7 +659,14 @@ struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask;
 // Cost model of one head pass on the int6 GEMM (us), from the measured launch shapes (profiles/): weight-streaming
 // bound up to ~40 rows, then ~1.45 us per row; and what a head pass costs besides int6 (RoIPool, reduce, int7, heads,
 // the level's geometry kernel).
-static double pass_us(double rows) { const double t = 60.0 + 1.4 * rows; return t < 92.0 ? 92.0 : t; }
+// (int6 on the 16-bit matrix cores, az_set_gemm_mode 2 / 3: a row costs a fraction of that, a launch somewhat more)
+static double pass_us(double rows, int parts = 0)
+{
+    if (parts == 2) { const double t = 85.0 + 0.25 * rows; return t < 100.0 ? 100.0 : t; }
+    if (parts == 3) { const double t = 125.0 + 0.43 * rows; return t < 150.0 ? 150.0 : t; }
+    const double t = 60.0 + 1.4 * rows;
+    return t < 92.0 ? 92.0 : t;
+}
 constexpr double PASS_OVERHEAD_US = 90.0, LOOKUP_US = 8.0;
 
 // Pair speculation: the head pass of level l also evaluates one row per distinct RoIPool window among ALL children of
@@ -665,8 +691,8 @@ static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool f
             // rows the speculation adds: what it added last time, else level l+1's unique rois scaled by parents / zoomed parents
             const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
                                                  : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
-            const double with = pass_us(c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
-            const double without = pass_us(c->hint_U[l]) + pass_us(c->hint_U[l + 1]) + 2 * PASS_OVERHEAD_US;
+            const double with = pass_us(c->hint_U[l] + S, c->gemm_parts) + PASS_OVERHEAD_US + LOOKUP_US;
+            const double without = pass_us(c->hint_U[l], c->gemm_parts) + pass_us(c->hint_U[l + 1], c->gemm_parts) + 2 * PASS_OVERHEAD_US;
             want = with < without && c->hint_U[l] + S + 2 < c->maxR;
         }
         if (want) { mask |= 1 << l; ++l; }          // level l+1 is looked up: it has no pass to carry rows
@@ -1092,7 +1118,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
     hipStream_t s = c->stream;
-    auto enqueue = [&]() { c->npass = 0; return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
+    auto enqueue = [&]() { c->npass = 0; prep_scale(c); return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
     if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
@@ -1505,6 +1531,7 @@ int az_head_forward(az_ctx *c, const float *rois, int R, float *zoom_prob, float
     if (rc) return rc;
     if ((rc = stage_rois(c, rois, R)) != AZ_OK) return rc;
     if (!(c->profiling & 4)) clear_events(c);
+    prep_scale(c);
     // (the row count is known on the host here: many rows take the many-row GEMM, as a one-pass search does)
     launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0, c->zoom_u, c->score_u, c->delta_u, 0.0, false, 0, nullptr, nullptr, R);
     HIPCHK(c, hipStreamSynchronize(c->stream));

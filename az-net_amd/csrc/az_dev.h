@@ -221,7 +221,7 @@ void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
 // (planes[q * plane_stride + ...]) instead of fp32 pool5, for the split-bf16 GEMM.
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
-                  size_t plane_stride, int parts, int min_strips, int coop_tail = 0);
+                  size_t plane_stride, int parts, int min_strips, int coop_tail = 0, const float *xscale = nullptr);
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
 // rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);
@@ -244,9 +244,13 @@ int azk_fc_chunk(int K, int S);
 int azk_gemm_grid();
 // split-bf16 GEMM (az_head_bf16.hip): operands as `parts` bf16 round-off planes
 void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long long n, long long plane_stride,
-                      int parts);
+                      int parts, float scale);
+// two-term (fp16) mode: scales[0] = power-of-two scale of pool5 for this map, scales[1] = 1 / (scales[0] * sw);
+// scales[2..3] are scratch words that must start at zero
+void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw);
 int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
-                     int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part);
+                     int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
+                     int parts, const float *scales);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu);
 // int7_1|int7_2's slab sum + bias + ReLU, then adj_score + adj_bbox + zoom_score (56 outputs) + bias +

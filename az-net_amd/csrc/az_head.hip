@@ -9,6 +9,7 @@
 // is what makes az_head_forward (unit call) and az_propose (fused loop) agree bit for bit and
 // makes the result independent of cfg.SEAR.BATCH_SIZE chunking.
 #include "az_dev.h"
+#include <hip/hip_fp16.h>
 #include <float.h>
 #include <stdlib.h>
 
@@ -85,17 +86,39 @@ __global__ void k_tile_weights(const float *__restrict__ in, float *__restrict__
 // not change a bit of the result.  Launches with many rois take the wave-per-bin path instead.
 constexpr int ROI_POOL_COOP_MAX = 96;      // rois per launch up to which windows are large (levels 1-3)
 
+// the 16-bit terms of one pool5 value: bf16 round-off terms, or (xs != 0, two-term mode) fp16 terms of x * xs
+__device__ __forceinline__ void write_terms(float x, unsigned short *po, size_t plane_stride, int parts, float xs)
+{
+    if (xs != 0.f) {
+        x *= xs;
+        for (int q = 0; q < parts; ++q) {
+            const __half h = __float2half_rn(x);
+            po[q * plane_stride] = __half_as_ushort(h);
+            x -= __half2float(h);
+        }
+        return;
+    }
+    for (int q = 0; q < parts; ++q) {
+        unsigned b = __float_as_uint(x);
+        b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
+        po[q * plane_stride] = (unsigned short)(b >> 16);
+        x -= __uint_as_float(b & 0xFFFF0000u);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat, AzHeadDims d,
                                                   float spatial_scale, const float *__restrict__ urois,
                                                   const int *Uptr, float *__restrict__ pool5,
                                                   unsigned short *__restrict__ planes, size_t plane_stride,
-                                                  int parts, int min_strips, int coop_tail)
+                                                  int parts, int min_strips, int coop_tail,
+                                                  const float *__restrict__ xscale)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     __shared__ __attribute__((aligned(16))) float spart[4][512];
     const int U = *Uptr;
     // launches that the split-bf16 GEMM will consume get their bf16 terms written here directly
     const bool to_planes = parts > 0 && ((U + 31) >> 5) >= min_strips;
+    const float xs = xscale ? xscale[0] : 0.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (coop_tail: the last `coop_tail` rois of a many-roi launch are large all the same -- the deferred root of
@@ -147,14 +170,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                         if (!to_planes) {
                             out[cb + 64 * j + lane] = m[j];
                         } else {
-                            float x = m[j];
-                            unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane;
-                            for (int q = 0; q < parts; ++q) {
-                                unsigned b = __float_as_uint(x);
-                                b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
-                                po[q * plane_stride] = (unsigned short)(b >> 16);
-                                x -= __uint_as_float(b & 0xFFFF0000u);
-                            }
+                            write_terms(m[j], planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane, plane_stride,
+                                        parts, xs);
                         }
                     }
             }
@@ -220,14 +237,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                     if (!to_planes) {
                         out[c] = m;
                     } else {
-                        float x = m;
-                        unsigned short *po = planes + (size_t)u * d.K6 + (size_t)p * d.C + c;
-                        for (int q = 0; q < parts; ++q) {
-                            unsigned b = __float_as_uint(x);
-                            b += 0x7FFFu + ((b >> 16) & 1u);            // bf16 round to nearest even
-                            po[q * plane_stride] = (unsigned short)(b >> 16);
-                            x -= __uint_as_float(b & 0xFFFF0000u);
-                        }
+                        write_terms(m, planes + (size_t)u * d.K6 + (size_t)p * d.C + c, plane_stride, parts, xs);
                     }
                 }
             }
@@ -966,11 +976,11 @@ __global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int n
 // --------------------------------------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
                   const int *Uptr, int capU, float *pool5, unsigned short *planes, size_t plane_stride, int parts,
-                  int min_strips, int coop_tail)
+                  int min_strips, int coop_tail, const float *xscale)
 {
     (void)capU;
     hipLaunchKernelGGL(k_roi_pool, dim3(4096), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
-                       planes, plane_stride, parts, min_strips, coop_tail);
+                       planes, plane_stride, parts, min_strips, coop_tail, xscale);
 }
 
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)

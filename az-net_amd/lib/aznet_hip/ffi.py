@@ -164,9 +164,9 @@ class AzContext(object):
     """One GPU's search context (az_ctx).  Not thread-safe; one per process/GPU."""
 
     def __init__(self, device=0, max_regions=None, max_candidates=None, gemm_mode=None):
-        """gemm_mode: 0 fp32 MFMA (default); 2 = int6 on the bf16 matrix cores with fp32 operands
-        split into two bf16 terms for launches of > 64 rois (az_set_gemm_mode); None reads the
-        AZ_GEMM_MODE environment variable.  Anything else raises ValueError."""
+        """gemm_mode: 0 fp32 MFMA (default); 2 = int6 on the 16-bit matrix cores with fp32 operands as two
+        fp16 terms (3 MFMAs per product, ~2^-21); 3 = as three bf16 terms (6 MFMAs, all 24 mantissa bits)
+        (az_set_gemm_mode); None reads the AZ_GEMM_MODE environment variable (default 0)."""
         self.L = load_library()
         h = ctypes.c_void_p()
         rc = self.L.az_create(int(device), ctypes.byref(h))
@@ -183,9 +183,9 @@ class AzContext(object):
                                            int(max_candidates or max_regions * AZ_NUM_SUBREG)))
         if gemm_mode is None:
             gemm_mode = int(os.environ.get("AZ_GEMM_MODE", "0"))
-        if int(gemm_mode) not in (0, 2):
+        if int(gemm_mode) not in (0, 2, 3):
             self.close()
-            raise ValueError("gemm_mode must be 0 (fp32 MFMA) or 2 (split bf16), got %r" % (gemm_mode,))
+            raise ValueError("gemm_mode must be 0 (fp32 MFMA), 2 (two fp16 terms) or 3 (three bf16 terms), got %r" % (gemm_mode,))
         self.gemm_mode = int(gemm_mode)
         if self.gemm_mode:
             self._chk(self.L.az_set_gemm_mode(self.h, self.gemm_mode))

@@ -346,7 +346,17 @@ def main():
     for n in nets:
         ktimes += n.ctx.last_kernel_times()
         n.ctx.set_profiling(0)
-    net.set_conv(conv)                 # (the timed loop left its last map in the context)
+    # every launch group of the search against ITS bound, from HIP events on a few extra, untimed steps (an event pair
+    # per launch group perturbs the stream by ~7 us each, so these steps are not part of `value`)
+    net.set_conv(conv)
+    net.ctx.set_profiling(2 | 4)
+    n_tab = 6
+    for i in range(n_tab):
+        net.ctx.propose_launch(params, fmap=convs[i % len(convs)], producer_done=True)
+        net.ctx.propose_fetch()
+    tab_times = net.ctx.last_kernel_times()
+    net.ctx.set_profiling(0)
+    net.set_conv(conv)                 # (the loops left their last map in the context)
     Y, S, st = net.propose(params, want_scores=True, want_stats=True)
     uniq = [int(st.level_unique[l]) for l in range(st.n_levels)]
     regions = [int(st.level_regions[l]) for l in range(st.n_levels)]
@@ -405,6 +415,37 @@ def main():
         per_level = {}
         for n, l, ms in ktimes:
             per_level.setdefault("%s@L%d" % (n, l + 1), []).append(ms)
+        # per launch group and pass: time, algorithmic bytes / flops (SURVEY 8d's units), fraction of its bound
+        ktab = {}
+        for n, l, ms in tab_times:
+            ktab.setdefault((n, l), []).append(ms)
+        pass_rows_now = rows_per_pass(st) or []
+        pass_levels = sorted({l for (n, l) in ktab if n == "fc6_gemm"})
+        kernel_table = []
+        for (n, l), v in sorted(ktab.items(), key=lambda kv: (kv[0][1], kv[0][0])):
+            us = float(np.mean(v)) * 1e3
+            rows = pass_rows_now[pass_levels.index(l)] if (l in pass_levels and pass_levels.index(l) < len(pass_rows_now)) else None
+            ent = {"kernel": n, "first_level": ("2" if l < 0 else str(l + 1)), "avg_us": us}
+            if rows is not None and not st.static_plan:
+                if n == "fc6_gemm":
+                    fl = rows * 2.0 * 25088 * 4096
+                    bound = max(25088 * 4096 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
+                    ent.update(rows=rows, bound="max(weights / 8 TB/s, flops / 157.3 TF)", t_min_us=bound, frac=bound / us)
+                elif n == "fc7_gemm":
+                    fl = rows * 2.0 * 4096 * 1280
+                    bound = max(4096 * 1280 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
+                    ent.update(rows=rows, bound="max(weights / 8 TB/s, flops / 157.3 TF)", t_min_us=bound, frac=bound / us)
+                elif n == "fc6_reduce":
+                    by = rows * 4096 * 4 * 17.0                     # 16 slabs read, one row of int6 written
+                    ent.update(rows=rows, bound="hbm", bytes=by, gb_per_s=by / us / 1e3, frac=by / HBM_PEAK * 1e6 / us)
+                elif n == "roi_pool":
+                    by = rows * 100352.0 + 4.0 * fmap_elems         # pool5 written, the map read once
+                    ent.update(rows=rows, bound="hbm", bytes=by, gb_per_s=by / us / 1e3, frac=by / HBM_PEAK * 1e6 / us)
+                elif n == "tail":
+                    by = rows * (8 * 1280 * 4 + 56 * 4 + 44 * 8) + 1280 * 64 * 4.0
+                    ent.update(rows=rows, bound="hbm (latency-bound in practice)", bytes=by, gb_per_s=by / us / 1e3,
+                               frac=by / HBM_PEAK * 1e6 / us)
+            kernel_table.append(ent)
         floor_us = t_min_us(uniq, fmap_elems)
         form = ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows) if st.static_plan else \
                ("level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
@@ -447,6 +488,11 @@ def main():
                               "note": "one-time work per image shape (shape-dependent pre-pass / plan, first-use allocations), "
                                       "done before the warm-up and not part of `value`"},
             "kernel_ms_per_step": {k: float(np.sum(v)) / n_timed_steps for k, v in sorted(per_level.items())},
+            "kernel_table": {"rows": kernel_table, "sum_us": float(sum(e["avg_us"] for e in kernel_table)),
+                             "note": "every launch group of one search (HIP events on the ctx stream, %d untimed steps right "
+                                     "behind the timed region): the geometry kernels (spec_levels, level_geom, final_select) "
+                                     "move a few hundred KB each and are latency chains of one workgroup -- no bandwidth "
+                                     "figure is given for them" % n_tab},
             "step_ms": {"median": float(np.median(steps_ms)), "p95": float(np.percentile(steps_ms, 95)),
                         "max": float(steps_ms.max()), "over_1.5x_median": int((steps_ms > 1.5 * np.median(steps_ms)).sum()),
                         "note": "host-side wall time per step of the timed loop (a step whose batch exchange is collected "
@@ -534,21 +580,58 @@ def main():
                                 "note": "independent images overlapped on three az_ctx/streams: the latency-bound "
                                         "geometry kernels of one image hide under the other's GEMMs"}
         del nets2[1:]
-    # ---- opt-in fast mode: int6 on the bf16 matrix cores, fp32 operands split in two bf16 terms ----
+    # ---- opt-in: int6 on the 16-bit matrix cores, fp32 operands as two fp16 / three bf16 terms (az_set_gemm_mode) -----
     if not args.no_fast and net.ctx.gemm_mode == 0:
-        nf = HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=2)
-        nf.set_conv(conv)
-        nf.propose(params)
-        n_f = max(20, args.steps // 2)
-        d1 = timed_loop(simple_run(params, nf), n_f)
+        # error of the head's outputs against an f64 evaluation of the same head (numpy; pool5 from the RoIPool kernel,
+        # which is bit-exact), mode 0 beside the others: what the 16-bit-term modes give up, if anything
+        rng = np.random.RandomState(5)
+        nr = 32
+        x1 = rng.uniform(0, 900, nr); y1 = rng.uniform(0, 500, nr)
+        rr = np.stack([np.zeros(nr), x1, y1, x1 + rng.uniform(16, 300, nr), y1 + rng.uniform(16, 300, nr)], 1).astype(np.float32)
+        net.set_conv(conv)
+        p5 = net.ctx.roi_pool(rr).astype(np.float64)
+
+        def f64_fc(x, W, b, relu):
+            y = x @ W.astype(np.float64).T + b.astype(np.float64)
+            return np.maximum(y, 0) if relu else y
+        h6 = f64_fc(p5, head["W6"], head["b6"], True)
+        h71 = f64_fc(h6, head["W71"], head["b71"], True)
+        h72 = f64_fc(h6, head["W72"], head["b72"], True)
+        truth = (1 / (1 + np.exp(-f64_fc(h72, head["Wz"], head["bz"], False))),
+                 1 / (1 + np.exp(-f64_fc(h71, head["Was"], head["bas"], False))), f64_fc(h71, head["Wab"], head["bab"], False))
+        del p5, h6
+
+        def err_vs_f64(n_):
+            n_.set_conv(conv)
+            o = n_.ctx.head_forward(rr)
+            return {k: float(np.abs(a - t).max()) for k, a, t in zip(("zoom_prob", "adj_prob", "adj_bbox"), o, truth)}
+        e0 = err_vs_f64(net)
+        modes = {}
+        for gm, label in ((2, "f16x3: int6 operands as two fp16 terms of x * 2^k (22 mantissa bits), 3 fp16 MFMAs per product, "
+                              "fp32 accumulate"),
+                          (3, "bf16x6: int6 operands as three bf16 terms (all 24 mantissa bits), 6 bf16 MFMAs per product, "
+                              "fp32 accumulate")):
+            nf = HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=gm)
+            nf.set_conv(conv)
+            ent = {"dtype": label, "max_abs_err_vs_f64": err_vs_f64(nf), "fp32_mfma_path_err_vs_f64": e0}
+            n_f = max(20, args.steps // 2)
+            for key, prm in (("level_loop", mk(False)), ("one_pass", mk(True))):
+                if args.tz > 0 and key == "one_pass":
+                    continue
+                nf.set_conv(conv)
+                Yf, Sf, stf = nf.propose(prm, want_scores=True, want_stats=True)
+                d1 = timed_loop(simple_run(prm, nf), n_f)
+                nf.set_conv(conv)
+                stf = nf.propose(prm, want_stats=True)[1]
+                ent[key] = {"value": world * NUM_PROPOSALS * n_f / d1, "unit": "proposals/s", "ms_per_image": d1 / n_f * 1e3,
+                            "rows_per_pass": rows_per_pass(stf),
+                            "max_score_diff_vs_fp32_path": float(np.abs(Sf - S).max()) if Sf.shape == S.shape else None}
+            ent["note"] = ("opt-in (az_set_gemm_mode %d), not `value`: int6 leaves the fp32-input MFMA; everything else is "
+                           "unchanged.  The error columns are the head's outputs against an f64 evaluation on %d rois" % (gm, nr))
+            modes["gemm_mode_%d" % gm] = ent
+            del nf
         if rank == 0:
-            out["split_bf16_mode"] = {
-                "value": world * NUM_PROPOSALS * n_f / d1, "unit": "proposals/s", "ms_per_image": d1 / n_f * 1e3,
-                "dtype": "bf16x3 (az_set_gemm_mode 2: int6 operands as two bf16 terms, 3 bf16 MFMAs per "
-                         "product, fp32 accumulate)",
-                "note": "opt-in, NOT the reference's fp32 arithmetic: earns no credit; scores / box deltas stay within "
-                        "1e-5 of the fp32 path (tolerance 1e-4)"}
-        del nf
+            out["int6_on_16bit_matrix_cores"] = modes
     # ---- a data-dependent tree: Tz = the median zoom score over the full tree's regions ----------
     if not args.no_calibrated:
         net.set_conv(conv)

@@ -106,14 +106,18 @@ const char *az_last_error(const az_ctx *ctx);
  * candidate capacity (default 16384*11).  Buffers are sized once, for 288 GB of HBM. */
 int az_set_limits(az_ctx *ctx, int max_regions, int max_candidates);
 
-/* Optional, before az_load_head.  How int6 (95 % of the head's FLOPs) is evaluated for launches of
- * more than 64 rois:
+/* Optional, before az_load_head.  How int6 (95 % of the head's FLOPs) is evaluated:
  *   0 (default)  fp32 MFMA (v_mfma_f32_32x32x2_f32), bitwise an fmaf chain;
- *   2            fp32 operands split into two bf16 round-off terms, three bf16 MFMAs per product with
- *                fp32 accumulation: products good to ~2^-16 (outputs still within 1e-4), 3/16 of the
- *                matrix-pipe cost.
- * Any other value is AZ_ERR_INVALID.  Launches of <= 64 rois are weight-streaming bound and always use
- * the fp32 kernel. */
+ *   2            fp32 operands as TWO fp16 terms (x * 2^k = x0 + x1, 22 mantissa bits; 2^k brings the largest
+ *                |weight| resp. the largest |feature-map value| of the image to [2^14, 2^15), so nothing overflows and
+ *                the scaling is exact), three fp16 MFMAs per product (x0*w1 + x1*w0 + x0*w0) with fp32 accumulation:
+ *                products good to ~2^-21; the head's outputs are as close to an f64 evaluation as mode 0's
+ *                (measured: tests/test_gpu_gemm_modes.py), at 3/16 of the matrix-pipe cost;
+ *   3            fp32 operands as THREE bf16 terms (24 mantissa bits: every fp32 value exactly), six bf16 MFMAs per
+ *                product (all cross terms of order <= 2), fp32 accumulation: nothing of fp32's precision or range is
+ *                given up; 6/16 of the matrix-pipe cost.
+ * In modes 2 and 3 every launch, whatever its row count, uses the same per-row arithmetic (a roi's bits do not
+ * depend on its batch), and int6 is the only layer that changes.  Any other value is AZ_ERR_INVALID. */
 int az_set_gemm_mode(az_ctx *ctx, int parts);
 
 /* Replaces caffe.Net(test_fc.prototxt, caffemodel) (tools/prop_az.py:95-96): the AZ head

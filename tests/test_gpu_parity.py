@@ -576,35 +576,34 @@ def test_im_detect_shared_and_apply_nms(det_small, small, mods):
         assert np.array_equal(nmsd[j][0], all_boxes[j][0][ref])
 
 
-# ---------------------------------------------------------------- split-bf16 int6 (gemm_mode 2)
-def test_split_bf16_mode_accuracy_and_row_independence(mods):
-    """az_set_gemm_mode(2): int6 on the bf16 matrix cores with fp32 operands split into two bf16
-    terms.  Outputs stay within 1e-4 of the fp32 path and of the BLAS oracle (measured ~1e-5),
-    and a roi's bits do not depend on the batch (both tile shapes use the same per-row arithmetic)."""
+# ---------------------------------------------------------------- int6 on the 16-bit matrix cores (gemm_mode 2 / 3)
+@pytest.mark.parametrize("mode", [2, 3])
+def test_16bit_term_modes_accuracy_and_row_independence(mods, mode):
+    """az_set_gemm_mode(2 / 3): int6 on the fp16 / bf16 matrix cores with fp32 operands as two fp16 resp. three bf16
+    terms (reduced head here; the full head, against f64: tests/test_gpu_gemm_modes.py).  Outputs within 1e-4 of the
+    fp32 path and of the BLAS oracle (measured ~1e-6), and a roi's bits do not depend on the batch (both tile
+    shapes use the same per-row arithmetic)."""
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
     fmap = synth.make_feature_map(3, synth.SMALL_DIMS["C"], 38, 63)
     rois = _rand_rois(np.random.RandomState(11), 300, 1000, 600)
     ref = orc.head_forward(head, fmap[0], rois)
-    nets = {m: HipAZNet(head, name="m%d" % m, max_regions=1024, gemm_mode=m) for m in (0, 2)}
+    nets = {m: HipAZNet(head, name="m%d" % m, max_regions=1024, gemm_mode=m) for m in (0, mode)}
     out = {}
     for m, net in nets.items():
         net.set_conv(fmap)
         out[m] = net.ctx.head_forward(rois)
-    for a, b, r in zip(out[2], out[0], ref):
+    for a, b, r in zip(out[mode], out[0], ref):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-4)
     for n in (1, 40, 64, 65, 130):          # 1-2 strips: 4-wave shape; >= 3 strips: 8-wave shape
-        sub = nets[2].ctx.head_forward(rois[:n])
-        for a, b in zip(sub, out[2]):
+        sub = nets[mode].ctx.head_forward(rois[:n])
+        for a, b in zip(sub, out[mode]):
             assert np.array_equal(a, b[:n])
-    # whole search in mode 2 vs mode 0: same tree, scores within 1e-4
+    # whole search vs mode 0: same tree, scores within 1e-4
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0)
-    res = {m: nets[m].propose(p, want_scores=True, want_stats=True) for m in (0, 2)}
-    assert list(res[0][2].level_unique[:5]) == list(res[2][2].level_unique[:5])
-    c0, c2 = nets[0].ctx.last_candidates(), nets[2].ctx.last_candidates()
+    res = {m: nets[m].propose(p, want_scores=True, want_stats=True) for m in (0, mode)}
+    assert list(res[0][2].level_unique[:5]) == list(res[mode][2].level_unique[:5])
+    c0, c2 = nets[0].ctx.last_candidates(), nets[mode].ctx.last_candidates()
     assert c0[0].shape == c2[0].shape
     np.testing.assert_allclose(c2[1], c0[1], rtol=0, atol=1e-4)
-    for bad in (5, 3):           # only 0 and 2 exist (include/aznet_hip.h: az_set_gemm_mode)
-        with pytest.raises(ValueError):
-            ffi.AzContext(0, gemm_mode=bad)
