@@ -357,10 +357,10 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     }
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
-                   (size_t)c->maxR * d.K6, c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
+                   azk_act_plane_elems(c->maxR, d.K6), c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
     { Timed t(c, "fc6_gemm", level, 1);
       if (c->gemm_parts)
-          azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, (size_t)c->maxR * d.K6, c->W6p, d.K6, (size_t)d.n6 * d.K6, Uptr,
+          azk_fc_gemm_bf16(c->stream, c->pool5p, d.K6, azk_act_plane_elems(c->maxR, d.K6), c->W6p, d.K6, azk_weight_plane_elems(d.n6, d.K6), Uptr,
                            c->maxR, d.n6, d.K6, c->S6, azk_fc_chunk(d.K6, c->S6), c->part, c->gemm_parts, c->gscale);
       else {
           const bool can12 = (d.n6 / 128) * c->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
@@ -545,7 +545,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         A(part, pm > pw ? pm : pw);
     }
     A(h6, R * n6); A(h7, R * d.n7);
-    if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * n6 * d.K6); A(pool5p, (size_t)c->gemm_parts * R * d.K6); A(gscale, 4); }
+    if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * azk_weight_plane_elems(n6, d.K6)); A(pool5p, (size_t)c->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
+        HIPCHK(c, hipMemsetAsync(c->pool5p, 0, (size_t)c->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, c->stream)); }
 #undef A
     // Weights: Caffe [out, in] row-major is already the K-contiguous "B^T" layout the GEMM reads.
     // int6 reads pool5, which this library keeps bin-major ([p][c], see az_head.hip): permute
@@ -571,7 +572,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
             if (mx > 0.f && mx < INFINITY) { int e; (void)frexpf(mx, &e); c->w6_scale = ldexpf(1.f, 15 - e); }
             HIPCHK(c, hipMemsetAsync(c->gscale, 0, 4 * sizeof(float), c->stream));
         }
-        azk_split_planes(c->stream, tmp, c->W6p, (long long)n6 * d.K6, (long long)n6 * d.K6, c->gemm_parts, c->w6_scale);
+        azk_split_weight_planes(c->stream, tmp, c->W6p, n6, d.K6, c->gemm_parts, c->w6_scale);
     }
     azk_tile_weights(c->stream, tmp, c->W6, n6, d.K6);
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -247,6 +247,20 @@ void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long 
                       int parts, float scale);
 // two-term (fp16) mode: scales[0] = power-of-two scale of pool5 for this map, scales[1] = 1 / (scales[0] * sw);
 // scales[2..3] are scratch words that must start at zero
+// activation (pool5) planes of k_fc_terms: tile-major too -- block (row / 32, k / 32) holds 32 rows x 32 terms (2 KB), K padded
+// to a multiple of 32 (the padding is zeroed once, at allocation) -- so that a wave's tile load is 1 KB contiguous
+__host__ __device__ inline size_t azk_act_plane_index(int row, int k, int K)
+{
+    const int KT = (K + 31) >> 5;
+    return ((size_t)(row >> 5) * KT + (k >> 5)) * 1024 + (size_t)(row & 31) * 32 + (k & 31);
+}
+__host__ __device__ inline size_t azk_act_plane_elems(int rows, int K)
+{
+    return (size_t)((rows + 31) >> 5) * ((K + 31) >> 5) * 1024;
+}
+// weight planes of k_fc_terms: tile-major (128 rows x 32 terms per 8 KB block), zero-padded; elements per plane
+size_t azk_weight_plane_elems(int N, int K);
+void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out, int N, int K, int parts, float scale);
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw);
 int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,

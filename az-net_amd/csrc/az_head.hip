@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                         if (!to_planes) {
                             out[cb + 64 * j + lane] = m[j];
                         } else {
-                            write_terms(m[j], planes + (size_t)u * d.K6 + (size_t)p * d.C + cb + 64 * j + lane, plane_stride,
+                            write_terms(m[j], planes + azk_act_plane_index(u, p * d.C + cb + 64 * j + lane, d.K6), plane_stride,
                                         parts, xs);
                         }
                     }
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                     if (!to_planes) {
                         out[c] = m;
                     } else {
-                        write_terms(m, planes + (size_t)u * d.K6 + (size_t)p * d.C + c, plane_stride, parts, xs);
+                        write_terms(m, planes + azk_act_plane_index(u, p * d.C + c, d.K6), plane_stride, parts, xs);
                     }
                 }
             }

@@ -160,6 +160,8 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
     const int cstrip = wave & 3;
     const int lrow = lane & 31;
     const int nk = (kend - k0 + BK - 1) / BK;
+    const int KT = (ldw + BK - 1) / BK;                       // K steps of a whole weight row (ldw = K)
+    const int KTA = (ldx + BK - 1) / BK;                      // ... of a whole activation row
 
     floatx16 acc[NR][CW];
 #pragma unroll
@@ -174,22 +176,33 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
     __amdgpu_buffer_rsrc_t rsA[P], rsB[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        rsA[p] = tile_rsrc16(Xp + p * xplane + (size_t)m0 * ldx, (size_t)(M - m0) * ldx);
-        rsB[p] = tile_rsrc16(Wp + p * wplane + (size_t)n0 * ldw, (size_t)(N - n0) * ldw);
+        // (tile-major activation planes: block (row / 32, k / 32) is 2 KB; rows past M inside the last strip hold stale
+        //  finite terms that only reach output rows nobody stores, strips past it are outside the descriptor: zeros)
+        rsA[p] = tile_rsrc16(Xp + p * xplane + (size_t)(m0 >> 5) * KTA * 1024, (size_t)(((M + 31) >> 5) - (m0 >> 5)) * KTA * 1024);
+        // (tile-major weight planes: block (n0 / 128 + c, k / 32) is 8 KB; the descriptor spans this tile's CW block rows)
+        rsB[p] = tile_rsrc16(Wp + p * wplane + (size_t)(n0 / BN) * KT * (BN * BK),
+                             (size_t)min(CW, (N + BN - 1) / BN - n0 / BN) * KT * (BN * BK));      // (past the last block row: zeros)
     }
     unsigned voA[NA], voB[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) voA[i] = (unsigned)((min(srow + RS * i, M - 1 - m0) * ldx + sc8) * 2);
+    for (int i = 0; i < NA; ++i) {
+        const int arow = srow + RS * i;
+        voA[i] = (unsigned)(((size_t)(arow >> 5) * KTA * 1024 + (arow & 31) * 32 + sc8) * 2);
+    }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) voB[i] = (unsigned)((min(srow + RS * i, N - 1 - n0) * ldw + sc8) * 2);
+    for (int i = 0; i < NB; ++i) {
+        const int brow = srow + RS * i;                       // row of the B tile: block row brow / 128, row brow % 128 inside
+        voB[i] = (unsigned)(((size_t)(brow / BN) * KT * (BN * BK) + (brow % BN) * BK + sc8) * 2);
+    }
     auto gload = [&](int kt, v4u (&ra)[P][NA], v4u (&rb)[P][NB]) {
-        const unsigned so = (unsigned)(k0 + kt * BK) * 2u;
+        const unsigned soa = (unsigned)(k0 / BK + kt) * 2048u;
+        const unsigned sob = (unsigned)(k0 / BK + kt) * (unsigned)(BN * BK * 2);      // (chunks start on K-step boundaries)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[p][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA[p], voA[i], so, 0);
+            for (int i = 0; i < NA; ++i) ra[p][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA[p], voA[i], soa, 0);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[p][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB[p], voB[i], so, AZ_W_AUX);
+            for (int i = 0; i < NB; ++i) rb[p][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB[p], voB[i], sob, AZ_W_AUX);
         }
     };
     auto lstore = [&](int kt, int buf, const v4u (&ra)[P][NA], const v4u (&rb)[P][NB]) {
@@ -396,6 +409,50 @@ void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long 
                       int parts, float scale)
 {
     hipLaunchKernelGGL(k_split_planes, dim3(4096), dim3(256), 0, s, in, out, n, plane_stride, parts, scale);
+}
+
+// Weight planes for k_fc_terms: tile-major -- block (n / 128, k / 32) holds 128 rows x 32 terms (8 KB) contiguously, K padded
+// with zeros to a multiple of 32, N to a multiple of 128 -- so that a K step's weight tile is one contiguous 8 KB
+// read per plane instead of 128 pieces of 64 B that are a weight row (tens of KB) apart.
+size_t azk_weight_plane_elems(int N, int K)
+{
+    return (size_t)((N + BN - 1) / BN) * BN * (size_t)((K + BK - 1) / BK) * BK;
+}
+
+namespace {
+__global__ void k_split_planes_tiled(const float *__restrict__ in, unsigned short *__restrict__ out, int N, int K,
+                                     long long plane_stride, int parts, float scale)
+{
+    const int KT = (K + BK - 1) / BK;
+    const long long total = (long long)((N + BN - 1) / BN) * BN * KT * BK;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int kk = (int)(o % BK), r = (int)((o / BK) % BN);
+        const long long blk = o / (BK * BN);
+        const int kt = (int)(blk % KT), nt = (int)(blk / KT);
+        const int n = nt * BN + r, k = kt * BK + kk;
+        float x = (n < N && k < K) ? in[(size_t)n * K + k] : 0.f;
+        if (scale != 0.f) {
+            x *= scale;
+            for (int p = 0; p < parts; ++p) {
+                const __half h = __float2half_rn(x);
+                out[p * plane_stride + o] = __half_as_ushort(h);
+                x -= __half2float(h);
+            }
+        } else {
+            for (int p = 0; p < parts; ++p) {
+                const unsigned short h = f2bf(x);
+                out[p * plane_stride + o] = h;
+                x -= bf2f(h);
+            }
+        }
+    }
+}
+}  // namespace
+
+void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out, int N, int K, int parts, float scale)
+{
+    hipLaunchKernelGGL(k_split_planes_tiled, dim3(4096), dim3(256), 0, s, in, out, N, K,
+                       (long long)azk_weight_plane_elems(N, K), parts, scale);
 }
 
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw)
