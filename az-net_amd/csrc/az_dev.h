@@ -252,7 +252,9 @@ void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long 
 __host__ __device__ inline size_t azk_act_plane_index(int row, int k, int K)
 {
     const int KT = (K + 31) >> 5;
-    return ((size_t)(row >> 5) * KT + (k >> 5)) * 1024 + (size_t)(row & 31) * 32 + (k & 31);
+    // (inside a block the four 16-byte vectors of a row are XOR-swizzled the way the LDS tile is read -- vector v of
+    //  row r sits at v ^ ((r >> 2) & 3) --, so global -> LDS is a linear copy)
+    return ((size_t)(row >> 5) * KT + (k >> 5)) * 1024 + (size_t)(row & 31) * 32 + ((((k & 31) >> 3) ^ ((row >> 2) & 3)) << 3) + (k & 7);
 }
 __host__ __device__ inline size_t azk_act_plane_elems(int rows, int K)
 {

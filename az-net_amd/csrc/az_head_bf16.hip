@@ -142,6 +142,11 @@ __device__ __forceinline__ void mtile_rows(int strips, int mt, int t, int &strip
 //           per CU.  CW = 1: 256 x 128 tiles (three terms: LDS);  CW = 2: 256 x 256 tiles, two column strips per
 //           wave (two terms: a third fewer LDS bytes per MFMA, what that mode is bound by: 480 -> 410 us at 670 rows);
 //         WAVES = 4 / AROWS = 64 for launches of <= 2 row strips (wave w: column strip w, every row strip), two per CU.
+#ifndef AZ_TERMS_DMA
+#define AZ_TERMS_DMA 1          /* 1: tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), no staging registers, no
+                                   ds_write pass; 0: through registers, requested two K steps ahead.  Measured at 670 rows:
+                                   direct 364 / 629 us (two / three terms), through registers 378 / 655 */
+#endif
 template <int NRTW, int WAVES, int AROWS, int P, bool F16, int CW>
 __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__ Xp, int ldx, size_t xplane,
                                               const unsigned short *__restrict__ Wp, int ldw, size_t wplane, int M,
@@ -172,7 +177,6 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 
     const int srow = tid >> 2, sc8 = (tid & 3) * 8;
-    const int swz_st = (((tid & 3) ^ ((srow >> 2) & 3)) * 8);            // (RS is a multiple of 16: the same for every i)
     __amdgpu_buffer_rsrc_t rsA[P], rsB[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -205,26 +209,34 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
             for (int i = 0; i < NB; ++i) rb[p][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB[p], voB[i], sob, AZ_W_AUX);
         }
     };
+    // (the planes are tile-major, zero-padded in K and pre-swizzled: the stage is a linear image of the tile, and a K that
+    //  is not a multiple of the K step needs no masking -- chunks start on K-step boundaries, the last one ends in zeros)
     auto lstore = [&](int kt, int buf, const v4u (&ra)[P][NA], const v4u (&rb)[P][NB]) {
+        (void)kt;
         unsigned short *st = lds + buf * STAGE;
-        // (a K that is not a multiple of the K step: the last tile's vectors past the end are stored as zero --
-        //  a workgroup-uniform case, so the common path carries no per-thread selects)
-        const bool tail = (k0 + kt * BK + BK) > kend;
-        const bool ok = !tail || (k0 + kt * BK + sc8) < kend;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                v4u v = ra[p][i];
-                if (__builtin_expect(tail, 0)) v = ok ? v : v4u{0, 0, 0, 0};
-                *reinterpret_cast<v4u *>(st + p * ATILE + (srow + RS * i) * BK + swz_st) = v;
-            }
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<v4u *>(st + p * ATILE + (srow + RS * i) * BK + sc8) = ra[p][i];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                v4u v = rb[p][i];
-                if (__builtin_expect(tail, 0)) v = ok ? v : v4u{0, 0, 0, 0};
-                *reinterpret_cast<v4u *>(st + P * ATILE + p * BTILE + (srow + RS * i) * BK + swz_st) = v;
-            }
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<v4u *>(st + P * ATILE + p * BTILE + (srow + RS * i) * BK + sc8) = rb[p][i];
+        }
+    };
+    // direct form: one wave instruction moves the 1 KB (16 rows x 64 B) its lanes would have staged, to the same place
+    auto dma = [&](int kt, int buf) {
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        unsigned short *st = lds + buf * STAGE + wave * 16 * BK;
+        const unsigned soa = (unsigned)(k0 / BK + kt) * 2048u;
+        const unsigned sob = (unsigned)(k0 / BK + kt) * (unsigned)(BN * BK * 2);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA[p], (lds_ptr)(st + p * ATILE + RS * i * BK), 16, voA[i], soa, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[p], (lds_ptr)(st + P * ATILE + p * BTILE + RS * i * BK), 16, voB[i], sob, 0,
+                                                         AZ_W_AUX);
         }
     };
     const int fsw = (lrow >> 2) & 3, fhi = lane >> 5;
@@ -238,15 +250,23 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
     // Tiles are requested two K steps ahead with two register sets (the set whose tile has just gone to LDS is re-used
     // at once for the tile two steps on; set 0: even tiles, set 1: odd tiles) -- or, where registers are short (the
     // 256-column shape), one step ahead with one set.
-    constexpr bool TWO = CW == 1;
+    constexpr bool DMA = (AZ_TERMS_DMA != 0) && P > 0;       // (value-dependent, so that the unused branch is discarded)
+    constexpr bool TWO = CW == 1 && !DMA;
     v4u ra0[P][NA], rb0[P][NB], ra1[TWO ? P : 1][NA], rb1[TWO ? P : 1][NB];
-    gload(0, ra0, rb0);
-    if constexpr (TWO) gload(nk > 1 ? 1 : 0, ra1, rb1);
-    __syncthreads();                 // the previous work item's readers are done with both stages
-    lstore(0, 0, ra0, rb0);
-    __syncthreads();
-    if constexpr (TWO) gload(nk > 2 ? 2 : nk - 1, ra0, rb0);
-    else gload(nk > 1 ? 1 : 0, ra0, rb0);
+    if constexpr (DMA) {
+        __syncthreads();             // the previous work item's readers are done with both stages
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        gload(0, ra0, rb0);
+        if constexpr (TWO) gload(nk > 1 ? 1 : 0, ra1, rb1);
+        __syncthreads();                 // the previous work item's readers are done with both stages
+        lstore(0, 0, ra0, rb0);
+        __syncthreads();
+        if constexpr (TWO) gload(nk > 2 ? 2 : nk - 1, ra0, rb0);
+        else gload(nk > 1 ? 1 : 0, ra0, rb0);
+    }
     constexpr int NPH = 2 * NRTW;
     bf16x8 bq[2][CW][P], aq[2][P];
     auto rdA = [&](int buf, int h, int r, bf16x8 (&a)[P]) {
@@ -283,10 +303,15 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
     };
     if constexpr (NRTW > 0) { rdB(0, 0, bq[0]); rdA(0, 0, 0, aq[0]); }
     constexpr int AHEAD = TWO ? 3 : 2;
-    auto step = [&](int kt, int buf, v4u (&rs_a)[P][NA], v4u (&rs_b)[P][NB]) {     // the set holding tile kt + 1
+    auto step = [&](int kt, int buf, auto &rs_a, auto &rs_b) {     // the set holding tile kt + 1
         if constexpr (NRTW == 0) {
-            lstore(kt + 1, buf ^ 1, rs_a, rs_b);
-            gload(kt + AHEAD < nk ? kt + AHEAD : nk - 1, rs_a, rs_b);
+            if constexpr (DMA) {
+                dma(kt + 1 < nk ? kt + 1 : nk - 1, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                lstore(kt + 1, buf ^ 1, rs_a, rs_b);
+                gload(kt + AHEAD < nk ? kt + AHEAD : nk - 1, rs_a, rs_b);
+            }
             __syncthreads();
         } else {
             constexpr int NW = P * (NA + NB);                     // tile vectors per thread: stores = requests
@@ -295,12 +320,19 @@ __device__ __forceinline__ void fc_tile_terms(const unsigned short *__restrict__
                 constexpr int h = ph / NRTW, r = ph % NRTW;
                 constexpr bool last = ph == NPH - 1;
                 constexpr int nh = (ph + 1) / NRTW, nr = (ph + 1) % NRTW;
-                constexpr bool st_here = ph == 0, ld_here = ph == (NPH > 1 ? 1 : 0);
+                constexpr bool st_here = ph == 0 && !DMA, ld_here = DMA ? ph == 0 : ph == (NPH > 1 ? 1 : 0);
                 constexpr int nother = P + (st_here ? NW : 0) + (ld_here ? NW : 0) + ((last || nh != h) ? CW * P : 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (last) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (last) {
+                    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (st_here) lstore(kt + 1, buf ^ 1, rs_a, rs_b);     // (past the last step: a tile nobody reads)
-                if constexpr (ld_here) gload(kt + AHEAD < nk ? kt + AHEAD : nk - 1, rs_a, rs_b);   // unconditional: exact vmcnt bookkeeping
+                if constexpr (ld_here) {
+                    if constexpr (DMA) dma(kt + 1 < nk ? kt + 1 : nk - 1, buf ^ 1);
+                    else gload(kt + AHEAD < nk ? kt + AHEAD : nk - 1, rs_a, rs_b);   // unconditional: exact vmcnt bookkeeping
+                }
                 if constexpr (!last) {
                     rdA(buf, nh, nr, aq[(ph + 1) & 1]);
                     if constexpr (nh != h) rdB(buf, nh, bq[nh]);
@@ -426,9 +458,12 @@ __global__ void k_split_planes_tiled(const float *__restrict__ in, unsigned shor
     const int KT = (K + BK - 1) / BK;
     const long long total = (long long)((N + BN - 1) / BN) * BN * KT * BK;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
-        const int kk = (int)(o % BK), r = (int)((o / BK) % BN);
+        // (o = position in the plane; inside a row the four 16-byte vectors are XOR-swizzled the way the LDS tile is
+        //  read, so global -> LDS is a linear copy: position vector pv of row r holds k vector pv ^ ((r >> 2) & 3))
+        const int pk = (int)(o % BK), r = (int)((o / BK) % BN);
         const long long blk = o / (BK * BN);
         const int kt = (int)(blk % KT), nt = (int)(blk / KT);
+        const int kk = ((((pk >> 3) ^ ((r >> 2) & 3)) << 3) | (pk & 7));
         const int n = nt * BN + r, k = kt * BK + kk;
         float x = (n < N && k < K) ? in[(size_t)n * K + k] : 0.f;
         if (scale != 0.f) {
