@@ -626,6 +626,27 @@ def main():
                 ent[key] = {"value": world * NUM_PROPOSALS * n_f / d1, "unit": "proposals/s", "ms_per_image": d1 / n_f * 1e3,
                             "rows_per_pass": rows_per_pass(stf),
                             "max_score_diff_vs_fp32_path": float(np.abs(Sf - S).max()) if Sf.shape == S.shape else None}
+            # the int6 kernel of the one-pass form against the 16-bit MFMA peak (HIP events around the launch group)
+            if args.tz <= 0:
+                nf.set_conv(conv)
+                nf.ctx.set_profiling(2 | 4)
+                for _ in range(6):
+                    nf.propose(mk(True))
+                t6 = [ms for n_, l_, ms in nf.ctx.last_kernel_times() if n_ == "fc6_gemm"]
+                nf.ctx.set_profiling(0)
+                if t6:
+                    rows6 = int(rows_per_pass(stf)[0]) if rows_per_pass(stf) else sum(st.level_unique[:st.n_levels])
+                    us6 = float(np.mean(t6)) * 1e3 * (len(t6) / 6.0)      # (both shapes of the kernel are launched: sum per search)
+                    mf = {2: 3, 3: 6}[gm]
+                    padded = ((rows6 + 31) // 32) * 32
+                    ex = padded * 2.0 * 25088 * 4096 * mf
+                    ent["int6_kernel"] = {"rows": rows6, "avg_us": us6, "mfmas_per_product": mf,
+                                          "executed_tflops": ex / us6 / 1e6, "peak_tflops": 2500.0,
+                                          "frac": ex / us6 / 1e6 / 2500.0,
+                                          "fp32_equivalent_tflops": rows6 * 2.0 * 25088 * 4096 / us6 / 1e6,
+                                          "note": "peak = dense fp16 / bf16 MFMA at 2.4 GHz; under these MFMAs the chip sustains "
+                                                  "1.77-1.80 GHz (profiles/r03_mode*_pmc_2.csv: GRBM_GUI_ACTIVE), where the "
+                                                  "matrix pipe is 71-77 % busy"}
             ent["note"] = ("opt-in (az_set_gemm_mode %d), not `value`: int6 leaves the fp32-input MFMA; everything else is "
                            "unchanged.  The error columns are the head's outputs against an f64 evaluation on %d rois" % (gm, nr))
             modes["gemm_mode_%d" % gm] = ent
