@@ -78,6 +78,12 @@ struct az_ctx {
         double *ubox = nullptr;
         int *reg_u = nullptr, *cand_src = nullptr, *meta = nullptr;
         unsigned long long last_use = 0;
+        // whole-tree speculation (SearchPlan::full): window table over the plan's rows, the speculative rows' map, the
+        // pass's rois = the plan's non-root rows ++ extra rows (speculative rows whose window the plan lacks) ++ the root
+        unsigned long long *htab = nullptr; unsigned hT = 0;
+        int *spec_map = nullptr, *full_meta = nullptr;
+        float *full_urois = nullptr; double *full_ubox = nullptr;
+        int Ufull = 0, full_state = 0;        // 0: not built, 1: ready, -1: cannot be used for this shape
     };
     std::vector<StaticPlan *> plans;
     StaticPlan *plan = nullptr;               // the plan of the search being launched / in flight
@@ -94,6 +100,10 @@ struct az_ctx {
     int hint_h = -1, hint_w = -1, hint_nlev = 0;
     int pair_env = -1;                        // AZ_PAIR_SPEC: 0 never, 1 by history (default), 2 always
     std::vector<std::pair<int, int>> nopair;  // image shapes whose pair-speculation rows outgrew the tables
+    int full_env = -1;                        // AZ_FULL_SPEC: 0 never, 1 by history (default), 2 always
+    bool full_now = false;                    // the search being launched takes the whole-tree pass
+    int last_full = 0;
+    double *pred_w = nullptr; float *score_w = nullptr, *zoom_w = nullptr; unsigned char *keep_w = nullptr; unsigned *key_w = nullptr;   // second *_v set
     int last_pair_mask = 0;                   // levels whose head pass carried pair-speculation rows (search in flight / last)
     // pair speculation: all-children offsets / child -> row of the level whose pass carries the rows; looked-up outputs
     int *choff_pair = nullptr, *crow = nullptr;
@@ -260,6 +270,7 @@ int ensure_geom(az_ctx *c)
     A(key_u, R * AZ_NSUB);
     A(choff_pair, R); A(crow, CH > 8192 ? CH : 8192);
     A(pred_v, R * AZ_NSUB * 4); A(score_v, R * AZ_NSUB); A(zoom_v, R); A(keep_v, R * AZ_NSUB); A(key_v, R * AZ_NSUB);
+    A(pred_w, R * AZ_NSUB * 4); A(score_w, R * AZ_NSUB); A(zoom_w, R); A(keep_w, R * AZ_NSUB); A(key_w, R * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
@@ -405,9 +416,12 @@ int ev_grow(az_ctx *c, int i, void **slot, size_t bytes)
 
 void free_plan(az_ctx::StaticPlan *q)
 {
-    for (void *p : {(void *)q->urois, (void *)q->ubox, (void *)q->reg_u, (void *)q->cand_src, (void *)q->meta})
+    for (void *p : {(void *)q->urois, (void *)q->ubox, (void *)q->reg_u, (void *)q->cand_src, (void *)q->meta,
+                    (void *)q->htab, (void *)q->spec_map, (void *)q->full_meta, (void *)q->full_urois, (void *)q->full_ubox})
         if (p) hipFree(p);
     q->urois = nullptr; q->ubox = nullptr; q->reg_u = nullptr; q->cand_src = nullptr; q->meta = nullptr;
+    q->htab = nullptr; q->spec_map = nullptr; q->full_meta = nullptr; q->full_urois = nullptr; q->full_ubox = nullptr;
+    q->full_state = 0;
 }
 
 int check_geom(az_ctx *c)
@@ -655,7 +669,7 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
 }
 
 // Which form of the search a call takes.
-struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; };
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; bool full; };
 
 // Cost model of one head pass on the int6 GEMM (us), from the measured launch shapes (profiles/): weight-streaming
 // bound up to ~40 rows, then ~1.45 us per row; and what a head pass costs besides int6 (RoIPool, reduce, int7, heads,
@@ -669,6 +683,7 @@ static double pass_us(double rows, int parts = 0)
     return t < 92.0 ? 92.0 : t;
 }
 constexpr double PASS_OVERHEAD_US = 90.0, LOOKUP_US = 8.0;
+constexpr unsigned AZ_TAB_ROOT_HOST = 0x1FFFu;      // (az_geom_dev.h: AZ_TAB_ROOT)
 
 // Pair speculation: the head pass of level l also evaluates one row per distinct RoIPool window among ALL children of
 // its regions, so that level l+1 needs no pass of its own (az_level.hip).  Worth it when most regions zoom: the extra
@@ -701,6 +716,8 @@ static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool f
     return mask;
 }
 
+static bool plan_is_for(const az_ctx::StaticPlan &k, const az_params *p, int nlev);
+
 static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune)
 {
     SearchPlan q;
@@ -727,6 +744,11 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     for (const auto &e : c->lv_limits)
         if (e.h == p->im_h && e.w == p->im_w) q.lv_limit = e.limit;
     q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv, q.lv_limit);
+    // whole-tree speculation (decided and prepared by az_propose_launch: full_prepare): one head pass over the rows of
+    // the image shape's full tree, every level's outputs by window lookup -- no deferred root, no pair rows
+    q.full = c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit > nlev && c->plan &&
+             c->plan->full_state == 1 && plan_is_for(*c->plan, p, nlev);
+    if (q.full) { q.defer_root = false; q.pair_mask = 0; }
     return q;
 }
 
@@ -890,6 +912,88 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
     return AZ_OK;
 }
 
+// Whole-tree speculation: should this search evaluate the rows of the image shape's FULL tree in one head pass and find
+// every level's outputs by window lookup?  It pays when the tree the context saw last for this shape is dense: the
+// level-by-level forms stream the int6 weights once per pass and pay each pass's fixed cost (RoIPool, reduce, int7, heads,
+// a geometry kernel), the whole-tree pass pays the rows the tree does not have.  Builds what the form needs (the shape's
+// plan, the non-deferred speculative pre-pass, the window table, the row map) outside any graph capture; sets
+// c->full_now.  params.reserved bit 8: never, bit 9: whenever the shape allows (tests); AZ_FULL_SPEC=0 / 2 likewise.
+static int full_prepare(az_ctx *c, const az_params *p, int nlev, bool tune)
+{
+    c->full_now = false;
+    if (tune || (p->reserved & (1 | 2 | 16 | 256)) || !p->fixed_num) return AZ_OK;
+    if (c->full_env < 0) { const char *e = getenv("AZ_FULL_SPEC"); c->full_env = e ? atoi(e) : 1; }
+    const bool forced = (p->reserved & 512) || c->full_env == 2;
+    if (!forced && c->full_env == 0) return AZ_OK;
+    const SearchPlan q0 = plan_search(c, p, nlev, tune);        // (full_now is false: the other form's plan)
+    if (!(q0.fused && q0.fused_lv && q0.n_spec == 3 && q0.lv_limit > nlev && nlev > q0.n_spec)) return AZ_OK;
+    // By history: only when the previous search of this image shape walked the FULL tree (every region zoomed at every
+    // level but the last).  A pruned tree may keep another _sift_dup survivor than the full tree does (same 10-px hash,
+    // other coordinates, other RoIPool window): such a window is not among the pass's rows and the search has to be
+    // repeated level by level -- the closure over all survivor choices would be 773 rows instead of 688 at 600x1000.
+    bool have_hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
+    for (int l = 0; have_hist && l + 1 < nlev; ++l) have_hist = c->hint_P[l] > 0 && c->hint_PZ[l] == c->hint_P[l];
+    if (!forced && !have_hist) return AZ_OK;
+    int rc;
+    if ((rc = ensure_static_plan(c, p, nlev)) != AZ_OK) return rc;
+    if (!static_plan_matches(c, p, nlev)) return AZ_OK;
+    az_ctx::StaticPlan &k = *c->plan;
+    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: full_prepare (%dx%d) plan state %d\n", p->im_h, p->im_w, k.full_state);
+    if (k.full_state < 0) return AZ_OK;
+    // the non-deferred layout of the speculative rows (the root is row 0 there; here it maps to the pass's last row)
+    SearchPlan q1 = q0; q1.defer_root = false;
+    if ((rc = ensure_spec_cache(c, p, q1)) != AZ_OK) return rc;
+    const auto &sp = c->spc[0];
+    if (!(sp.h == p->im_h && sp.w == p->im_w && sp.scale == p->scale && sp.min_side == p->min_side)) return AZ_OK;
+    if (k.full_state == 0) {
+        hipStream_t s = c->stream;
+        const int cap = k.Utot + sp.U + 1;
+        unsigned T = 64; while (T < 2u * (unsigned)cap) T <<= 1;
+        auto grab = [&](void **q, size_t bytes) { return hipMalloc(q, bytes + 256) == hipSuccess; };
+        if (cap > c->maxR || cap >= (int)AZ_TAB_ROOT_HOST || sp.U > 64 ||
+            !grab((void **)&k.htab, (size_t)T * 8) || !grab((void **)&k.spec_map, (size_t)sp.U * sizeof(int)) ||
+            !grab((void **)&k.full_meta, 16) || !grab((void **)&k.full_urois, (size_t)cap * 5 * sizeof(float)) ||
+            !grab((void **)&k.full_ubox, (size_t)cap * 4 * sizeof(double))) {
+            (void)hipGetLastError();
+            k.full_state = -1;
+            return AZ_OK;
+        }
+        k.hT = T;
+        const int root = k.Utot - 1;                   // the plan's last row
+        HIPCHK(c, hipMemsetAsync(k.full_meta, 0, 16, s));
+        HIPCHK(c, hipMemcpyAsync(k.full_urois, k.urois, (size_t)root * 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(k.full_ubox, k.ubox, (size_t)root * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        azk_full_tab_build(s, k.urois, k.Utot, root, c->spatial_scale, k.htab, T, k.full_meta + 2);
+        azk_full_map(s, c->spec_urois[0], sp.U, c->spatial_scale, k.htab, T, root, cap, k.full_urois, k.full_ubox, k.spec_map,
+                     k.full_meta + 1, k.full_meta + 2);
+        int h[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpyAsync(h, k.full_meta, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h[2]) { k.full_state = -1; return AZ_OK; }
+        k.Ufull = root + h[1] + 1;
+        // the root: the pass's last row (RoIPool treats the tail of a launch cooperatively)
+        HIPCHK(c, hipMemcpyAsync(k.full_urois + (size_t)(k.Ufull - 1) * 5, k.urois + (size_t)root * 5, 5 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(k.full_ubox + (size_t)(k.Ufull - 1) * 4, k.ubox + (size_t)root * 4, 4 * sizeof(double),
+                                 hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(k.full_meta, &k.Ufull, sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        k.full_state = 1;
+    }
+    if (!forced) {
+        // the previous search of this shape: rows of the levels behind the speculative ones, passes they would take
+        int later = 0, lv = 0;
+        for (int l = q0.n_spec; l < nlev; ++l) { later += c->hint_U[l]; lv += c->hint_U[l] > 0; }
+        const double now = pass_us(sp.U, c->gemm_parts) + PASS_OVERHEAD_US +
+                           (lv ? pass_us(later, c->gemm_parts) + ((lv + 1) / 2) * PASS_OVERHEAD_US + LOOKUP_US : 0.0);
+        const double full = pass_us(k.Ufull, c->gemm_parts) + PASS_OVERHEAD_US + LOOKUP_US * (nlev - q0.n_spec);
+        if (!(full + 10.0 < now)) return AZ_OK;
+    }
+    c->full_now = true;
+    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: whole-tree pass on (%dx%d): %d rows (plan %d)\n", p->im_h, p->im_w, k.Ufull, k.Utot);
+    return AZ_OK;
+}
+
 static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 {
     const auto &q = *c->plan;
@@ -959,7 +1063,21 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                    c->choff_all, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
         azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
     }
-    if (fused)
+    const bool full = plan.full;
+    const az_ctx::StaticPlan *fp = full ? c->plan : nullptr;
+    // (whole-tree speculation: the *_v sets alternate by level -- a level's geometry kernel reads its own set while it
+    //  writes the next level's)
+    auto Vp = [&](int l) { return (full && (l & 1)) ? c->pred_w : c->pred_v; };
+    auto Vs = [&](int l) { return (full && (l & 1)) ? c->score_w : c->score_v; };
+    auto Vz = [&](int l) { return (full && (l & 1)) ? c->zoom_w : c->zoom_v; };
+    auto Vk = [&](int l) { return (full && (l & 1)) ? c->keep_w : c->keep_v; };
+    auto Vy = [&](int l) { return (full && (l & 1)) ? c->key_w : c->key_v; };
+    if (full)
+        // the search's ONE head pass: the unique rois of the image shape's full tree (+ the speculative rows the plan
+        // lacks), the root last; outputs by row in zoom_s / score_s / delta_s
+        launch_head(c, fp->full_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 1,
+                    fp->full_urois, fp->full_ubox, fp->Ufull);
+    else if (fused)
         launch_head(c, c->spec_U[defer_root ? 1 : 0], -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
                     0, c->spec_urois[defer_root ? 1 : 0], nullptr, c->spc[defer_root ? 1 : 0].U);
     else if (n_spec)
@@ -982,16 +1100,19 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0; a.defer_root = defer_root ? 1 : 0;
         a.spec_next = (plan.pair_mask >> n_spec) & 1; a.choff_next = c->choff_pair; a.crow = c->crow;
         a.spatial_scale = c->spatial_scale;
+        a.row_map = full ? fp->spec_map : nullptr; a.root_row = full ? fp->Ufull - 1 : 0;
+        a.stab = full ? fp->htab : nullptr; a.stabT = full ? fp->hT : 0;
+        a.pred_v = Vp(n_spec); a.score_v = Vs(n_spec); a.zoom_v = Vz(n_spec); a.keep_v = Vk(n_spec); a.key_v = Vy(n_spec);
         azk_spec_levels(s, a);
     }
-    bool have_v = false;              // this level's head outputs were looked up among the previous pass's rows (*_v arrays)
+    bool have_v = full;               // this level's head outputs were looked up among the previous pass's rows (*_v arrays)
     for (int l = fused ? n_spec : 0; l < nlev; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
         // (the last level's copy + top-k stay chip-wide; from plan.lv_limit on the levels outgrow the fused kernel)
         const bool lv_here = fused_lv && l + 1 < nlev && l < plan.lv_limit;
-        const bool pair_here = fused_lv && ((plan.pair_mask >> l) & 1) && !have_v;   // this pass carries level l+1's rows
+        const bool pair_here = !full && fused_lv && ((plan.pair_mask >> l) & 1) && !have_v;   // this pass carries level l+1's rows
         if (lv_here) {
             // this level's rois were projected and deduplicated by the previous geometry kernel, which also left the
             // pass's row count (its unique rois + pair-speculation rows + the deferred root's) in cnt->PR[l]
@@ -1003,20 +1124,22 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             AzLevelArgs a;
             a.cnt = c->cnt; a.level = l; a.nlev = nlev;
             a.B = c->B[cur]; a.Bnext = c->B[cur ^ 1];
-            a.pred_u = have_v ? c->pred_v : c->pred_u; a.score_u = have_v ? c->score_v : c->score_u;
-            a.zoom_u = have_v ? c->zoom_v : c->zoom_u; a.keep_u = have_v ? c->keep_v : c->keep_u; a.Uptr = Uptr;
+            a.pred_u = have_v ? Vp(l) : c->pred_u; a.score_u = have_v ? Vs(l) : c->score_u;
+            a.zoom_u = have_v ? Vz(l) : c->zoom_u; a.keep_u = have_v ? Vk(l) : c->keep_u; a.Uptr = Uptr;
             a.urois = c->urois; a.index = c->index; a.inv = c->inv; a.ubox = c->ubox;
             a.Yall = c->Yall; a.Sall = c->Sall;
             a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
             a.batch = p->batch_size; a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
             a.force_root = 1; a.root_row = (defer_root && l == n_spec && !have_v) ? 1 : 0;
-            a.lookup_next = pair_here ? 1 : 0;
-            a.spec_next = (!pair_here && ((plan.pair_mask >> (l + 1)) & 1)) ? 1 : 0;
-            a.delta_u = c->delta_u; a.choff_all = c->choff_pair; a.choff_next = c->choff_pair; a.crow = c->crow;
-            a.pred_v = c->pred_v; a.score_v = c->score_v; a.zoom_v = c->zoom_v; a.keep_v = c->keep_v; a.key_v = c->key_v;
+            a.lookup_next = full ? 2 : (pair_here ? 1 : 0);
+            a.spec_next = (!full && !pair_here && ((plan.pair_mask >> (l + 1)) & 1)) ? 1 : 0;
+            a.delta_u = full ? c->delta_s : c->delta_u; a.choff_all = c->choff_pair; a.choff_next = c->choff_pair; a.crow = c->crow;
+            a.stab = full ? fp->htab : nullptr; a.stabT = full ? fp->hT : 0; a.root_row_full = full ? fp->Ufull - 1 : 0;
+            a.score_all = c->score_s; a.zoom_all = c->zoom_s;
+            a.pred_v = Vp(l + 1); a.score_v = Vs(l + 1); a.zoom_v = Vz(l + 1); a.keep_v = Vk(l + 1); a.key_v = Vy(l + 1);
             a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = c->spatial_scale;
             azk_level_geom(s, a);
-            have_v = pair_here;
+            have_v = full || pair_here;
             continue;
         }
         if (!fused_lv || l > plan.lv_limit) {   // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
@@ -1040,9 +1163,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         if (final_fused) {
             Timed t(c, "final_select", l);
             AzFinalArgs a;
-            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = have_v ? c->key_v : c->key_u;
-            a.pred_u = have_v ? c->pred_v : c->pred_u;
-            a.score_u = have_v ? c->score_v : c->score_u; a.zoom_u = have_v ? c->zoom_v : c->zoom_u;
+            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = have_v ? Vy(l) : c->key_u;
+            a.pred_u = have_v ? Vp(l) : c->pred_u;
+            a.score_u = have_v ? Vs(l) : c->score_u; a.zoom_u = have_v ? Vz(l) : c->zoom_u;
             a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
             a.force_root = (l == 0) ? 1 : 0; a.capCand = c->maxCand; a.k = k;
             a.Yout = (double *)((unsigned char *)c->cnt + RES_HDR);
@@ -1056,9 +1179,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                                &c->cnt->nhis, &c->cnt->err);
         }
         { Timed t(c, "flags_compact", l);
-          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, have_v ? c->pred_v : c->pred_u,
-                            have_v ? c->score_v : c->score_u,
-                            have_v ? c->zoom_v : c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
+          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, have_v ? Vp(l) : c->pred_u,
+                            have_v ? Vs(l) : c->score_u,
+                            have_v ? Vz(l) : c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
                             c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z, c->zr); }
         if (l + 1 < nlev) {      // the reference also divides after the last level but never uses it
             const bool track = (n_spec && l == 1);       // level-3 regions remember their speculative row
@@ -1115,6 +1238,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         stat = static_plan_matches(c, p, nlev);          // (a tree that outgrows the plan buffers: level loop)
     }
     c->last_static = stat ? 1 : 0;
+    c->full_now = false;
+    if (!stat && (rc = full_prepare(c, p, nlev, tune)) != AZ_OK) return rc;
+    c->last_full = (!stat && plan_search(c, p, nlev, tune).full) ? 1 : 0;
     if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
@@ -1143,8 +1269,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         key.append((const char *)&c->last_static, sizeof(int));
         key.append((const char *)&c->last_pair_mask, sizeof(int));
         key.append((const char *)&c->last_defer, sizeof(int));
+        key.append((const char *)&c->last_full, sizeof(int));
         for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
-        const void *pp = stat ? (const void *)c->plan : nullptr;
+        const void *pp = (stat || c->last_full) ? (const void *)c->plan : nullptr;
         key.append((const char *)&pp, sizeof(pp));
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
@@ -1307,6 +1434,14 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
         c->nopair.emplace_back(q.p.im_h, q.p.im_w);
         az_params p2 = q.p;
         p2.reserved = (p2.reserved | 64) & ~128;
+        return rerun(p2);
+    }
+    if ((h.err & 256) && !(q.p.reserved & 256)) {
+        // the whole-tree pass did not hold a window this search needed (a _sift_dup survivor other than the full tree's):
+        // repeat it level by level; its history then says "pruned tree" and the next search of the shape goes that way at once
+        if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: whole-tree pass missed a window (%dx%d, err %d)\n", q.p.im_h, q.p.im_w, h.err);
+        az_params p2 = q.p;
+        p2.reserved = (p2.reserved | 256) & ~512;
         return rerun(p2);
     }
     if ((h.err & 8) && !(q.p.reserved & 2)) {

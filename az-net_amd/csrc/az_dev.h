@@ -152,6 +152,11 @@ struct AzFinalArgs {
 void azk_final_select(hipStream_t s, const AzFinalArgs &a);
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u);
 void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src);
+// whole-tree speculation: window table over a plan's rows (root_row gets the marker row), map of the speculative rows
+void azk_full_tab_build(hipStream_t s, const float *urois, int n_rows, int root_row, float ss, unsigned long long *tab,
+                        unsigned T, int *err);
+void azk_full_map(hipStream_t s, const float *spec_urois, int n_spec, float ss, const unsigned long long *tab, unsigned T,
+                  int base_extra, int cap_rows, float *urois_full, double *ubox_full, int *map, int *n_extra, int *err);
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);
 // candidates + final top-k in one launch (fixed proposal count); false: the tree is too large for it
 bool azk_static_select(hipStream_t s, const AzStaticArgs &a);
@@ -176,6 +181,12 @@ struct AzFusedArgs {
     double scale, Tz, min_side, eps;
     float dedup;
     int batch, im_h, im_w, nlev, n_fused, capR, capCh, capCand;
+    // whole-tree speculation (stab != nullptr): zoom_s / score_s / delta_s are the outputs of the whole-tree pass, row i of
+    // the speculative layout is row row_map[i] there, and the first level after the fused ones gets its outputs by window
+    // lookup here (into the *_v arrays) instead of a head pass
+    const int *row_map; int root_row;
+    const unsigned long long *stab; unsigned stabT;
+    double *pred_v; float *score_v, *zoom_v; unsigned char *keep_v; unsigned *key_v;
 };
 
 // (also clears the counters and writes the root region: it is the first kernel of a fused search)
@@ -200,7 +211,9 @@ struct AzLevelArgs {
     // pair speculation (az_capi.hip): this level's head pass also evaluated rows for all children of its regions
     // (lookup_next) -> level l+1's outputs are looked up and decoded here into the *_v arrays instead of a head pass;
     // or the NEXT level's pass shall carry such rows (spec_next): they are appended behind its unique rois here
-    int lookup_next, spec_next;
+    int lookup_next, spec_next;    // lookup_next = 2: by RoIPool window in the whole-tree pass (stab), not among pair rows
+    const unsigned long long *stab; unsigned stabT; int root_row_full;
+    const float *score_all, *zoom_all;   // (lookup_next = 2) outputs of the whole-tree pass (delta_u: its raw deltas)
     const float *delta_u;          // raw box deltas of this level's pass (lookup_next)
     const int *choff_all;          // (lookup_next) written by the previous geometry kernel; (spec_next) written here
     int *choff_next, *crow;        // all-children offsets of the next level's regions; child -> spec row (read / written)

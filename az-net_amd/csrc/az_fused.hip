@@ -200,10 +200,25 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     const int specU_h = a.reset ? a.specU : cnt->specU;
     const int P1spec = a.reset ? a.specP1 : cnt->specP1;
     const bool pre = specU_h <= SPEC_PRE && P1spec <= SPEC_PRE;
+    if (a.stab && !pre) { if (tid == 0) atomicOr(&cnt->err, 8 | 256); return; }       // (whole-tree pass: rows come through the map)
     if (pre) {
-        for (int i = tid; i < specU_h; i += NTL) s_zs[i] = a.zoom_s[i];
-        for (int i = tid; i < specU_h * AZ_NSUB; i += NTL) s_ss[i] = a.score_s[i];
-        for (int i = tid; i < specU_h * 4 * AZ_NSUB; i += NTL) s_ds[i] = a.delta_s[i];
+        if (a.stab) {
+            // whole-tree speculation: row i of the speculative layout is row row_map[i] of the one pass
+            auto rowof = [&](int i) { const int m = a.row_map[i]; return m == (int)AZ_TAB_ROOT ? a.root_row : m; };
+            for (int i = tid; i < specU_h; i += NTL) s_zs[i] = a.zoom_s[rowof(i)];
+            for (int i = tid; i < specU_h * AZ_NSUB; i += NTL) {
+                const int r = i / AZ_NSUB;
+                s_ss[i] = a.score_s[(size_t)rowof(r) * AZ_NSUB + (i - r * AZ_NSUB)];
+            }
+            for (int i = tid; i < specU_h * 4 * AZ_NSUB; i += NTL) {
+                const int r = i / (4 * AZ_NSUB);
+                s_ds[i] = a.delta_s[(size_t)rowof(r) * 4 * AZ_NSUB + (i - r * 4 * AZ_NSUB)];
+            }
+        } else {
+            for (int i = tid; i < specU_h; i += NTL) s_zs[i] = a.zoom_s[i];
+            for (int i = tid; i < specU_h * AZ_NSUB; i += NTL) s_ss[i] = a.score_s[i];
+            for (int i = tid; i < specU_h * 4 * AZ_NSUB; i += NTL) s_ds[i] = a.delta_s[i];
+        }
         for (int i = tid; i < P1spec; i += NTL) s_choff[i] = a.choff_all[i];
     }
     // (deferred root: level 2's regions are the pre-pass's B1 -- same round trip)
@@ -381,7 +396,41 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         if (P > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path
         __syncthreads();
         const int U = roi_dedup_sorted(sB[nxt], P, a.scale, a.dedup, ssort, ssort + FL_R, sbins, smm, wsum, nullptr,
-                                       a.index, a.inv, a.urois, a.ubox);
+                                       a.index, a.inv, a.urois, a.ubox, sidx);
+        if (a.stab) {
+            // whole-tree speculation: that level's head outputs by RoIPool window among the rows of the one pass (what
+            // k_level_geom's lookup stage does for the levels after it): raw deltas decoded against the representative's own
+            // box, scores / zoom copied -- what the tail kernel would have written for that roi, bit for bit
+            __syncthreads();
+            int miss = 0;
+            for (int i = tid; i < U * AZ_NSUB; i += NTL) {
+                const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+                const double *bx0 = sB[nxt] + 4 * sidx[slot];
+                float roi5[5];
+                roi5[0] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(bx0[q] * a.scale);
+                const int row = az_tab_lookup(a.stab, a.stabT, roi5, a.spatial_scale, a.root_row);
+                if (row < 0) { miss = 1; continue; }
+                float d4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d4[q] = a.delta_s[(size_t)row * 4 * AZ_NSUB + 4 * sub + q];
+                double bx[4];
+                az_decode_box(bx0, d4, a.im_h, a.im_w, a.eps, bx);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a.pred_v[(size_t)i * 4 + q] = bx[q];
+                const float sc = a.score_s[(size_t)row * AZ_NSUB + sub];
+                a.score_v[i] = sc;
+                const bool kp = cand_keep(bx, a.min_side);
+                a.keep_v[i] = kp ? 1 : 0;
+                const unsigned kk = score_key(sc);
+                a.key_v[i] = kp ? (kk ? kk : 1u) : 0u;
+                if (sub == 0) a.zoom_v[slot] = a.zoom_s[row];
+            }
+            if (miss) atomicOr(&cnt->err, 8 | 256);
+            if (tid == 0) { cnt->U[a.n_fused] = U; cnt->SPB[a.n_fused] = U; cnt->SPN[a.n_fused] = 0; cnt->PR[a.n_fused] = 0; }
+            return;
+        }
 #ifdef AZ_SPEC_TIMING
         __syncthreads();
         if (tid == 0) printf("closing: handover + roi dedup %llu (x10ns)\n", wall_clock64() - tc0);

@@ -311,6 +311,31 @@ static __device__ __forceinline__ bool pool_key(const float *roi5, float ss, uns
     return ok;
 }
 
+// Whole-tree speculation (az_capi.hip: SearchPlan::full): ONE head pass evaluates the unique rois of the image shape's full
+// tree (the one-pass plan's rows); a search with any Tz then finds a region's head outputs by its RoIPool window in a
+// table built once per shape: open addressing in global memory, word = (window key << 13) | row, EMPTY = ~0.
+// Row AZ_TAB_ROOT stands for the root's row (the last row of the pass, wherever the extra rows push it).
+constexpr unsigned AZ_TAB_ROOT = 0x1FFFu;
+static __device__ __forceinline__ unsigned az_tab_hash(unsigned long long key, unsigned T)
+{
+    return (unsigned)((((key * 0x9E3779B97F4A7C15ull) >> 32) * (unsigned long long)T) >> 32);
+}
+// -1: the window is not in the table
+static __device__ __forceinline__ int az_tab_lookup(const unsigned long long *tab, unsigned T, const float *roi5, float ss,
+                                                    int root_row)
+{
+    unsigned long long key;
+    if (!pool_key(roi5, ss, &key)) return -1;
+    unsigned slot = az_tab_hash(key, T);
+    for (unsigned probes = 0; probes < T; ++probes) {
+        const unsigned long long w = tab[slot];
+        if (w == ~0ull) return -1;
+        if ((w >> 13) == key) { const unsigned r = (unsigned)(w & 0x1FFFu); return r == AZ_TAB_ROOT ? root_row : (int)r; }
+        slot = slot + 1 == T ? 0u : slot + 1;
+    }
+    return -1;
+}
+
 // one child's box without its _sift_dup hash (the hash costs four f64 divisions nobody needs here)
 static __device__ __forceinline__ void div_child_box(const double *r, const DivPlan &p, int bi, double *c)
 {

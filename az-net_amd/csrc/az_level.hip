@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
                 for (int q = 0; q < 4; ++q) { sBn[4 * slot + q] = c[q]; a.Bnext[4 * (size_t)slot + q] = c[q]; }
                 // which child of which region of THIS level it is, as an index into the all-children list the previous
                 // geometry kernel laid out: finds the region's row among this level's pair-speculation rows
-                if (a.lookup_next) sprov[slot] = a.choff_all[szr[ci >> 16]] + (ci & 0xFFFF);
+                if (a.lookup_next == 1) sprov[slot] = a.choff_all[szr[ci >> 16]] + (ci & 0xFFFF);
             }
         }
         Pn += tot;
@@ -289,7 +289,38 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     if (tid == 0) cnt->U[l + 1] = Un;
     __syncthreads();
     TSTAMP();
-    if (a.lookup_next) {
+    if (a.lookup_next == 2) {
+        // ---- whole-tree speculation: level l+1's head outputs by RoIPool window among the rows of the search's one head
+        //      pass (the full tree of this image shape; table built once per shape, az_static.hip).  Same arithmetic as
+        //      the pair-row lookup below; a window the table does not hold sends the search back to the other form.
+        int miss = 0;
+        for (int i = tid; i < Un * AZ_NSUB; i += NT) {
+            const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+            const int rpos = sidx[slot];
+            float roi5[5];
+            roi5[0] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(sBn[4 * rpos + q] * a.scale);
+            const int row = az_tab_lookup(a.stab, a.stabT, roi5, a.spatial_scale, a.root_row_full);
+            if (row < 0) { miss = 1; continue; }
+            float d4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d4[q] = a.delta_u[(size_t)row * 4 * AZ_NSUB + 4 * sub + q];
+            double bx[4];
+            az_decode_box(sBn + 4 * rpos, d4, a.im_h, a.im_w, a.eps, bx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a.pred_v[(size_t)i * 4 + q] = bx[q];
+            const float sc = a.score_all[(size_t)row * AZ_NSUB + sub];
+            a.score_v[i] = sc;
+            const bool kp = cand_keep(bx, a.min_side);
+            a.keep_v[i] = kp ? 1 : 0;
+            const unsigned kk = score_key(sc);
+            a.key_v[i] = kp ? (kk ? kk : 1u) : 0u;
+            if (sub == 0) a.zoom_v[slot] = a.zoom_all[row];
+        }
+        if (miss) atomicOr(&cnt->err, 8 | 256);
+        if (tid == 0) { cnt->PR[l + 1] = 0; cnt->SPB[l + 1] = Un; cnt->SPN[l + 1] = 0; }
+    } else if (a.lookup_next) {
         // ---- level l+1's head outputs without a head pass: every one of its regions is a child of a region of this
         //      level, and this level's pass evaluated one row per distinct RoIPool window among all such children
         //      (az_geom_dev.h: spec_children_rows).  For each unique roi of level l+1: the row of its REPRESENTATIVE

@@ -419,3 +419,60 @@ void azk_static_candidates(hipStream_t s, const AzStaticArgs &a)
     const int nb = (Nv + SC_NT - 1) / SC_NT;
     k_static_candidates<<<dim3(nb + 1), dim3(SC_NT), 0, s>>>(a, nb);
 }
+
+// ---- whole-tree speculation: the window table of an image shape's plan rows, and the speculative rows' map ----------
+namespace {
+__global__ void k_full_tab_build(const float *__restrict__ urois, int n_rows, int root_row, float ss,
+                                 unsigned long long *tab, unsigned T, int *err)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    unsigned long long key;
+    if (!pool_key(urois + 5 * (size_t)r, ss, &key)) { atomicOr(err, 1); return; }
+    const unsigned long long word = (key << 13) | (unsigned)(r == root_row ? AZ_TAB_ROOT : (unsigned)r);
+    unsigned slot = az_tab_hash(key, T);
+    for (;;) {
+        unsigned long long old = tab[slot];
+        if (old == ~0ull) {
+            old = atomicCAS(&tab[slot], ~0ull, word);
+            if (old == ~0ull) return;
+        }
+        if ((old >> 13) == key) { atomicMin(&tab[slot], word); return; }       // (same window twice: either row will do)
+        slot = slot + 1 == T ? 0u : slot + 1;
+    }
+}
+
+// every row of the speculative pass (levels 1-3) -> its row in the whole-tree pass; a window the plan does not hold (a
+// _sift_dup duplicate with other coordinates than the survivor) becomes an extra row behind the plan's non-root rows
+__global__ void k_full_map(const float *__restrict__ spec_urois, int n_spec, float ss, const unsigned long long *tab,
+                           unsigned T, int base_extra, int cap_rows, float *urois_full, double *ubox_full, int *map,
+                           int *n_extra, int *err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_spec) return;
+    const float *roi = spec_urois + 5 * (size_t)i;
+    int row = az_tab_lookup(tab, T, roi, ss, (int)AZ_TAB_ROOT);
+    if (row < 0) {
+        const int e = atomicAdd(n_extra, 1);
+        row = base_extra + e;
+        if (row + 1 >= cap_rows) { atomicOr(err, 1); map[i] = 0; return; }
+        for (int q = 0; q < 5; ++q) urois_full[5 * (size_t)row + q] = roi[q];
+        for (int q = 0; q < 4; ++q) ubox_full[4 * (size_t)row + q] = 0.0;          // (decoded boxes of these rows are never read)
+    }
+    map[i] = row;
+}
+}  // namespace
+
+void azk_full_tab_build(hipStream_t s, const float *urois, int n_rows, int root_row, float ss, unsigned long long *tab,
+                        unsigned T, int *err)
+{
+    hipMemsetAsync(tab, 0xFF, (size_t)T * sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(k_full_tab_build, dim3((n_rows + 255) / 256), dim3(256), 0, s, urois, n_rows, root_row, ss, tab, T, err);
+}
+
+void azk_full_map(hipStream_t s, const float *spec_urois, int n_spec, float ss, const unsigned long long *tab, unsigned T,
+                  int base_extra, int cap_rows, float *urois_full, double *ubox_full, int *map, int *n_extra, int *err)
+{
+    hipLaunchKernelGGL(k_full_map, dim3((n_spec + 255) / 256), dim3(256), 0, s, spec_urois, n_spec, ss, tab, T, base_extra,
+                       cap_rows, urois_full, ubox_full, map, n_extra, err);
+}

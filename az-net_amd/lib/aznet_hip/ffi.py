@@ -268,7 +268,7 @@ class AzContext(object):
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
                     dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True,
-                    tune=False, radix_select=False, fused_levels=True, static_tree=True, pair_spec=None):
+                    tune=False, radix_select=False, fused_levels=True, static_tree=True, pair_spec=None, full_spec=None):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
         slower); fused=False keeps the geometry of those levels as separate launches;
         fused_levels=False does the same for the levels after them (az_level.hip).  All
@@ -279,13 +279,17 @@ class AzContext(object):
         walk the tree level by level instead of forwarding all levels' rois in one head pass (same bits).
         pair_spec: None = let the context decide from its previous search whether a level's head pass also carries the
         rows of ALL children of its regions (so that the next level needs no pass); False = never; True = at every
-        eligible level (same bits in all three)."""
+        eligible level (same bits in all three).
+        full_spec: None = let the context decide from its previous search of this image shape whether the search's ONE
+        head pass evaluates the rows of the shape's full tree, every level finding its outputs by RoIPool window (pays
+        for dense trees); False = never; True = whenever the shape allows (same bits in all three)."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
                         1 if fixed_num else 0,
                         (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0) |
                         (8 if radix_select else 0) | (0 if fused_levels else 16) | (0 if static_tree else 32) |
-                        (0 if pair_spec is None else (128 if pair_spec else 64)))
+                        (0 if pair_spec is None else (128 if pair_spec else 64)) |
+                        (0 if full_spec is None else (512 if full_spec else 256)))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates

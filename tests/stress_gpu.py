@@ -75,6 +75,20 @@ def run_case(net, case):
         return False, desc, "pair-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d passes %s" % (
             np.array_equal(c[0], b[0]), np.array_equal(c[1], b[1]), np.array_equal(Yc, Yb), np.array_equal(Sc, Sb),
             c[2].num_eval, b[2].num_eval, list(c[2].pass_rows[:c[2].n_passes]))
+    # whole-tree speculation forced (one head pass over the image shape's full tree, outputs by window lookup; a pruned tree
+    # that needs a window the pass lacks is repeated level by level): same bits either way
+    if fixed:
+        pf = ffi.AzContext.make_params(H, W, scale, Tz, full_spec=True, **kw)
+        e = net.propose(pf, want_scores=True, want_stats=True)
+        Ye, Se = net.ctx.last_candidates()
+        ok = (np.array_equal(e[0], b[0]) and np.array_equal(e[1], b[1]) and np.array_equal(Ye, Yb) and
+              np.array_equal(Se, Sb) and e[2].num_eval == b[2].num_eval and e[2].depth == b[2].depth and
+              list(e[2].level_unique) == list(b[2].level_unique) and list(e[2].level_zoomed) == list(b[2].level_zoomed))
+        if not ok:
+            return False, desc, "whole-tree-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d passes %s" % (
+                np.array_equal(e[0], b[0]), np.array_equal(e[1], b[1]), np.array_equal(Ye, Yb), np.array_equal(Se, Sb),
+                e[2].num_eval, b[2].num_eval, list(e[2].pass_rows[:e[2].n_passes]))
+        desc += " wt-passes %d" % e[2].n_passes
     if fixed:
         net.ctx.propose_launch(ffi.AzContext.make_params(H, W, scale, Tz, **kw))
         net.ctx.propose_launch(pp)

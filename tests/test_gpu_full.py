@@ -1,0 +1,134 @@
+"""Whole-tree speculation in the level loop (az_capi.hip: full_prepare, az_static.hip: window table, az_fused.hip /
+az_level.hip: lookup stages) vs the plain level loop -- identical bits.
+
+For a dense tree the search's ONE head pass evaluates the unique rois of the image shape's FULL tree (the one-pass plan's
+rows, plus the speculative rows whose window the plan lacks); every level then finds its regions' head outputs by
+RoIPool window (a roi's outputs are a function of its pooled window only) and decodes them against its own boxes.
+Valid for any Tz: a pruned tree may keep another _sift_dup survivor than the full tree (same 10-px hash, other
+coordinates, other window); a search that needs a window the pass did not evaluate is repeated level by level.
+Everything observable must equal the search without it, and the full-size search must equal the pure-CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    from oracle import az_oracle as orc
+    return ffi, synth, HipAZNet, orc
+
+
+@pytest.fixture(scope="module")
+def small(mods):
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    return HipAZNet(head, name="small_full"), head
+
+
+def _scale(H, W):
+    scale = 600.0 / min(H, W)
+    if np.round(scale * max(H, W)) > 1000:
+        scale = 1000.0 / max(H, W)
+    return scale
+
+
+def _run(net, ffi, H, W, scale, Tz, full, **kw):
+    Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, static_tree=False, full_spec=full, **kw),
+                           want_scores=True, want_stats=True)
+    Ya, Sa = net.ctx.last_candidates()
+    return dict(Y=Y, S=S, Ya=Ya, Sa=Sa, st=st)
+
+
+def _same(a, b):
+    for k in ("Y", "S", "Ya", "Sa"):
+        assert a[k].shape == b[k].shape, k
+        assert np.array_equal(a[k], b[k]), k
+    sa, sb = a["st"], b["st"]
+    for f in ("n_proposals", "num_eval", "depth", "n_levels", "n_candidates"):
+        assert getattr(sa, f) == getattr(sb, f), f
+    for f in ("level_regions", "level_unique", "level_zoomed"):
+        assert list(getattr(sa, f)) == list(getattr(sb, f)), f
+
+
+def _zooms(net, ffi, H, W, scale):
+    net.propose(ffi.AzContext.make_params(H, W, scale, 0.0, tune=True))
+    return np.sort(net.ctx.last_anchors()[1].astype(np.float64))
+
+
+SHAPES = [(600, 1000), (375, 500), (480, 640), (500, 353), (333, 500), (720, 1280), (600, 600), (420, 1000)]
+
+
+@pytest.mark.parametrize("H,W", SHAPES, ids=["%dx%d" % s for s in SHAPES])
+def test_forced_whole_tree_pass_equals_plain_level_loop(small, mods, H, W):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    scale = _scale(H, W)
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    if orc.num_levels(H, W) - 1 < 4:
+        pytest.skip("fewer than four levels: nothing behind the speculative ones")
+    for seed in (5, 6):
+        net.set_conv(synth.make_feature_map(seed, synth.SMALL_DIMS["C"], fh, fw))
+        z = _zooms(net, ffi, H, W, scale)
+        for Tz in (0.0, float(np.quantile(z, 0.3)), float(np.quantile(z, 0.6)), float(z[len(z) // 2]), 1.5):
+            for kw in ({}, {"dedup": 0.0}, {"num_proposals": 2000}):
+                plain = _run(net, ffi, H, W, scale, Tz, False, pair_spec=False, **kw)
+                full = _run(net, ffi, H, W, scale, Tz, True, **kw)
+                _same(plain, full)
+                # (a level of more than 1024 regions outgrows the fused level kernel: such trees stay level by level)
+                # (so do shapes whose speculative pass has more than 64 rows)
+                if Tz == 0.0 and not kw and (H, W) in ((600, 1000), (375, 500), (480, 640), (600, 600)):
+                    assert full["st"].n_passes == 1, (full["st"].n_passes, list(full["st"].pass_rows[:4]))
+
+
+def test_history_turns_it_on_for_dense_trees_only(small, mods):
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    H, W = 600, 1000
+    net.set_conv(synth.make_feature_map(9, synth.SMALL_DIMS["C"], 38, 63))
+    p0 = ffi.AzContext.make_params(H, W, 1.0, 0.0, static_tree=False)
+    a = net.propose(p0, want_scores=True, want_stats=True)          # first search of the shape: no history
+    b = net.propose(p0, want_scores=True, want_stats=True)          # dense tree seen: one pass
+    assert a[2].n_passes >= 2 and b[2].n_passes == 1
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    z = _zooms(net, ffi, H, W, 1.0)
+    psparse = ffi.AzContext.make_params(H, W, 1.0, float(np.quantile(z, 0.6)), static_tree=False)
+    net.propose(psparse)
+    c = net.propose(psparse, want_stats=True)                        # pruned tree seen: level by level again
+    assert c[1].num_eval < b[2].num_eval and c[1].pass_rows[0] < b[2].pass_rows[0]
+    d = net.propose(p0, want_scores=True, want_stats=True)          # (history says pruned: the full tree is found out first)
+    e = net.propose(p0, want_scores=True, want_stats=True)
+    assert e[2].n_passes == 1 and np.array_equal(e[0], a[0]) and np.array_equal(d[0], a[0])
+
+
+def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods):
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+    net = HipAZNet(head, name="full_whole", max_regions=4096)
+    H, W = 600, 1000
+    fmap = synth.make_feature_map(31, 512, 38, 63)
+    net.set_conv(fmap)
+    onet = orc.OracleNet(head, feat_fn=lambda d: fmap)
+    nets = {"full": onet, "fc": onet}
+    _, tr0 = orc.im_propose(nets, (H, W), 1.0, orc.OracleCfg(Tz=0.0), return_trace=True)
+    zs = np.sort(np.concatenate([lv["zoom"] for lv in tr0["levels"][1:3]]))
+    j = next(j for j in range(len(zs) // 4, len(zs) - 1) if zs[j + 1] - zs[j] > 2e-3)
+    for Tz in (0.0, 0.5 * (zs[j] + zs[j + 1])):
+        Yref, tr = orc.im_propose(nets, (H, W), 1.0, orc.OracleCfg(Tz=Tz), return_trace=True)
+        z = np.concatenate([lv["zoom"] for lv in tr["levels"]])
+        assert np.abs(z - Tz).min() > 2e-4
+        Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz, static_tree=False, full_spec=True),
+                               want_scores=True, want_stats=True)
+        # (the pruned tree may need a window the full tree's rows lack: then the search was repeated level by level)
+        assert st.n_passes == 1 or Tz > 0.0
+        assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
+        for l, lev in enumerate(tr["levels"]):
+            assert st.level_regions[l] == lev["B"].shape[0]
+            assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"])
+            assert st.level_zoomed[l] == len(lev["indZ"])
+        Yall, Sall = net.ctx.last_candidates()
+        assert Yall.shape == tr["Y_all"].shape
+        assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
+        np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2)
