@@ -448,7 +448,11 @@ def main():
             kernel_table.append(ent)
         floor_us = t_min_us(uniq, fmap_elems)
         form = ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows) if st.static_plan else \
-               ("level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
+               ("level by level (the form every Tz > 0 takes; the context's last search of this shape having walked the "
+                "full tree, ONE head pass evaluates the full tree's unique rois and every level finds its outputs by RoIPool "
+                "window -- zoom selection, divide_region, _sift_dup, dedup all run): head passes of %s rows" % (prow if prow else "?")
+                if (prow and len(prow) == 1) else
+                "level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
         out = {
             "metric": "AZ proposals/sec (600x1000 img)", "value": value, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -553,6 +557,22 @@ def main():
                                            "passes, the tree is a function of the image shape, all levels' rois go through "
                                            "ONE head pass (az_static.hip); proposals and scores bit-identical to `value`'s. "
                                            "No Tz > 0 search can take this form."}
+    # ---- the level loop WITHOUT the whole-tree pass (two head passes: speculative rows, then level 4 + pair rows) ------
+    if not one_pass_main and not args.no_level_loop and st.n_passes == 1:
+        pw = ffi.AzContext.make_params(H_IM, W_IM, scale0, args.tz, num_proposals=NUM_PROPOSALS, static_tree=False,
+                                       full_spec=False)
+        n_w = max(20, args.steps // 2)
+        net.propose(pw)
+        d_w = timed_loop(simple_run(pw), n_w)
+        net.set_conv(conv)
+        Yw, Sw, stw = net.propose(pw, want_scores=True, want_stats=True)
+        assert np.array_equal(Yw, Y) and np.array_equal(Sw, S), "the forms of the level loop disagree"
+        if rank == 0:
+            out["level_loop_without_whole_tree_pass"] = {
+                "value": world * NUM_PROPOSALS * n_w / d_w, "unit": "proposals/s", "ms_per_image": d_w / n_w * 1e3,
+                "rows_per_pass": rows_per_pass(stw),
+                "path_floor_frac": t_min_us([int(stw.level_unique[l]) for l in range(stw.n_levels)], fmap_elems) / (d_w / n_w * 1e6),
+                "note": "the form a pruned tree takes (and round 3's `value` before the whole-tree pass): bit-identical results"}
     # ---- same work with three images in flight per GPU (three contexts / streams), for context ------
     if not args.no_pipelined and args.inflight == 1:
         NFL = 3

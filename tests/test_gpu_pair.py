@@ -36,7 +36,8 @@ def _scale(H, W):
 
 
 def _run(net, ffi, H, W, scale, Tz, pair, **kw):
-    Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, static_tree=False, pair_spec=pair, **kw),
+    # (full_spec=False: these tests are about the pair rows; the whole-tree pass has tests/test_gpu_full.py)
+    Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, static_tree=False, pair_spec=pair, full_spec=False, **kw),
                            want_scores=True, want_stats=True)
     Ya, Sa = net.ctx.last_candidates()
     return dict(Y=Y, S=S, Ya=Ya, Sa=Sa, st=st)
