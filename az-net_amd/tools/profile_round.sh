@@ -1,7 +1,8 @@
 #!/bin/bash
 # One profiling pass of bench.py for profiles/: kernel stats and the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
 # SQ/GRBM), each summarised with the tools beside this file, for three workloads:
-#   main     the level loop at Tz = 0 (bench.py's `value`)                      -> <tag>_*
+#   main     the level loop at Tz = 0 (bench.py's `value`: whole-tree pass)     -> <tag>_*
+#   twopass  the same with AZ_FULL_SPEC=0 (48-row pass + 670-row pass)          -> <tag>_twopass_*
 #   onepass  the Tz <= 0 one-pass form (`one_pass`)                             -> <tag>_onepass_*
 #   extras   calibrated Tz, deep tree (config 4), shared detection (config 3), az_nms at 100 / 300 / 2000 / 8129 boxes:
 #            the geometry / NMS / detection kernels (k_nms_*, k_divide, k_dedup_*, k_level_geom, k_spec_levels, ...)
@@ -11,7 +12,7 @@
 set -u
 tag=${1:-prof}
 shift || true
-sets=${*:-main onepass extras}
+sets=${*:-main twopass onepass extras}
 repo=$(pwd)
 out=$repo/gpurun_out/$tag
 tools=$repo/az-net_amd/tools
@@ -48,9 +49,12 @@ run_set() {
 
 for s in $sets; do
   case $s in
-    # kernels whose name contains k_fc_splitk per image: int6 / int7 of the first pass (48 rows), k_fc_splitk12 (the second
-    # pass's int6: level 4 + all children of level 4), its int7 = 4
-    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 4 ;;
+    # kernels whose name contains k_fc_splitk per image: the whole-tree pass's int6 (k_fc_splitk12, 688 rows) and int7 = 2
+    # (the search's first, history-less image takes the two-pass form: one stray pair of launches in the averages)
+    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
+    # the level loop without the whole-tree pass (AZ_FULL_SPEC=0): 48-row pass (k_fc_splitk int6, int7), 670-row pass
+    # (k_fc_splitk12 int6, int7) = 4
+    twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "twopass_" 4 ;;
     # one pass: k_fc_splitk12 (int6, 688 rows), k_fc_splitk (int7) = 2
     onepass) run_set onepass "--steps 100 --warmup 10 $common --no-calibrated --no-level-loop --no-extras --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
     extras)  run_set extras "--steps 10 --warmup 2 $common --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;

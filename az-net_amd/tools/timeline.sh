@@ -10,9 +10,10 @@ python3 - "$kt" <<'PY'
 import csv, re, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:28]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-# last complete image: from the last-but-one k_spec_levels' preceding k_roi_pool
+# an image from the timed loop (a third of the way through the trace: behind it the bench measures other forms)
 idx = [i for i, r in enumerate(rows) if r[2].startswith("k_final_select")]
-a, b = idx[-3] + 1, idx[-2] + 1
+m = len(idx) // 3
+a, b = idx[m] + 1, idx[m + 1] + 1
 t0 = rows[a][0]
 prev = rows[a - 1][1]
 for s, e, n in rows[a:b + 2]:
