@@ -255,9 +255,7 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
                  int N, int K, int S, float *part, int max_strips = 1 << 30);
 int azk_fc_chunk(int K, int S);
 int azk_gemm_grid();
-// split-bf16 GEMM (az_head_bf16.hip): operands as `parts` bf16 round-off planes
-void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long long n, long long plane_stride,
-                      int parts, float scale);
+// int6 on the 16-bit matrix cores (az_head_terms.hip): operands as `parts` planes of 16-bit terms
 // two-term (fp16) mode: scales[0] = power-of-two scale of pool5 for this map, scales[1] = 1 / (scales[0] * sw);
 // scales[2..3] are scratch words that must start at zero
 // activation (pool5) planes of k_fc_terms: tile-major too -- block (row / 32, k / 32) holds 32 rows x 32 terms (2 KB), K padded
@@ -277,7 +275,7 @@ __host__ __device__ inline size_t azk_act_plane_elems(int rows, int K)
 size_t azk_weight_plane_elems(int N, int K);
 void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out, int N, int K, int parts, float scale);
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw);
-int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
+int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
                      int parts, const float *scales);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,

@@ -1,4 +1,4 @@
-// az_head_bf16.hip -- the int6 GEMM on the 16-bit matrix cores with fp32 operands written as sums of 16-bit terms
+// az_head_terms.hip -- the int6 GEMM on the 16-bit matrix cores with fp32 operands written as sums of 16-bit terms
 // (az_set_gemm_mode 2 / 3; the default, mode 0, is the fp32-input MFMA of az_head.hip / az_head12.hip).
 //
 // gfx950's fp32-input MFMA runs at 1/16 of the fp16 / bf16 MFMA rate.  An fp32 value is a sum of 16-bit terms, each the
@@ -40,31 +40,6 @@ __device__ __forceinline__ unsigned short f2bf(float x)      // round to nearest
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-// rows [R][K] fp32 -> PARTS planes [p][R][K] of 16-bit terms (plane stride = rows_cap * K).
-// scale == 0: bf16 round-off terms.  scale != 0 (a power of two): fp16 terms of x * scale (|x * scale| < 65504).
-__global__ void k_split_planes(const float *__restrict__ in, unsigned short *__restrict__ out, long long n,
-                               long long plane_stride, int parts, float scale)
-{
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        float x = in[i];
-        if (scale != 0.f) {
-            x *= scale;
-            for (int p = 0; p < parts; ++p) {
-                const __half h = __float2half_rn(x);
-                out[p * plane_stride + i] = __half_as_ushort(h);
-                x -= __half2float(h);
-            }
-            continue;
-        }
-        for (int p = 0; p < parts; ++p) {
-            const unsigned short h = f2bf(x);
-            out[p * plane_stride + i] = h;
-            x -= bf2f(h);
-        }
-    }
-}
 
 // Scale of the fp16 terms of pool5 (two-term mode): pool5 values are maxima of feature-map values, so
 // |pool5| <= max |map|; sc[0] = sx = the power of two that brings that maximum into [2^14, 2^15), sc[1] = 1 / (sx * sw)
@@ -437,12 +412,6 @@ k_fc_terms(const unsigned short *__restrict__ Xp, int ldx, size_t xplane, const 
 }  // namespace
 
 // --------------------------------------------------------------------------------------
-void azk_split_planes(hipStream_t s, const float *in, unsigned short *out, long long n, long long plane_stride,
-                      int parts, float scale)
-{
-    hipLaunchKernelGGL(k_split_planes, dim3(4096), dim3(256), 0, s, in, out, n, plane_stride, parts, scale);
-}
-
 // Weight planes for k_fc_terms: tile-major -- block (n / 128, k / 32) holds 128 rows x 32 terms (8 KB) contiguously, K padded
 // with zeros to a multiple of 32, N to a multiple of 128 -- so that a K step's weight tile is one contiguous 8 KB
 // read per plane instead of 128 pieces of 64 B that are a weight row (tens of KB) apart.
@@ -503,7 +472,7 @@ void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales
 //                    matters; weight panels are re-read from the Infinity Cache).
 // Both are launched; each reads the row count on the device and one of them returns at once.
 // Kc (elements) is the fp32 kernel's chunking, so the slabs feed the same k_fc_reduce.
-int azk_fc_gemm_bf16(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
+int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
                      int parts, const float *scales)
 {
