@@ -255,11 +255,9 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
                  int N, int K, int S, float *part, int max_strips = 1 << 30);
 int azk_fc_chunk(int K, int S);
 int azk_gemm_grid();
-// int6 on the 16-bit matrix cores (az_head_terms.hip): operands as `parts` planes of 16-bit terms
-// two-term (fp16) mode: scales[0] = power-of-two scale of pool5 for this map, scales[1] = 1 / (scales[0] * sw);
-// scales[2..3] are scratch words that must start at zero
-// activation (pool5) planes of k_fc_terms: tile-major too -- block (row / 32, k / 32) holds 32 rows x 32 terms (2 KB), K padded
-// to a multiple of 32 (the padding is zeroed once, at allocation) -- so that a wave's tile load is 1 KB contiguous
+// ---- int6 on the 16-bit matrix cores (az_head_terms.hip): operands as `parts` planes of 16-bit terms ----
+// Activation (pool5) planes: tile-major -- block (row / 32, k / 32) holds 32 rows x 32 terms (2 KB), K padded to a
+// multiple of 32 (the padding is zeroed once, at allocation) -- so that a wave's tile load is 1 KB contiguous.
 __host__ __device__ inline size_t azk_act_plane_index(int row, int k, int K)
 {
     const int KT = (K + 31) >> 5;
@@ -271,13 +269,18 @@ __host__ __device__ inline size_t azk_act_plane_elems(int rows, int K)
 {
     return (size_t)((rows + 31) >> 5) * ((K + 31) >> 5) * 1024;
 }
-// weight planes of k_fc_terms: tile-major (128 rows x 32 terms per 8 KB block), zero-padded; elements per plane
+// Weight planes: tile-major (128 rows x 32 terms per 8 KB block, same swizzle), zero-padded; elements per plane.
+// scale == 0: bf16 round-off terms; otherwise fp16 terms of w * scale (a power of two).
 size_t azk_weight_plane_elems(int N, int K);
 void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out, int N, int K, int parts, float scale);
+// two-term (fp16) mode: scales[0] = power-of-two scale of pool5 for this map, scales[1] = 1 / (scales[0] * sw);
+// scales[2..3] are scratch words that must start at zero
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw);
+// part[s][m][n] = chunk s of X . W^T from the planes (parts = 2: fp16 terms, 3 MFMAs per product; 3: bf16 terms, 6);
+// same K chunks / slabs as azk_fc_gemm; xplane / wplane: elements per plane
 int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
-                     int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
-                     int parts, const float *scales);
+                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
+                      int parts, const float *scales);
 void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const int *Mptr, int capM, int N,
                    int S, float *y, int ldy, int relu);
 // int7_1|int7_2's slab sum + bias + ReLU, then adj_score + adj_bbox + zoom_score (56 outputs) + bias +
