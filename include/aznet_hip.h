@@ -73,7 +73,12 @@ typedef struct {
                                  bit 6: no pair speculation; bit 7: pair speculation at every eligible level (by
                                  default the context decides from its previous search whether the head pass of a
                                  level also evaluates the rois of ALL children of its regions, a superset of the next
-                                 level's, which then needs no pass of its own; same bits in all three)            */
+                                 level's, which then needs no pass of its own; same bits in all three);
+                                 bit 8: no whole-tree speculation; bit 9: whole-tree speculation whenever the image
+                                 shape allows (by default, when the context's previous search of the shape walked
+                                 the FULL tree, the search's one head pass evaluates the full tree's unique rois and
+                                 every level finds its outputs by RoIPool window; a search that needs a window that
+                                 pass lacks is repeated level by level; same bits in all three)                    */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
