@@ -10,7 +10,8 @@ az_propose_launch / az_propose_stage_result_dev / az_propose_fetch, exchanges th
 DeviceGather (one all_gather_into_tensor per batch, padding rows for short ranks) and compares EVERY image of the
 gathered list with a plain az_propose of that image on this rank.  The images cover: a healthy search, a search
 whose fused levels overflow on first sight (err bit 8: rerun + restaging of the record, az_capi.hip) and a search
-whose one-pass premise fails (NaN zoom score, err bit 32: rerun through the level loop + restaging).
+whose one-pass premise fails (NaN zoom score, err bit 32: rerun through the level loop + restaging), and forced
+whole-tree passes whose pruned trees miss a window (err bit 256: rerun + restaging).
 Prints "RCCL_WORKER_OK <rank> <images checked>" on success."""
 import os
 import sys
@@ -35,7 +36,10 @@ def image_case(i, synth):
 
 def params_of(i, ffi, synth, k):
     H, W, scale, Tz, seed, hk, static = image_case(i, synth)
-    return ffi.AzContext.make_params(H, W, scale, Tz, num_proposals=k, static_tree=static)
+    # every fifth image forces the whole-tree pass: with Tz = 0.45 the pruned tree needs windows that pass lacks
+    # (err bit 256 -> rerun level by level, record restaged)
+    return ffi.AzContext.make_params(H, W, scale, Tz, num_proposals=k, static_tree=static,
+                                     full_spec=(True if i % 5 == 1 else None))
 
 
 def main():
