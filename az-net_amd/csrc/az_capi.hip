@@ -746,7 +746,7 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv, q.lv_limit);
     // whole-tree speculation (decided and prepared by az_propose_launch: full_prepare): one head pass over the rows of
     // the image shape's full tree, every level's outputs by window lookup -- no deferred root, no pair rows
-    q.full = c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit > nlev && c->plan &&
+    q.full = c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit >= q.n_spec && c->plan &&
              c->plan->full_state == 1 && plan_is_for(*c->plan, p, nlev);
     if (q.full) { q.defer_root = false; q.pair_mask = 0; }
     return q;
@@ -926,7 +926,7 @@ static int full_prepare(az_ctx *c, const az_params *p, int nlev, bool tune)
     const bool forced = (p->reserved & 512) || c->full_env == 2;
     if (!forced && c->full_env == 0) return AZ_OK;
     const SearchPlan q0 = plan_search(c, p, nlev, tune);        // (full_now is false: the other form's plan)
-    if (!(q0.fused && q0.fused_lv && q0.n_spec == 3 && q0.lv_limit > nlev && nlev > q0.n_spec)) return AZ_OK;
+    if (!(q0.fused && q0.fused_lv && q0.n_spec == 3 && q0.lv_limit >= q0.n_spec && nlev > q0.n_spec)) return AZ_OK;
     // By history: only when the previous search of this image shape walked the FULL tree (every region zoomed at every
     // level but the last).  A pruned tree may keep another _sift_dup survivor than the full tree does (same 10-px hash,
     // other coordinates, other RoIPool window): such a window is not among the pass's rows and the search has to be
@@ -1152,6 +1152,13 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         // kernels: same bits.)
         const bool final_fused = fused && !tune && l + 1 == nlev && l >= n_spec && p->fixed_num && !(p->reserved & 8) &&
                                  c->final_env;
+        if (full && !have_v && l >= n_spec) {
+            // whole-tree speculation, a level on the multi-launch kernels: its outputs by window lookup, chip-wide
+            Timed t(c, "full_lookup", l);
+            azk_full_lookup(s, Uptr, c->urois, c->ubox, fp->htab, fp->hT, fp->Ufull - 1, c->spatial_scale, c->delta_s, c->score_s,
+                            c->zoom_s, p->im_h, p->im_w, p->eps, p->min_side, Vp(l), Vs(l), Vz(l), Vk(l), Vy(l), &c->cnt->err);
+            have_v = true;
+        }
         if (l < n_spec) {
             Timed t(c, "spec_lookup", l);
             azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,

@@ -155,6 +155,10 @@ void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src);
 // whole-tree speculation: window table over a plan's rows (root_row gets the marker row), map of the speculative rows
 void azk_full_tab_build(hipStream_t s, const float *urois, int n_rows, int root_row, float ss, unsigned long long *tab,
                         unsigned T, int *err);
+void azk_full_lookup(hipStream_t s, const int *Uptr, const float *urois, const double *ubox, const unsigned long long *tab,
+                     unsigned T, int root_row, float ss, const float *delta_all, const float *score_all, const float *zoom_all,
+                     int im_h, int im_w, double eps, double min_side, double *pred_v, float *score_v, float *zoom_v,
+                     unsigned char *keep_v, unsigned *key_v, int *err);
 void azk_full_map(hipStream_t s, const float *spec_urois, int n_spec, float ss, const unsigned long long *tab, unsigned T,
                   int base_extra, int cap_rows, float *urois_full, double *ubox_full, int *map, int *n_extra, int *err);
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);

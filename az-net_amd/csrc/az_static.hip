@@ -463,6 +463,50 @@ __global__ void k_full_map(const float *__restrict__ spec_urois, int n_spec, flo
 }
 }  // namespace
 
+namespace {
+// Whole-tree speculation, a level that runs on the multi-launch geometry kernels (more regions than the fused level kernel
+// holds): the head outputs of its unique rois by RoIPool window among the rows of the search's one pass -- the lookup
+// stage of k_level_geom, chip-wide.  ubox = the representative's own box of every unique roi (k_dedup_rois).
+__global__ void __launch_bounds__(256) k_full_lookup(const int *Uptr, const float *__restrict__ urois,
+                                                      const double *__restrict__ ubox, const unsigned long long *tab,
+                                                      unsigned T, int root_row, float ss,
+                                                      const float *__restrict__ delta_all, const float *__restrict__ score_all,
+                                                      const float *__restrict__ zoom_all, int im_h, int im_w, double eps,
+                                                      double min_side, double *pred_v, float *score_v, float *zoom_v,
+                                                      unsigned char *keep_v, unsigned *key_v, int *err)
+{
+    const int U = *Uptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < U * AZ_NSUB; i += gridDim.x * blockDim.x) {
+        const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+        const int row = az_tab_lookup(tab, T, urois + 5 * (size_t)slot, ss, root_row);
+        if (row < 0) { atomicOr(err, 8 | 256); continue; }
+        float d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d4[q] = delta_all[(size_t)row * 4 * AZ_NSUB + 4 * sub + q];
+        double bx[4];
+        az_decode_box(ubox + 4 * (size_t)slot, d4, im_h, im_w, eps, bx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pred_v[(size_t)i * 4 + q] = bx[q];
+        const float sc = score_all[(size_t)row * AZ_NSUB + sub];
+        score_v[i] = sc;
+        const bool kp = cand_keep(bx, min_side);
+        keep_v[i] = kp ? 1 : 0;
+        const unsigned kk = score_key(sc);
+        key_v[i] = kp ? (kk ? kk : 1u) : 0u;
+        if (sub == 0) zoom_v[slot] = zoom_all[row];
+    }
+}
+}  // namespace
+
+void azk_full_lookup(hipStream_t s, const int *Uptr, const float *urois, const double *ubox, const unsigned long long *tab,
+                     unsigned T, int root_row, float ss, const float *delta_all, const float *score_all, const float *zoom_all,
+                     int im_h, int im_w, double eps, double min_side, double *pred_v, float *score_v, float *zoom_v,
+                     unsigned char *keep_v, unsigned *key_v, int *err)
+{
+    hipLaunchKernelGGL(k_full_lookup, dim3(256), dim3(256), 0, s, Uptr, urois, ubox, tab, T, root_row, ss, delta_all, score_all,
+                       zoom_all, im_h, im_w, eps, min_side, pred_v, score_v, zoom_v, keep_v, key_v, err);
+}
+
 void azk_full_tab_build(hipStream_t s, const float *urois, int n_rows, int root_row, float ss, unsigned long long *tab,
                         unsigned T, int *err)
 {

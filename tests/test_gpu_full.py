@@ -132,3 +132,23 @@ def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods):
         assert Yall.shape == tr["Y_all"].shape
         assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
         np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2)
+
+
+def test_deep_tree_takes_the_whole_tree_pass_too(small, mods):
+    """BASELINE config 4's shape (800x1200 at 0.75: six levels, 2048 regions at the last): the levels that outgrow the
+    fused level kernel run on the multi-launch geometry kernels and find their outputs with the chip-wide lookup."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    H, W, scale = 800, 1200, 0.75
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    net.set_conv(synth.make_feature_map(17, synth.SMALL_DIMS["C"], fh, fw))
+    plain = _run(net, ffi, H, W, scale, 0.0, False, pair_spec=False)
+    assert [int(plain["st"].level_regions[l]) for l in range(6)] == [1, 8, 32, 128, 512, 2048]
+    _run(net, ffi, H, W, scale, 0.0, True)          # (the first fused attempt of the shape learns which level overflows)
+    full = _run(net, ffi, H, W, scale, 0.0, True)
+    _same(plain, full)
+    assert full["st"].n_passes == 1 and full["st"].pass_rows[0] >= 2672
+    z = _zooms(net, ffi, H, W, scale)
+    for q in (0.2, 0.5):
+        Tz = float(np.quantile(z, q))
+        _same(_run(net, ffi, H, W, scale, Tz, False, pair_spec=False), _run(net, ffi, H, W, scale, Tz, True))
