@@ -616,6 +616,10 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipDeviceSynchronize());
     // the many-row GEMM's LDS opt-in is per device; without it every launch stays on k_fc_splitk
     if (azk_fc_gemm12_prepare() != 0) { (void)hipGetLastError(); c->gemm12_min_rows = 0x7fffffff; c->gemm12_env = 1; }
+    if (c->gemm_parts && azk_fc_terms_prepare(c->gemm_parts) != 0) {
+        (void)hipGetLastError();
+        return fail(c, AZ_ERR_HIP, "az_load_head: the 16-bit-term GEMM's LDS opt-in failed on this device (az_set_gemm_mode)");
+    }
     c->head_loaded = true;
     return AZ_OK;
 }

@@ -282,6 +282,7 @@ void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw);
 // part[s][m][n] = chunk s of X . W^T from the planes (parts = 2: fp16 terms, 3 MFMAs per product; 3: bf16 terms, 6);
 // same K chunks / slabs as azk_fc_gemm; xplane / wplane: elements per plane
+int azk_fc_terms_prepare(int parts);     // per device (dynamic-LDS opt-in), with that device current; != 0: unavailable
 int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
                       int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
                       int parts, const float *scales);

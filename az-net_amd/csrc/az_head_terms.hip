@@ -472,33 +472,46 @@ void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales
 //                    matters; weight panels are re-read from the Infinity Cache).
 // Both are launched; each reads the row count on the device and one of them returns at once.
 // Kc (elements) is the fp32 kernel's chunking, so the slabs feed the same k_fc_reduce.
-int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
-                     int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
-                     int parts, const float *scales)
-{
-    static const int xcd_order = getenv("AZ_X3_ORDER") ? atoi(getenv("AZ_X3_ORDER")) : 1;      // experiment knob
-    // 64-byte LDS rows, two stages.  Wide shape: 256 x 128 tiles with three terms (144 KB), 256 x 256 with two (128 KB).
-    auto launch_terms = [&](auto pc, auto fc, auto cwc) -> int {
-        constexpr int P = decltype(pc)::value;
-        constexpr bool F16 = decltype(fc)::value;
-        constexpr int CW = decltype(cwc)::value;          // column strips per wave of the wide shape
-        const size_t shm_w = (size_t)2 * P * (256 + BN * CW) * BK * sizeof(unsigned short);
-        const size_t shm_n = (size_t)2 * P * (64 + BN) * BK * sizeof(unsigned short);      // 72 KB, 48 KB
-        static bool attr = false;
-        if (!attr) {
-            if (hipFuncSetAttribute((const void *)k_fc_terms<8, 256, P, F16, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shm_w) != hipSuccess) return -1;
-            if (hipFuncSetAttribute((const void *)k_fc_terms<4, 64, P, F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)shm_n) != hipSuccess) return -1;
-            attr = true;
-        }
+namespace {
+template <int P, bool F16, int CW> struct TermsShape {
+    static constexpr size_t shm_w = (size_t)2 * P * (256 + BN * CW) * BK * sizeof(unsigned short);   // 144 KB (P = 3), 128 KB (P = 2)
+    static constexpr size_t shm_n = (size_t)2 * P * (64 + BN) * BK * sizeof(unsigned short);         // 72 KB, 48 KB
+    static int prepare()
+    {
+        if (hipFuncSetAttribute((const void *)k_fc_terms<8, 256, P, F16, CW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm_w) != hipSuccess) return -1;
+        if (hipFuncSetAttribute((const void *)k_fc_terms<4, 64, P, F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm_n) != hipSuccess) return -1;
+        return 0;
+    }
+    static void launch(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp, int ldw,
+                       size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part, int xcd_order,
+                       const float *scales)
+    {
         hipLaunchKernelGGL((k_fc_terms<4, 64, P, F16, 1>), dim3(512), dim3(256), shm_n, s, Xp, ldx, xplane, Wp, ldw, wplane,
                            Mptr, capM, N, K, S, Kc, part, 1, 2, 0, scales);
         hipLaunchKernelGGL((k_fc_terms<8, 256, P, F16, CW>), dim3(256), dim3(512), shm_w, s, Xp, ldx, xplane, Wp, ldw, wplane,
                            Mptr, capM, N, K, S, Kc, part, 3, 1 << 30, xcd_order, scales);
-        return 0;
-    };
-    if (parts == 3) return launch_terms(std::integral_constant<int, 3>{}, std::false_type{}, std::integral_constant<int, 1>{});
-    if (parts == 2) return launch_terms(std::integral_constant<int, 2>{}, std::true_type{}, std::integral_constant<int, 2>{});
-    return -1;
+    }
+};
+typedef TermsShape<2, true, 2> Terms2;       // two fp16 terms: 256 x 256 tiles
+typedef TermsShape<3, false, 1> Terms3;      // three bf16 terms: 256 x 128 tiles
+}  // namespace
+
+// The kernels' dynamic LDS (> 64 KB) needs an opt-in that is recorded per DEVICE: every context calls this once with its
+// device current (az_load_head); != 0: the mode cannot run there.
+int azk_fc_terms_prepare(int parts)
+{
+    return parts == 2 ? Terms2::prepare() : parts == 3 ? Terms3::prepare() : -1;
+}
+
+int azk_fc_gemm_terms(hipStream_t s, const unsigned short *Xp, int ldx, size_t xplane, const unsigned short *Wp,
+                      int ldw, size_t wplane, const int *Mptr, int capM, int N, int K, int S, int Kc, float *part,
+                      int parts, const float *scales)
+{
+    static const int xcd_order = getenv("AZ_X3_ORDER") ? atoi(getenv("AZ_X3_ORDER")) : 1;      // experiment knob
+    if (parts == 3) Terms3::launch(s, Xp, ldx, xplane, Wp, ldw, wplane, Mptr, capM, N, K, S, Kc, part, xcd_order, scales);
+    else if (parts == 2) Terms2::launch(s, Xp, ldx, xplane, Wp, ldw, wplane, Mptr, capM, N, K, S, Kc, part, xcd_order, scales);
+    else return -1;
+    return 0;
 }

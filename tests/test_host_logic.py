@@ -86,6 +86,18 @@ def test_ffi_struct_layout_matches_header():
     assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, num_proposals=300, batch_size=1000, speculate=False)
     assert (p.im_h, p.im_w, p.Tz, p.batch_size, p.fixed_num, p.reserved) == (600, 1000, 0.3, 1000, 1, 1)
+    # the flag bits of params.reserved (include/aznet_hip.h)
+    mk = lambda **kw: ffi.AzContext.make_params(600, 1000, 1.0, 0.3, **kw).reserved      # noqa: E731
+    assert mk() == 0
+    assert mk(fused=False) == 2 and mk(tune=True) == 4 and mk(radix_select=True) == 8 and mk(fused_levels=False) == 16
+    assert mk(static_tree=False) == 32
+    assert mk(pair_spec=False) == 64 and mk(pair_spec=True) == 128
+    assert mk(full_spec=False) == 256 and mk(full_spec=True) == 512
+    assert mk(pair_spec=False, full_spec=True, static_tree=False) == 64 + 512 + 32
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "aznet_hip.h")).read()
+    for bit in range(10):
+        assert re.search(r"bit %d\b" % bit, hdr), "params.reserved bit %d is not documented in the header" % bit
 
 
 def _make_voc_tree(root, year="2007"):
