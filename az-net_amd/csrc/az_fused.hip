@@ -402,16 +402,24 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
             // k_level_geom's lookup stage does for the levels after it): raw deltas decoded against the representative's own
             // box, scores / zoom copied -- what the tail kernel would have written for that roi, bit for bit
             __syncthreads();
+            // (one probe per unique roi, its row parked in LDS; then one thread per (roi, sub-region) decodes)
             int miss = 0;
-            for (int i = tid; i < U * AZ_NSUB; i += NTL) {
-                const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+            for (int slot = tid; slot < U; slot += NTL) {
                 const double *bx0 = sB[nxt] + 4 * sidx[slot];
                 float roi5[5];
                 roi5[0] = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(bx0[q] * a.scale);
                 const int row = az_tab_lookup(a.stab, a.stabT, roi5, a.spatial_scale, a.root_row);
-                if (row < 0) { miss = 1; continue; }
+                sslot[slot] = row;
+                if (row < 0) miss = 1; else a.zoom_v[slot] = a.zoom_s[row];
+            }
+            __syncthreads();
+            for (int i = tid; i < U * AZ_NSUB; i += NTL) {
+                const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+                const int row = sslot[slot];
+                if (row < 0) continue;
+                const double *bx0 = sB[nxt] + 4 * sidx[slot];
                 float d4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) d4[q] = a.delta_s[(size_t)row * 4 * AZ_NSUB + 4 * sub + q];
@@ -425,7 +433,6 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
                 a.keep_v[i] = kp ? 1 : 0;
                 const unsigned kk = score_key(sc);
                 a.key_v[i] = kp ? (kk ? kk : 1u) : 0u;
-                if (sub == 0) a.zoom_v[slot] = a.zoom_s[row];
             }
             if (miss) atomicOr(&cnt->err, 8 | 256);
             if (tid == 0) { cnt->U[a.n_fused] = U; cnt->SPB[a.n_fused] = U; cnt->SPN[a.n_fused] = 0; cnt->PR[a.n_fused] = 0; }

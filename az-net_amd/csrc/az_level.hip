@@ -293,16 +293,24 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
         // ---- whole-tree speculation: level l+1's head outputs by RoIPool window among the rows of the search's one head
         //      pass (the full tree of this image shape; table built once per shape, az_static.hip).  Same arithmetic as
         //      the pair-row lookup below; a window the table does not hold sends the search back to the other form.
+        // (one probe per unique roi, its row parked in LDS; then one thread per (roi, sub-region) decodes)
         int miss = 0;
-        for (int i = tid; i < Un * AZ_NSUB; i += NT) {
-            const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+        for (int slot = tid; slot < Un; slot += NT) {
             const int rpos = sidx[slot];
             float roi5[5];
             roi5[0] = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) roi5[1 + q] = (float)(sBn[4 * rpos + q] * a.scale);
             const int row = az_tab_lookup(a.stab, a.stabT, roi5, a.spatial_scale, a.root_row_full);
-            if (row < 0) { miss = 1; continue; }
+            sprov[slot] = row;
+            if (row < 0) miss = 1; else a.zoom_v[slot] = a.zoom_all[row];
+        }
+        __syncthreads();
+        for (int i = tid; i < Un * AZ_NSUB; i += NT) {
+            const int slot = i / AZ_NSUB, sub = i - slot * AZ_NSUB;
+            const int rpos = sidx[slot];
+            const int row = sprov[slot];
+            if (row < 0) continue;
             float d4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) d4[q] = a.delta_u[(size_t)row * 4 * AZ_NSUB + 4 * sub + q];
@@ -316,7 +324,6 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
             a.keep_v[i] = kp ? 1 : 0;
             const unsigned kk = score_key(sc);
             a.key_v[i] = kp ? (kk ? kk : 1u) : 0u;
-            if (sub == 0) a.zoom_v[slot] = a.zoom_all[row];
         }
         if (miss) atomicOr(&cnt->err, 8 | 256);
         if (tid == 0) { cnt->PR[l + 1] = 0; cnt->SPB[l + 1] = Un; cnt->SPN[l + 1] = 0; }
