@@ -1766,9 +1766,19 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         if (!(c->profiling & 4)) clear_events(c);
         { Timed t(c, "nms", n);
           azk_nms_one_small(s, hd, n, thresh, hk, hn); }
-        HIPCHK(c, hipStreamSynchronize(s));
+        // The kernel writes the count last (behind a system-wide fence): poll it in the mapped block -- a stream
+        // synchronisation costs an interrupt round trip (~10-15 us) on top of a kernel of about that length.  The stream's
+        // own completion is picked up by whatever uses it next (same stream: ordered).  (AZ_NMS_POLL=0, profiling, or no
+        // answer within a millisecond: the plain wait.)
+        static const bool poll = !(getenv("AZ_NMS_POLL") && !atoi(getenv("AZ_NMS_POLL")));
+        bool got = false;
+        if (poll && !c->profiling) {
+            const volatile int *vn = hn;
+            for (int spin = 0; spin < 200000 && !got; ++spin) got = *vn >= 0;
+        }
+        if (!got) HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
-        const int nk = *hn;
+        const int nk = *(const volatile int *)hn;
         if (nk < 0 || nk > n) return fail(c, AZ_ERR_HIP, "az_nms: the kernel left no result");
         *n_keep = nk;
         for (int i = 0; i < nk; ++i) keep[i] = hk[i];

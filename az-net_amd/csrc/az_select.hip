@@ -517,6 +517,9 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
                 }
             }
         }
+        // (the count is the LAST thing written: az_nms's small case polls it in host-mapped memory instead of waiting for
+        //  the stream's completion signal, so everything before it must be visible system-wide first)
+        __threadfence_system();
         if (lane == 0) nkeep[g] = nk;
     }
 }
