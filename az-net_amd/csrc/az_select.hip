@@ -418,7 +418,9 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
 // all in LDS.  Same arithmetic, same order conventions as the three kernels above.
 constexpr int NMS_SMALL = 256;
 
-__global__ void __launch_bounds__(256)
+constexpr int NMS_SMALL_NT = 1024;       // 16 waves: the suppression words are n^2 / 64 (row, 64-column block) pairs of
+                                        // ~100 dependent cycles each -- 4 waves took 49 us of a 60 us kernel at 256 boxes
+__global__ void __launch_bounds__(NMS_SMALL_NT)
 k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const int *__restrict__ gsel,
             int n_single, double thresh, long long *__restrict__ keep, int *__restrict__ nkeep)
 {
@@ -431,14 +433,23 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
     const int g = goff ? gsel[blockIdx.x] : 0;
     const int o = goff ? goff[g] : 0, n = goff ? goff[g + 1] - o : n_single;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *d = dets + 5 * (size_t)o;
+    // the boxes come in with ONE round trip of coalesced loads (in az_nms's small case they sit in host-mapped memory: a
+    // strided read per field would be a PCIe transaction per lane and field -- 23 us of kernel for 100 boxes)
+    __shared__ float sraw[NMS_SMALL * 5];
+    {
+        const float *g = dets + 5 * (size_t)o;
+        for (int j = tid; j < 5 * n; j += NMS_SMALL_NT) sraw[j] = g[j];
+    }
+    __syncthreads();
+    const float *d = sraw;
     const int i = tid;
     const float si = i < n ? d[5 * i + 4] : 0.f;
-    ss[tid] = si;
+    if (tid < NMS_SMALL) ss[tid] = si;
     __syncthreads();
     if (i < n) {
         int rank = 0;
-        for (int j = 0; j < n; ++j) {
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) {                   // (eight independent LDS broadcasts in flight)
             const float sj = ss[j];
             rank += (sj > si) | ((sj == si) & (j > i));
         }
@@ -450,14 +461,20 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
     }
     __syncthreads();
     const int W = (n + 63) >> 6;
-    // suppression words: wave handles rows wave, wave + 4, ...; lane = column inside the 64-word
-    for (int r = wave; r < n; r += 4) {
-        const float ix1 = sd[r][0], iy1 = sd[r][1], ix2 = sd[r][2], iy2 = sd[r][3], iarea = sd[r][4];
-        for (int cb = 0; cb < W; ++cb) {
-            const int j = cb * 64 + lane;
+    // suppression words: lane = column j of a 64-column block (its box in registers), the workgroup's 16 waves share the
+    // rows (four rows per wave and turn written out by hand measured no better)
+    constexpr int NWV = NMS_SMALL_NT / 64;
+    for (int cb = 0; cb < W; ++cb) {
+        const int j = cb * 64 + lane;
+        const bool jin = j < n;
+        const float jx1 = jin ? sd[j][0] : 0.f, jy1 = jin ? sd[j][1] : 0.f, jx2 = jin ? sd[j][2] : 0.f,
+                    jy2 = jin ? sd[j][3] : 0.f, jarea = jin ? sd[j][4] : 0.f;
+        // (rows r >= (cb + 1) * 64 suppress nothing in this block: j > r never holds)
+        const int rend = min(n, (cb + 1) * 64);
+        for (int r = wave; r < rend; r += NWV) {
+            const float ix1 = sd[r][0], iy1 = sd[r][1], ix2 = sd[r][2], iy2 = sd[r][3], iarea = sd[r][4];
             bool sup = false;
-            if (j < n && j > r) {
-                const float jx1 = sd[j][0], jy1 = sd[j][1], jx2 = sd[j][2], jy2 = sd[j][3], jarea = sd[j][4];
+            if (jin && j > r) {
                 const float xx1 = ix1 >= jx1 ? ix1 : jx1;
                 const float yy1 = iy1 >= jy1 ? iy1 : jy1;
                 const float xx2 = ix2 <= jx2 ? ix2 : jx2;
@@ -474,6 +491,8 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
             const unsigned long long word = __ballot(sup);
             if (lane == 0) smask[r][cb] = word;
         }
+        // (rows past this block's end: no column of the block lies behind them)
+        for (int r = rend + tid; r < n; r += NMS_SMALL_NT) smask[r][cb] = 0ull;
     }
     __syncthreads();
     if (wave == 0) {
@@ -583,12 +602,12 @@ void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int 
                    long long *keep, int *nkeep)
 {
     if (n_sel > 0)
-        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(256), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep);
+        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(NMS_SMALL_NT), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep);
 }
 
 void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep)
 {
-    hipLaunchKernelGGL(k_nms_small, dim3(1), dim3(256), 0, s, dets, (const int *)nullptr, (const int *)nullptr, n, thresh,
+    hipLaunchKernelGGL(k_nms_small, dim3(1), dim3(NMS_SMALL_NT), 0, s, dets, (const int *)nullptr, (const int *)nullptr, n, thresh,
                        keep, nkeep);
 }
 
