@@ -28,8 +28,8 @@ struct az_ctx {
     bool head_loaded = false;
     AzHeadDims d{};
     int S6 = 1, S7 = 1;
-    // int6 on the bf16 matrix cores for launches of > 64 rows: 0 = off (fp32 MFMA everywhere),
-    // 2 = two bf16 terms / 3 MFMAs per product (~2^-16), 3 = three terms / 6 MFMAs (fp32-grade)
+    // int6 on the 16-bit matrix cores (az_set_gemm_mode): 0 = off (fp32 MFMA everywhere), 2 = two fp16 terms of
+    // x * 2^k / 3 MFMAs per product (~2^-21), 3 = three bf16 terms / 6 MFMAs (every fp32 value exactly)
     int gemm_parts = 0;
     unsigned short *W6p = nullptr, *pool5p = nullptr;
     float *gscale = nullptr;            // two-term (fp16) mode: {pool5 scale of this map, 1 / (sx * sw), scratch, scratch}

@@ -234,8 +234,9 @@ void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 // feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
 // pool5 comes out bin-major: [roi][ph*7+pw][c]
-// With parts > 0, launches of >= min_strips 32-row strips write bf16 round-off planes
-// (planes[q * plane_stride + ...]) instead of fp32 pool5, for the split-bf16 GEMM.
+// With parts > 0, launches of >= min_strips 32-row strips write `parts` planes of 16-bit terms (tile-major,
+// azk_act_plane_index; xscale != nullptr: fp16 terms of x * xscale[0], else bf16 round-off terms) instead of fp32
+// pool5, for the GEMM on the 16-bit matrix cores (az_head_terms.hip).
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
                   size_t plane_stride, int parts, int min_strips, int coop_tail = 0, const float *xscale = nullptr);

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     __shared__ __attribute__((aligned(16))) float spart[4][512];
     const int U = *Uptr;
-    // launches that the split-bf16 GEMM will consume get their bf16 terms written here directly
+    // launches that the 16-bit-term GEMM will consume get their terms written here directly
     const bool to_planes = parts > 0 && ((U + 31) >> 5) >= min_strips;
     const float xs = xscale ? xscale[0] : 0.f;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -633,7 +633,7 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
 
     const int M = *Mptr;
     if (M <= 0) return;
-    if (((M + 31) >> 5) > max_strips) return;   // larger launches of this layer run on the split-bf16 kernel
+    if (((M + 31) >> 5) > max_strips) return;   // larger launches of this layer belong to another kernel
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
     // With at least one group per workgroup, a workgroup owns whole groups and walks their

@@ -464,14 +464,11 @@ void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales
     hipLaunchKernelGGL(k_feat_scale, dim3(256), dim3(256), 0, s, feat, n, scales, sw);
 }
 
-// part[s][m][n] = sum over chunk s of X . W^T from two bf16 planes per operand.  Two shapes of one
-// kernel, same per-row arithmetic (so a row's bits do not depend on which one ran):
-//   <= 2 row strips: 128-row tiles, 4 waves, two workgroups per CU (weight-streaming bound: bytes
-//                    in flight matter);
-//   >= 3 row strips: 256-row tiles, 8 waves, one workgroup per CU (operand traffic per FLOP
-//                    matters; weight panels are re-read from the Infinity Cache).
-// Both are launched; each reads the row count on the device and one of them returns at once.
-// Kc (elements) is the fp32 kernel's chunking, so the slabs feed the same k_fc_reduce.
+// part[s][m][n] = sum over chunk s of X . W^T from the operands' planes of 16-bit terms.  Two shapes of one kernel, same
+// per-row arithmetic (a row's bits do not depend on which one ran): <= 2 row strips: 64-row tiles, 4 waves, two
+// workgroups per CU (weight streaming); >= 3 row strips: 256-row tiles, 8 waves, one workgroup per CU.  Both are launched;
+// each reads the row count on the device and one of them returns at once.  Kc (elements) is the fp32 kernels' chunking,
+// so the slabs feed the same k_fc_reduce.
 namespace {
 template <int P, bool F16, int CW> struct TermsShape {
     static constexpr size_t shm_w = (size_t)2 * P * (256 + BN * CW) * BK * sizeof(unsigned short);   // 144 KB (P = 3), 128 KB (P = 2)

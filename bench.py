@@ -128,7 +128,7 @@ def main():
                     help="images in flight per GPU in the timed region (each on its own az_ctx/stream); "
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra images-in-flight measurement")
-    ap.add_argument("--no-fast", action="store_true", help="skip the extra split-bf16 (gemm_mode 2) measurement")
+    ap.add_argument("--no-fast", action="store_true", help="skip the 16-bit-term modes (az_set_gemm_mode 2 / 3) measurement")
     ap.add_argument("--one-pass", action="store_true",
                     help="time the one-pass form (Tz <= 0 only: all levels' rois in one head pass) as the main measurement")
     ap.add_argument("--level-loop", action="store_true", help="(default since round 3) the level-by-level form is `value`")

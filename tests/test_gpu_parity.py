@@ -370,7 +370,7 @@ def test_fused_loop_vs_cpu_oracle_head(small, mods):
     Yall, Sall = net.ctx.last_candidates()
     assert Yall.shape == tr["Y_all"].shape
     np.testing.assert_allclose(Sall, tr["aScores"], rtol=0, atol=1e-4)
-    # px: fp32 head <= 1e-3; the split-bf16 int6 path (gemm_mode 2) keeps deltas within 1e-5, which a
+    # px: fp32 head <= 1e-3; the 16-bit-term int6 modes (gemm_mode 2 / 3) keep deltas within 1e-5, which a
     # 1700-px-wide unclipped box turns into <= 2e-2 px
     np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2 if net.ctx.gemm_mode else 1e-3)
     # top-300 sets agree except where scores tie within the tolerance
