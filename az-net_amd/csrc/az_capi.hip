@@ -98,6 +98,12 @@ struct az_ctx {
     // the last fetched level-loop search, per level: regions, zoomed regions, unique rois, pair-speculation rows (-1: none)
     int hint_P[AZ_MAX_LEVELS] = {0}, hint_PZ[AZ_MAX_LEVELS] = {0}, hint_U[AZ_MAX_LEVELS] = {0}, hint_SPN[AZ_MAX_LEVELS] = {0};
     int hint_h = -1, hint_w = -1, hint_nlev = 0;
+    // ... kept per image shape (a dataset mixes a few dozen shapes: each keeps the history of ITS last search; the fields
+    // above are the entry of the shape being launched / last fetched)
+    struct ShapeHint { int h, w, nlev; int rows[AZ_MAX_LEVELS], P[AZ_MAX_LEVELS], PZ[AZ_MAX_LEVELS], U[AZ_MAX_LEVELS], SPN[AZ_MAX_LEVELS];
+                       unsigned long long use; };
+    std::vector<ShapeHint> hints;
+    unsigned long long hint_clock = 0;
     int pair_env = -1;                        // AZ_PAIR_SPEC: 0 never, 1 by history (default), 2 always
     std::vector<std::pair<int, int>> nopair;  // image shapes whose pair-speculation rows outgrew the tables
     int full_env = -1;                        // AZ_FULL_SPEC: 0 never, 1 by history (default), 2 always
@@ -916,6 +922,44 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
     return AZ_OK;
 }
 
+// The history of an image shape's last level-loop search: into / out of the context's working fields.
+static void hint_load(az_ctx *c, int h, int w, int nlev)
+{
+    if (c->hint_h == h && c->hint_w == w && c->hint_nlev == nlev) return;
+    for (auto &e : c->hints)
+        if (e.h == h && e.w == w && e.nlev == nlev) {
+            std::memcpy(c->hint_rows, e.rows, sizeof(e.rows)); std::memcpy(c->hint_P, e.P, sizeof(e.P));
+            std::memcpy(c->hint_PZ, e.PZ, sizeof(e.PZ)); std::memcpy(c->hint_U, e.U, sizeof(e.U));
+            std::memcpy(c->hint_SPN, e.SPN, sizeof(e.SPN));
+            c->hint_h = h; c->hint_w = w; c->hint_nlev = nlev;
+            e.use = ++c->hint_clock;
+            return;
+        }
+    c->hint_h = -1; c->hint_w = -1; c->hint_nlev = 0;          // no search of this shape seen (yet)
+    std::memset(c->hint_rows, 0, sizeof(c->hint_rows));
+}
+
+static void hint_store(az_ctx *c)
+{
+    if (c->hint_h < 0) return;
+    az_ctx::ShapeHint *slot = nullptr;
+    for (auto &e : c->hints) if (e.h == c->hint_h && e.w == c->hint_w && e.nlev == c->hint_nlev) slot = &e;
+    if (!slot) {
+        if (c->hints.size() >= 64) {
+            size_t lru = 0;
+            for (size_t i = 1; i < c->hints.size(); ++i) if (c->hints[i].use < c->hints[lru].use) lru = i;
+            c->hints.erase(c->hints.begin() + (long)lru);
+        }
+        c->hints.emplace_back();
+        slot = &c->hints.back();
+        slot->h = c->hint_h; slot->w = c->hint_w; slot->nlev = c->hint_nlev;
+    }
+    std::memcpy(slot->rows, c->hint_rows, sizeof(slot->rows)); std::memcpy(slot->P, c->hint_P, sizeof(slot->P));
+    std::memcpy(slot->PZ, c->hint_PZ, sizeof(slot->PZ)); std::memcpy(slot->U, c->hint_U, sizeof(slot->U));
+    std::memcpy(slot->SPN, c->hint_SPN, sizeof(slot->SPN));
+    slot->use = ++c->hint_clock;
+}
+
 // Whole-tree speculation: should this search evaluate the rows of the image shape's FULL tree in one head pass and find
 // every level's outputs by window lookup?  It pays when the tree the context saw last for this shape is dense: the
 // level-by-level forms stream the int6 weights once per pass and pay each pass's fixed cost (RoIPool, reduce, int7, heads,
@@ -1243,6 +1287,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
+    hint_load(c, p->im_h, p->im_w, nlev);          // what this shape's last search looked like (decides the form below)
     bool stat = static_wanted(c, p, tune);
     if (stat) {
         if ((rc = ensure_static_plan(c, p, nlev)) != AZ_OK) return rc;
@@ -1496,6 +1541,7 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
             c->hint_SPN[l] = (in && ((q.pair_mask >> l) & 1)) ? h.SPN[l] : -1;
         }
         c->hint_h = q.p.im_h; c->hint_w = q.p.im_w; c->hint_nlev = nlev;
+        hint_store(c);
     }
     const int n = h.nsel;
     // (the candidate list stays readable only while no later search has been queued: it would be overwriting it)

@@ -152,3 +152,27 @@ def test_deep_tree_takes_the_whole_tree_pass_too(small, mods):
     for q in (0.2, 0.5):
         Tz = float(np.quantile(z, q))
         _same(_run(net, ffi, H, W, scale, Tz, False, pair_spec=False), _run(net, ffi, H, W, scale, Tz, True))
+
+
+def test_history_is_kept_per_image_shape(small, mods):
+    """A dataset mixes image shapes: each shape keeps the history of its own last search, so alternating shapes still
+    reach the speculative forms from their second search on."""
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="mixed")
+    shapes = [(600, 1000, 1.0), (375, 500, 1.6), (480, 640, 1.25)]
+    maps = [synth.make_feature_map(50 + i, synth.SMALL_DIMS["C"], synth.conv_out_size(int(round(H * sc))),
+                                   synth.conv_out_size(int(round(W * sc)))) for i, (H, W, sc) in enumerate(shapes)]
+    first, passes = {}, {}
+    for rnd in range(3):
+        for i, (H, W, sc) in enumerate(shapes):
+            net.set_conv(maps[i])
+            Y, S, st = net.propose(ffi.AzContext.make_params(H, W, sc, 0.0, static_tree=False), want_scores=True,
+                                   want_stats=True)
+            passes.setdefault(i, []).append(int(st.n_passes))
+            if rnd == 0:
+                first[i] = (Y, S)
+            else:
+                assert np.array_equal(Y, first[i][0]) and np.array_equal(S, first[i][1])
+    for i in range(len(shapes)):
+        assert passes[i][0] >= 2 and passes[i][1] == 1 and passes[i][2] == 1, passes
