@@ -67,6 +67,17 @@ struct az_ctx {
     double *specB1[2] = {nullptr, nullptr};
     int *spec_choff[2] = {nullptr, nullptr}, *spec_U[2] = {nullptr, nullptr};
     struct SpecCache { int h = -1, w = -1; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0; } spc[2];
+    // the pre-pass writes into the scratch buffers; its result is kept per image shape in exact-size buffers (a dataset
+    // mixes shapes: a shape seen before costs neither the pre-pass nor its host synchronisation) and spec_urois / specB1 /
+    // spec_choff / spec_U[defer] POINT at the entry of the shape in use
+    float *spec_scr_urois[2] = {nullptr, nullptr};
+    double *spec_scr_B1[2] = {nullptr, nullptr};
+    int *spec_scr_choff[2] = {nullptr, nullptr};
+    struct SpecEntry { int h = -1, w = -1, defer = 0; double scale = 0, min_side = 0; int P1 = 0, CH = 0, U = 0;
+                       float *urois = nullptr; double *B1 = nullptr; int *choff = nullptr, *Udev = nullptr;
+                       unsigned long long use = 0; };
+    std::vector<SpecEntry> spec_store;
+    unsigned long long spec_clock = 0;
     // Tz <= 0: the whole tree is a function of the image shape (az_static.hip); its rois / anchors / region -> row
     // map are kept per shape in exact-size HBM buffers (~100 B per roi: 70 KB for a 600x1000 image), least recently
     // used shapes are dropped beyond AZ_PLAN_CACHE entries; the per-level sizes stay on the host
@@ -272,7 +283,7 @@ int ensure_geom(az_ctx *c)
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
-    for (int i = 0; i < 2; ++i) { A(spec_urois[i], R * 5); A(specB1[i], R * 4); A(spec_choff[i], R); A(spec_U[i], 4); }
+    for (int i = 0; i < 2; ++i) { A(spec_scr_urois[i], R * 5); A(spec_scr_B1[i], R * 4); A(spec_scr_choff[i], R); }
     A(key_u, R * AZ_NSUB);
     A(choff_pair, R); A(crow, CH > 8192 ? CH : 8192);
     A(pred_v, R * AZ_NSUB * 4); A(score_v, R * AZ_NSUB); A(zoom_v, R); A(keep_v, R * AZ_NSUB); A(key_v, R * AZ_NSUB);
@@ -488,6 +499,8 @@ int az_destroy(az_ctx *c)
     for (void *p : c->allocs_det) hipFree(p);
     c->allocs_det.clear();
     for (auto *q : c->plans) { free_plan(q); delete q; }
+    for (auto &e : c->spec_store) for (void *q2 : {(void *)e.urois, (void *)e.B1, (void *)e.choff, (void *)e.Udev}) if (q2) hipFree(q2);
+    c->spec_store.clear();
     c->plans.clear();
     if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
     for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
@@ -772,19 +785,54 @@ static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
     auto &k = c->spc[defer];
     if (k.h == p->im_h && k.w == p->im_w && k.scale == p->scale && k.min_side == p->min_side)
         return AZ_OK;
+    auto use = [&](az_ctx::SpecEntry &e) {
+        c->spec_urois[defer] = e.urois; c->specB1[defer] = e.B1; c->spec_choff[defer] = e.choff; c->spec_U[defer] = e.Udev;
+        k.h = e.h; k.w = e.w; k.scale = e.scale; k.min_side = e.min_side; k.P1 = e.P1; k.CH = e.CH; k.U = e.U;
+        e.use = ++c->spec_clock;
+    };
+    for (auto &e : c->spec_store)
+        if (e.h == p->im_h && e.w == p->im_w && e.defer == defer && e.scale == p->scale && e.min_side == p->min_side) {
+            use(e);
+            return AZ_OK;
+        }
     hipStream_t s = c->stream;
-    azk_spec_prepass(s, c->cnt, c->B[0], c->specB1[defer], c->child, c->spec_choff[defer], c->spec_urois[defer], p->scale,
-                     p->min_side, c->maxR, c->maxCh, p->im_h, p->im_w, defer);
+    azk_spec_prepass(s, c->cnt, c->B[0], c->spec_scr_B1[defer], c->child, c->spec_scr_choff[defer], c->spec_scr_urois[defer],
+                     p->scale, p->min_side, c->maxR, c->maxCh, p->im_h, p->im_w, defer);
     HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->spec_U[defer], &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->h_cnt->err) {               // the speculative rows outgrow the context: take the multi-launch path
         c->nofuse_h = p->im_h; c->nofuse_w = p->im_w;
         k.h = -1;
         return AZ_OK;
     }
-    k.h = p->im_h; k.w = p->im_w; k.scale = p->scale; k.min_side = p->min_side;
-    k.P1 = c->h_cnt->specP1; k.CH = c->h_cnt->specCH; k.U = c->h_cnt->specU;
+    az_ctx::SpecEntry e;
+    e.h = p->im_h; e.w = p->im_w; e.defer = defer; e.scale = p->scale; e.min_side = p->min_side;
+    e.P1 = c->h_cnt->specP1; e.CH = c->h_cnt->specCH; e.U = c->h_cnt->specU;
+    if (hipMalloc((void **)&e.urois, (size_t)(e.U + 1) * 5 * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&e.B1, (size_t)(e.P1 + 1) * 4 * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&e.choff, (size_t)(e.P1 + 1) * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&e.Udev, 16) != hipSuccess) {
+        for (void *q2 : {(void *)e.urois, (void *)e.B1, (void *)e.choff, (void *)e.Udev}) if (q2) hipFree(q2);
+        return fail(c, AZ_ERR_HIP, "hipMalloc failed for a speculative pre-pass entry");
+    }
+    HIPCHK(c, hipMemcpyAsync(e.urois, c->spec_scr_urois[defer], (size_t)e.U * 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(e.B1, c->spec_scr_B1[defer], (size_t)e.P1 * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(e.choff, c->spec_scr_choff[defer], (size_t)e.P1 * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(e.Udev, &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (c->spec_store.size() >= 128) {
+        // drop the least recently used entry; captured launch sequences may hold its pointers: drop those too
+        size_t lru = 0;
+        for (size_t i = 1; i < c->spec_store.size(); ++i) if (c->spec_store[i].use < c->spec_store[lru].use) lru = i;
+        for (auto &g : c->graphs) hipGraphExecDestroy(g.second.exec);
+        c->graphs.clear();
+        auto &d = c->spec_store[lru];
+        for (int i = 0; i < 2; ++i) if (c->spec_urois[i] == d.urois) { c->spc[i].h = -1; }
+        for (void *q2 : {(void *)d.urois, (void *)d.B1, (void *)d.choff, (void *)d.Udev}) hipFree(q2);
+        c->spec_store.erase(c->spec_store.begin() + (long)lru);
+    }
+    c->spec_store.push_back(e);
+    use(c->spec_store.back());
     return AZ_OK;
 }
 
