@@ -46,22 +46,35 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 // (what the GEMM's epilogue multiplies its sums by; sw = the weights' power-of-two scale).  One launch: block maxima ->
 // atomicMax on the bits (|x| >= 0: unsigned order = float order) -> the last block to arrive writes the scales and
 // clears the scratch words sc[2], sc[3] for the next call.
-__global__ void __launch_bounds__(256) k_feat_scale(const float *__restrict__ feat, long long n, float *sc, float sw)
+__global__ void __launch_bounds__(1024) k_feat_scale(const float *__restrict__ feat, long long n, float *sc, float sw)
 {
-    __shared__ float wm[4];
+    __shared__ float wm[16];
     float m = 0.f;
     const long long n4 = n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (four independent loads in flight per thread: the loop is a chain of memory round trips otherwise)
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = reinterpret_cast<const float4 *>(feat)[i], b = reinterpret_cast<const float4 *>(feat)[i + stride],
+                     c = reinterpret_cast<const float4 *>(feat)[i + 2 * stride], d = reinterpret_cast<const float4 *>(feat)[i + 3 * stride];
+        const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+        const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4 *>(feat)[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     if (blockIdx.x == 0)
-        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(feat[i]));
+        for (long long t = (n4 << 2) + threadIdx.x; t < n; t += blockDim.x) m = fmaxf(m, fabsf(feat[t]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        m = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wm[w]);
         unsigned *w = reinterpret_cast<unsigned *>(sc);
         atomicMax(w + 2, __float_as_uint(m));
         __threadfence();
@@ -461,7 +474,7 @@ void azk_split_weight_planes(hipStream_t s, const float *in, unsigned short *out
 
 void azk_feat_scale(hipStream_t s, const float *feat, long long n, float *scales, float sw)
 {
-    hipLaunchKernelGGL(k_feat_scale, dim3(256), dim3(256), 0, s, feat, n, scales, sw);
+    hipLaunchKernelGGL(k_feat_scale, dim3(128), dim3(1024), 0, s, feat, n, scales, sw);
 }
 
 // part[s][m][n] = sum over chunk s of X . W^T from the operands' planes of 16-bit terms.  Two shapes of one kernel, same
