@@ -451,7 +451,7 @@ def main():
                ("level by level (the form every Tz > 0 takes; the context's last search of this shape having walked the "
                 "full tree, ONE head pass evaluates the full tree's unique rois and every level finds its outputs by RoIPool "
                 "window -- zoom selection, divide_region, _sift_dup, dedup all run): head passes of %s rows" % (prow if prow else "?")
-                if (prow and len(prow) == 1) else
+                if (prow and len(prow) == 1 and not st.static_plan and prow[0] > int(st.spec_rows) + 1) else
                 "level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
         out = {
             "metric": "AZ proposals/sec (600x1000 img)", "value": value, "unit": "proposals/s",
@@ -558,7 +558,7 @@ def main():
                                            "ONE head pass (az_static.hip); proposals and scores bit-identical to `value`'s. "
                                            "No Tz > 0 search can take this form."}
     # ---- the level loop WITHOUT the whole-tree pass (two head passes: speculative rows, then level 4 + pair rows) ------
-    if not one_pass_main and not args.no_level_loop and st.n_passes == 1:
+    if not one_pass_main and not args.no_level_loop and st.n_passes == 1 and int(st.pass_rows[0]) > int(st.spec_rows) + 1:
         pw = ffi.AzContext.make_params(H_IM, W_IM, scale0, args.tz, num_proposals=NUM_PROPOSALS, static_tree=False,
                                        full_spec=False)
         n_w = max(20, args.steps // 2)
