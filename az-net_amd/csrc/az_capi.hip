@@ -700,8 +700,9 @@ struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask;
 // (int6 on the 16-bit matrix cores, az_set_gemm_mode 2 / 3: a row costs a fraction of that, a launch somewhat more)
 static double pass_us(double rows, int parts = 0)
 {
-    if (parts == 2) { const double t = 85.0 + 0.25 * rows; return t < 100.0 ? 100.0 : t; }
-    if (parts == 3) { const double t = 125.0 + 0.43 * rows; return t < 150.0 ? 150.0 : t; }
+    // (measured: two terms 100-113 us at 48 rows, 365 us at 670; three terms 125 us and 630 us)
+    if (parts == 2) { const double t = 85.0 + 0.42 * rows; return t < 100.0 ? 100.0 : t; }
+    if (parts == 3) { const double t = 110.0 + 0.78 * rows; return t < 130.0 ? 130.0 : t; }
     const double t = 60.0 + 1.4 * rows;
     return t < 92.0 ? 92.0 : t;
 }
