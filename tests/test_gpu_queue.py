@@ -90,3 +90,45 @@ def test_queue_depth_is_two_and_needs_fixed_counts(mods):
         net.ctx.last_candidates()
     net.ctx.propose_fetch()
     assert net.ctx.last_candidates()[0].shape[0] > 300
+
+
+@pytest.mark.parametrize("kind", ["nan_premise", "whole_tree_miss"])
+def test_rerun_under_graph_replay_with_a_staged_record(mods, kind):
+    """A search that has to be repeated in another form inside propose_fetch (err bit 32: a NaN zoom score breaks the
+    one-pass premise; err bit 256: a pruned tree needs a window the whole-tree pass lacks), with hipGraph replay ON and
+    its result record staged into a caller's device buffer: the record is restaged by the rerun and equals the fetched
+    result, which equals the plain search."""
+    import torch
+    from aznet_hip import dist as azdist
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    if kind == "nan_premise":
+        head["bz"] = np.full(1, np.nan, dtype=np.float32)
+    fmap = torch.from_numpy(synth.make_feature_map(5, synth.SMALL_DIMS["C"], 38, 63)).cuda()
+    k = 300
+    ref = HipAZNet(head, name="g_ref")
+    ref.set_conv(fmap)
+    if kind == "nan_premise":
+        p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k)                  # one-pass plan -> level loop
+        pref = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k, static_tree=False, full_spec=False)
+    else:
+        ref.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0, tune=True))
+        z = np.sort(ref.ctx.last_anchors()[1].astype(np.float64))
+        Tz = float(z[int(0.3 * (len(z) - 1))])
+        p = ffi.AzContext.make_params(600, 1000, 1.0, Tz, num_proposals=k, static_tree=False, full_spec=True)
+        pref = ffi.AzContext.make_params(600, 1000, 1.0, Tz, num_proposals=k, static_tree=False, full_spec=False,
+                                         pair_spec=False)
+    Yw, Sw = ref.propose(pref, want_scores=True)
+    net = HipAZNet(head, name="g_run")
+    net.ctx.set_graphs(True)
+    layout = ffi.AzContext.result_record_layout(k)
+    buf = torch.zeros(layout[0], dtype=torch.uint8, device="cuda")
+    for rnd in range(3):                       # (first un-captured, then captured, then replayed)
+        buf.zero_()
+        net.ctx.propose_launch(p, fmap=fmap, producer_done=True)
+        net.ctx.stage_result(buf.data_ptr(), layout[0])
+        Y, S = net.ctx.propose_fetch(want_scores=True)
+        assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (kind, rnd)
+        torch.cuda.synchronize()
+        rec = azdist.unpack_device_record(buf.cpu().numpy(), layout, k)
+        assert rec is not None and np.array_equal(rec[0], Yw) and np.array_equal(rec[1], Sw), (kind, rnd)
