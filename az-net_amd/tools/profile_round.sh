@@ -51,7 +51,7 @@ for s in $sets; do
   case $s in
     # kernels whose name contains k_fc_splitk per image: the whole-tree pass's int6 (k_fc_splitk12, 688 rows) and int7 = 2
     # (the search's first, history-less image takes the two-pass form: one stray pair of launches in the averages)
-    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
+    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
     # the level loop without the whole-tree pass (AZ_FULL_SPEC=0): 48-row pass (k_fc_splitk int6, int7), 670-row pass
     # (k_fc_splitk12 int6, int7) = 4
     twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "twopass_" 4 ;;

@@ -128,6 +128,7 @@ def main():
                     help="images in flight per GPU in the timed region (each on its own az_ctx/stream); "
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra images-in-flight measurement")
+    ap.add_argument("--no-two-pass", action="store_true", help="skip the level loop without the whole-tree pass (extra key)")
     ap.add_argument("--no-fast", action="store_true", help="skip the 16-bit-term modes (az_set_gemm_mode 2 / 3) measurement")
     ap.add_argument("--one-pass", action="store_true",
                     help="time the one-pass form (Tz <= 0 only: all levels' rois in one head pass) as the main measurement")
@@ -558,7 +559,8 @@ def main():
                                            "ONE head pass (az_static.hip); proposals and scores bit-identical to `value`'s. "
                                            "No Tz > 0 search can take this form."}
     # ---- the level loop WITHOUT the whole-tree pass (two head passes: speculative rows, then level 4 + pair rows) ------
-    if not one_pass_main and not args.no_level_loop and st.n_passes == 1 and int(st.pass_rows[0]) > int(st.spec_rows) + 1:
+    if (not one_pass_main and not args.no_level_loop and not args.no_two_pass and st.n_passes == 1 and
+            int(st.pass_rows[0]) > int(st.spec_rows) + 1):
         pw = ffi.AzContext.make_params(H_IM, W_IM, scale0, args.tz, num_proposals=NUM_PROPOSALS, static_tree=False,
                                        full_spec=False)
         n_w = max(20, args.steps // 2)
