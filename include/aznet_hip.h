@@ -98,7 +98,9 @@ typedef struct {
     int32_t static_plan;                  /* 1: Tz <= 0, all levels went through one head pass of
                                              spec_rows rois (params.reserved bit 5 turns this off)  */
     int32_t n_passes;                     /* head passes (RoIPool -> int6 -> int7 -> heads) the search made */
-    int32_t pass_rows[AZ_MAX_LEVELS];     /* rois each of them evaluated (speculative rows included)       */
+    int32_t pass_rows[AZ_MAX_LEVELS];     /* rois each of them evaluated (speculative rows included); a search in
+                                             its whole-tree form: ONE pass of the image shape's full tree
+                                             (pass_rows[0] > spec_rows, static_plan = 0)                   */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
