@@ -146,6 +146,7 @@ struct az_ctx {
     unsigned long long *nms_mask = nullptr;
     long long *nms_keep = nullptr;
     unsigned char *h_nms = nullptr;     // host-mapped block of az_nms's small case
+    unsigned char *h_nmsb = nullptr; size_t h_nmsb_cap = 0; int *nms_done = nullptr; int nms_seq = 0;   // ... of az_nms_batched's
     // tuner (az_eval.hip): anchor history of the last search, score pool over an image set
     double *hisB = nullptr;
     float *hisZ = nullptr;
@@ -513,6 +514,8 @@ int az_destroy(az_ctx *c)
         if (c->ev_res[i]) hipEventDestroy(c->ev_res[i]);
     }
     if (c->h_nms) hipHostFree(c->h_nms);
+    if (c->h_nmsb) hipHostFree(c->h_nmsb);
+    if (c->nms_done) hipFree(c->nms_done);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -2076,6 +2079,49 @@ int az_nms_batched(az_ctx *c, const float *dets, const int32_t *offsets, int n_g
     if (total > 0 && (!dets || !keep)) return fail(c, AZ_ERR_INVALID, "az_nms_batched: NULL array");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    static const bool poll = !(getenv("AZ_NMS_POLL") && !atoi(getenv("AZ_NMS_POLL")));
+    if (!small.empty() && poll && !c->profiling && total <= 16384) {
+        // The reference's call site (apply_nms: 20 classes x <= 100 boxes per image): everything -- boxes, offsets, group
+        // list, keep lists, counts -- lives in ONE host-mapped block; one launch, no copy commands, and the host polls a
+        // flag that the last workgroup to finish raises (a stream synchronisation plus five copies cost 70 of 96 us).
+        const size_t o_off = ((size_t)total * 5 * sizeof(float) + 15) & ~(size_t)15;
+        const size_t o_sel = o_off + (((size_t)n_groups + 1) * sizeof(int) + 15 & ~(size_t)15);
+        const size_t o_keep = o_sel + ((small.size() * sizeof(int) + 15) & ~(size_t)15);
+        const size_t o_nk = o_keep + (size_t)total * sizeof(long long);
+        const size_t o_flag = o_nk + (((size_t)n_groups * sizeof(int) + 15) & ~(size_t)15);
+        const size_t need = o_flag + 64;
+        if (need > c->h_nmsb_cap) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->h_nmsb) hipHostFree(c->h_nmsb);
+            c->h_nmsb = nullptr; c->h_nmsb_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_nmsb, need + need / 2, hipHostMallocMapped));
+            c->h_nmsb_cap = need + need / 2;
+        }
+        if (!c->nms_done) {
+            HIPCHK(c, hipMalloc((void **)&c->nms_done, 16));
+            HIPCHK(c, hipMemsetAsync(c->nms_done, 0, 16, s));
+        }
+        unsigned char *b = c->h_nmsb;
+        std::memcpy(b, dets, (size_t)total * 5 * sizeof(float));
+        std::memcpy(b + o_off, offsets, ((size_t)n_groups + 1) * sizeof(int));
+        std::memcpy(b + o_sel, small.data(), small.size() * sizeof(int));
+        std::memset(b + o_nk, 0, (size_t)n_groups * sizeof(int));
+        volatile int *flag = (volatile int *)(b + o_flag);
+        const int seq = ++c->nms_seq;
+        *flag = 0;
+        azk_nms_small(s, (const float *)b, (const int *)(b + o_off), (const int *)(b + o_sel), (int)small.size(), thresh,
+                      (long long *)(b + o_keep), (int *)(b + o_nk), c->nms_done, (int *)(b + o_flag), seq);
+        bool got = false;
+        for (int spin = 0; spin < 400000 && !got; ++spin) got = *flag == seq;
+        if (!got) HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        const long long *hk = (const long long *)(b + o_keep);
+        const int *hn = (const int *)(b + o_nk);
+        for (int g : small) {
+            n_keep[g] = hn[g];
+            for (int k = 0; k < hn[g]; ++k) keep[offsets[g] + k] = hk[(size_t)offsets[g] + k];
+        }
+    } else
     if (!small.empty()) {
         int rc;
         if ((rc = ev_grow(c, 0, &c->ev_a, (size_t)total * 5 * sizeof(float))) != AZ_OK) return rc;

@@ -330,7 +330,7 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
 // many groups of <= azk_nms_small_max() boxes in one launch: group g = dets[goff[g] .. goff[g+1]); gsel lists
 // the groups to process; keep[goff[g] ..] gets the kept group-local indices, nkeep[g] their number
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
-                   long long *keep, int *nkeep);
+                   long long *keep, int *nkeep, int *done_cnt = nullptr, int *done_flag = nullptr, int done_seq = 0);
 int azk_nms_small_max();
 // one problem of n <= azk_nms_small_max() boxes in one launch (dets / keep / nkeep may be host-mapped)
 void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep);

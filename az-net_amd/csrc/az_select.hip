@@ -422,7 +422,8 @@ constexpr int NMS_SMALL_NT = 1024;       // 16 waves: the suppression words are 
                                         // ~100 dependent cycles each -- 4 waves took 49 us of a 60 us kernel at 256 boxes
 __global__ void __launch_bounds__(NMS_SMALL_NT)
 k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const int *__restrict__ gsel,
-            int n_single, double thresh, long long *__restrict__ keep, int *__restrict__ nkeep)
+            int n_single, double thresh, long long *__restrict__ keep, int *__restrict__ nkeep,
+            int *done_cnt, int *done_flag, int done_seq)
 {
     __shared__ float sd[NMS_SMALL][5];                     // sorted: x1, y1, x2, y2, area
     __shared__ int sorder[NMS_SMALL];
@@ -540,6 +541,15 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
         //  the stream's completion signal, so everything before it must be visible system-wide first)
         __threadfence_system();
         if (lane == 0) nkeep[g] = nk;
+        // (batched form on host-mapped memory: the LAST workgroup to finish raises the flag the host polls)
+        if (done_flag && lane == 0) {
+            __threadfence_system();
+            if (atomicAdd(done_cnt, 1) == (int)gridDim.x - 1) {
+                *done_cnt = 0;
+                __threadfence_system();
+                *(volatile int *)done_flag = done_seq;
+            }
+        }
     }
 }
 
@@ -599,16 +609,17 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
 int azk_nms_small_max() { return NMS_SMALL; }
 
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
-                   long long *keep, int *nkeep)
+                   long long *keep, int *nkeep, int *done_cnt, int *done_flag, int done_seq)
 {
     if (n_sel > 0)
-        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(NMS_SMALL_NT), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep);
+        hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(NMS_SMALL_NT), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep,
+                           done_cnt, done_flag, done_seq);
 }
 
 void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep)
 {
     hipLaunchKernelGGL(k_nms_small, dim3(1), dim3(NMS_SMALL_NT), 0, s, dets, (const int *)nullptr, (const int *)nullptr, n, thresh,
-                       keep, nkeep);
+                       keep, nkeep, (int *)nullptr, (int *)nullptr, 0);
 }
 
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
