@@ -146,6 +146,7 @@ struct az_ctx {
     unsigned long long *nms_mask = nullptr;
     long long *nms_keep = nullptr;
     unsigned char *h_nms = nullptr;     // host-mapped block of az_nms's small case
+    unsigned char *h_nmsg = nullptr; size_t h_nmsg_cap = 0;     // ... of az_nms's general case (keep list + count)
     unsigned char *h_nmsb = nullptr; size_t h_nmsb_cap = 0; int *nms_done = nullptr; int nms_seq = 0;   // ... of az_nms_batched's
     // tuner (az_eval.hip): anchor history of the last search, score pool over an image set
     double *hisB = nullptr;
@@ -515,6 +516,7 @@ int az_destroy(az_ctx *c)
     }
     if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_nmsb) hipHostFree(c->h_nmsb);
+    if (c->h_nmsg) hipHostFree(c->h_nmsg);
     if (c->nms_done) hipFree(c->nms_done);
     if (c->h_Y) { hipHostFree(c->h_Y); hipHostFree(c->h_S); }
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1900,6 +1902,32 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
     int *nk = c->nms_order + c->nms_cap;      // spare int after the order array
     HIPCHK(c, hipMemcpyAsync(c->nms_dets, dets, (size_t)n * 5 * 4, hipMemcpyHostToDevice, s));
     if (!(c->profiling & 4)) clear_events(c);
+    static const bool poll_g = !(getenv("AZ_NMS_POLL") && !atoi(getenv("AZ_NMS_POLL")));
+    if (poll_g && !c->profiling) {
+        // keep list and count straight into host-mapped memory, the count last (k_nms_scan): no copy-back commands, no
+        // stream synchronisation -- the host polls the count
+        const size_t need = (size_t)n * 8 + 64;
+        if (need > c->h_nmsg_cap) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            if (c->h_nmsg) hipHostFree(c->h_nmsg);
+            c->h_nmsg = nullptr; c->h_nmsg_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&c->h_nmsg, need * 2, hipHostMallocMapped));
+            c->h_nmsg_cap = need * 2;
+        }
+        volatile int *hn = (volatile int *)c->h_nmsg;
+        long long *hk = (long long *)(c->h_nmsg + 64);
+        *hn = -1;
+        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, hk, (int *)c->h_nmsg);
+        bool got = false;
+        for (long spin = 0; spin < 4000000 && !got; ++spin) got = *hn >= 0;
+        if (!got) HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        const int h_nk2 = *hn;
+        if (h_nk2 < 0 || h_nk2 > n) return fail(c, AZ_ERR_HIP, "az_nms: the kernels left no result");
+        *n_keep = h_nk2;
+        for (int i = 0; i < h_nk2; ++i) keep[i] = hk[i];
+        return AZ_OK;
+    }
     { Timed t(c, "nms", n);
       azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, c->nms_keep, nk); }
     int h_nk = 0;

@@ -410,6 +410,9 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
         }
         __syncthreads();
     }
+    // (the count is written LAST, behind a system-wide fence: az_nms polls it in host-mapped memory)
+    __threadfence_system();
+    __syncthreads();
     if (threadIdx.x == 0) *nkeep = s_nk;
 }
 
