@@ -356,8 +356,8 @@ int ensure_host(az_ctx *c, int cap)
 
 int set_count(az_ctx *c, int *dptr, int v)
 {
-    HIPCHK(c, hipMemcpyAsync(dptr, &v, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // v lives on this frame
+    // (a 32-bit fill carries the value in the command: nothing on this frame to keep alive, no synchronisation)
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)dptr, v, 1, c->stream));
     return AZ_OK;
 }
 
