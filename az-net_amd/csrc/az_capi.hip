@@ -137,6 +137,9 @@ struct az_ctx {
     int det_n6 = 0, det_n7 = 0, det_ncls = 0, det_S6 = 1, det_S7 = 1;
     std::vector<void *> allocs_det;
     float *dW6 = nullptr, *db6 = nullptr, *dW7 = nullptr, *db7 = nullptr, *dWt = nullptr, *dbt = nullptr;
+    // 16-bit-term modes: the detection head's fc6 on the same kernel as int6 (its own weight planes, weight scale and
+    // -- two fp16 terms -- its own {pool5 scale, 1 / (sx * sw)} pair)
+    unsigned short *dW6p = nullptr; float *dgscale = nullptr; float det_w6_scale = 0.f;
     float *dh6 = nullptr, *dh7 = nullptr, *dpart = nullptr, *dprob_u = nullptr, *ddelta_u = nullptr, *dprob = nullptr;
     double *dpred_u = nullptr, *dpred = nullptr;
     // nms scratch (grown on demand)
@@ -1973,6 +1976,11 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
     }
     A(dprob_u, R * ncls); A(ddelta_u, R * 4 * ncls); A(dpred_u, R * ncls * 4); A(dprob, R * ncls); A(dpred, R * ncls * 4);
     if (!c->pool5) { A(pool5, R * K6); }     // normally the AZ head's buffer is shared
+    c->dW6p = nullptr; c->dgscale = nullptr;
+    if (c->gemm_parts && c->pool5p && azk_fc_terms_prepare(c->gemm_parts) == 0) {
+        A(dW6p, (size_t)c->gemm_parts * azk_weight_plane_elems(n6, (int)K6)); A(dgscale, 4);
+        HIPCHK(c, hipMemsetAsync(c->dgscale, 0, 4 * sizeof(float), c->stream));
+    }
 #undef A
     if (!c->head_loaded) { c->d.C = C; c->d.pooled = 7; c->d.K6 = (int)K6; }
     {
@@ -1985,6 +1993,16 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
         HIPCHK(c, hipMemcpy(c->dpart, W6, (size_t)n6 * K6 * 4, hipMemcpyHostToDevice));
         azk_permute_k(c->stream, c->dpart, tmp, n6, C, 1);          // bin-major columns, like the AZ head
         azk_tile_weights(c->stream, tmp, c->dW6, n6, (int)K6);
+        if (c->dW6p) {
+            c->det_w6_scale = 0.f;
+            if (c->gemm_parts == 2) {
+                float mx = 0.f;
+                for (size_t i = 0, n = (size_t)n6 * K6; i < n; ++i) { const float a = fabsf(W6[i]); if (a > mx) mx = a; }
+                c->det_w6_scale = 1.f;
+                if (mx > 0.f && mx < INFINITY) { int e; (void)frexpf(mx, &e); c->det_w6_scale = ldexpf(1.f, 15 - e); }
+            }
+            azk_split_weight_planes(c->stream, tmp, c->dW6p, n6, (int)K6, c->gemm_parts, c->det_w6_scale);
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(tmp, W7, (size_t)n7 * n6 * 4, hipMemcpyHostToDevice));
         azk_tile_weights(c->stream, tmp, c->dW7, n7, n6);
@@ -2018,10 +2036,20 @@ static void launch_det_head(az_ctx *c, const int *Uptr, int im_h, int im_w, doub
         if (can12) azk_fc_gemm12(c->stream, x, ldx, W, K, Uptr, c->maxR, N, K, S, azk_fc_chunk(K, S), part);
         else azk_fc_gemm(c->stream, x, ldx, W, K, Uptr, c->maxR, N, K, S, part);
     };
+    const bool terms = c->gemm_parts && c->dW6p;             // (16-bit-term modes: fc6, 86 % of this head's FLOPs, as int6)
+    if (terms && c->gemm_parts == 2)
+        azk_feat_scale(c->stream, c->feat, (long long)d.C * d.H * d.W, c->dgscale, c->det_w6_scale);
     { Timed t(c, "det_roi_pool", 0);
-      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, nullptr, 0, 0, 0); }
+      azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, c->urois, Uptr, c->maxR, c->pool5, terms ? c->pool5p : nullptr,
+                   terms ? azk_act_plane_elems(c->maxR, K6) : 0, terms ? c->gemm_parts : 0, 0, 0,
+                   (terms && c->gemm_parts == 2) ? c->dgscale : nullptr); }
     { Timed t(c, "det_fc6_gemm", 0, 1);
-      gemm(c->pool5, K6, c->dW6, c->det_n6, K6, c->det_S6, c->dpart); }
+      if (terms)
+          azk_fc_gemm_terms(c->stream, c->pool5p, K6, azk_act_plane_elems(c->maxR, K6), c->dW6p, K6,
+                            azk_weight_plane_elems(c->det_n6, K6), Uptr, c->maxR, c->det_n6, K6, c->det_S6,
+                            azk_fc_chunk(K6, c->det_S6), c->dpart, c->gemm_parts, c->dgscale);
+      else
+          gemm(c->pool5, K6, c->dW6, c->det_n6, K6, c->det_S6, c->dpart); }
     { Timed t(c, "det_fc6_reduce", 0);
       azk_fc_reduce(c->stream, c->dpart, c->db6, Uptr, c->maxR, c->det_n6, c->det_S6, c->dh6, c->det_n6, 1); }
     { Timed t(c, "det_fc7_gemm", 0, 1);

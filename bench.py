@@ -669,6 +669,26 @@ def main():
                                           "note": "peak = dense fp16 / bf16 MFMA at 2.4 GHz; under these MFMAs the chip sustains "
                                                   "1.77-1.80 GHz (profiles/r03_mode*_pmc_2.csv: GRBM_GUI_ACTIVE), where the "
                                                   "matrix pipe is 71-77 % busy"}
+            # config 3 in this mode: the detection head's fc6 runs on the same kernel as int6
+            if not args.no_extras and args.tz <= 0:
+                import time as _t
+                nf.set_conv(conv)
+                pdet = mk(False)
+                Ypd = nf.propose(pdet)
+                detm = HipDetNet(synth.make_det_head(seed=99), nf)
+                for _ in range(3):
+                    scm, bxm = detm.detect(Ypd, 1.0, (H_IM, W_IM), 1. / 16., 10000, 1e-14)
+                torch.cuda.synchronize()
+                t0 = _t.perf_counter()
+                for _ in range(20):
+                    nf.propose(pdet)
+                t1 = _t.perf_counter()
+                for _ in range(20):
+                    detm.detect(Ypd, 1.0, (H_IM, W_IM), 1. / 16., 10000, 1e-14)
+                t2 = _t.perf_counter()
+                ent["shared_detection"] = {"az_propose_ms": (t1 - t0) / 20 * 1e3, "az_detect_ms": (t2 - t1) / 20 * 1e3,
+                                           "note": "config 3's two GPU parts in this mode (per-class NMS as in `shared_detection`)"}
+                del detm
             ent["note"] = ("opt-in (az_set_gemm_mode %d), not `value`: int6 leaves the fp32-input MFMA; everything else is "
                            "unchanged.  The error columns are the head's outputs against an f64 evaluation on %d rois" % (gm, nr))
             modes["gemm_mode_%d" % gm] = ent
