@@ -52,6 +52,9 @@ struct az_ctx {
     float *rois = nullptr, *urois = nullptr;
     long long *key = nullptr, *ckey = nullptr;
     int *grp = nullptr, *index = nullptr, *inv = nullptr, *choff = nullptr, *bc_c = nullptr, *bc_z = nullptr;
+    // inv_index of the ODD levels of a search (even levels and the unit entry points: `inv`): a level's fused geometry
+    // kernel writes the next level's inv_index while its second workgroup may still be reading this level's
+    int *inv_odd = nullptr;
     unsigned char *first = nullptr, *cflag = nullptr, *zflag = nullptr, *keep_u = nullptr;
     double *ubox = nullptr, *pred_u = nullptr, *Yall = nullptr, *Z = nullptr, *child = nullptr, *Yout = nullptr;
     float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr;
@@ -89,12 +92,20 @@ struct az_ctx {
         double *ubox = nullptr;
         int *reg_u = nullptr, *cand_src = nullptr, *meta = nullptr;
         unsigned long long last_use = 0;
-        // whole-tree speculation (SearchPlan::full): window table over the plan's rows, the speculative rows' map, the
-        // pass's rois = the plan's non-root rows ++ extra rows (speculative rows whose window the plan lacks) ++ the root
-        unsigned long long *htab = nullptr; unsigned hT = 0;
-        int *spec_map = nullptr, *full_meta = nullptr;
-        float *full_urois = nullptr; double *full_ubox = nullptr;
-        int Ufull = 0, full_state = 0;        // 0: not built, 1: ready, -1: cannot be used for this shape
+        // whole-tree speculation (SearchPlan::full): window table over the pass's rows, the speculative rows' map, the
+        // pass's rois.  Two row sets per shape:
+        //   fs[0] "tree":    the plan's non-root rows (the unique rois of the FULL tree) ++ extra rows (speculative rows
+        //                    whose window the plan lacks) ++ the root.  Serves a search whose tree is the full tree; a
+        //                    pruned tree may keep another _sift_dup survivor (same 10-px hash, other window) -> err bit 256.
+        //   fs[1] "closure": one row per distinct RoIPool window among ALL regions any pruning can produce -- level l+1 =
+        //                    every child of every region of level l, no _sift_dup (whichever duplicate survives is among
+        //                    them) -- ++ the root.  Serves every Tz; never misses.
+        struct FullSet {
+            unsigned long long *htab = nullptr; unsigned hT = 0;
+            int *spec_map = nullptr, *full_meta = nullptr;
+            float *full_urois = nullptr; double *full_ubox = nullptr;
+            int Ufull = 0, full_state = 0;    // 0: not built, 1: ready, -1: cannot be used for this shape
+        } fs[2];
     };
     std::vector<StaticPlan *> plans;
     StaticPlan *plan = nullptr;               // the plan of the search being launched / in flight
@@ -118,8 +129,13 @@ struct az_ctx {
     int pair_env = -1;                        // AZ_PAIR_SPEC: 0 never, 1 by history (default), 2 always
     std::vector<std::pair<int, int>> nopair;  // image shapes whose pair-speculation rows outgrew the tables
     int full_env = -1;                        // AZ_FULL_SPEC: 0 never, 1 by history (default), 2 always
-    bool full_now = false;                    // the search being launched takes the whole-tree pass
+    int full_now = 0;                         // the search being launched takes the whole-tree pass: 1 = tree rows, 2 = closure
     int last_full = 0;
+    // the closure's rows of the shape last looked at by the cost model (0: not built): what the one pass would cost
+    int n_rerun_total = 0;                    // searches this context has had to run twice (any reason) since it was created
+    // cost of one head pass (RoIPool + int6 + reduce + int7 + heads) at a few row counts, measured on THIS device with HIP
+    // events the first time a search is launched (calibrate_passes): what the choice between the search forms goes by
+    struct PassCal { int state = 0; int n = 0; int rows[6] = {0}; double us[6] = {0}; } cal;   // state 0: not yet, 1: measured, -1: off
     double *pred_w = nullptr; float *score_w = nullptr, *zoom_w = nullptr; unsigned char *keep_w = nullptr; unsigned *key_w = nullptr;   // second *_v set
     int last_pair_mask = 0;                   // levels whose head pass carried pair-speculation rows (search in flight / last)
     // pair speculation: all-children offsets / child -> row of the level whose pass carries the rows; looked-up outputs
@@ -151,6 +167,7 @@ struct az_ctx {
     unsigned char *h_nms = nullptr;     // host-mapped block of az_nms's small case
     unsigned char *h_nmsg = nullptr; size_t h_nmsg_cap = 0;     // ... of az_nms's general case (keep list + count)
     unsigned char *h_nmsb = nullptr; size_t h_nmsb_cap = 0; int *nms_done = nullptr; int nms_seq = 0;   // ... of az_nms_batched's
+    unsigned nms_tag = 0;               // sequence number carried by every word an NMS kernel writes to host-mapped memory
     // tuner (az_eval.hip): anchor history of the last search, score pool over an image set
     double *hisB = nullptr;
     float *hisZ = nullptr;
@@ -173,7 +190,7 @@ struct az_ctx {
     // into a pinned slot of its own; az_propose_fetch then only waits for that copy's event.
     struct PendingSearch {
         az_params p{};
-        int nlev = 0, is_static = 0, defer = 0, pair_mask = 0, npass = 0;
+        int nlev = 0, is_static = 0, defer = 0, pair_mask = 0, npass = 0, full = 0, reruns = 0;
         int pass_src[AZ_MAX_LEVELS + 2] = {0};
         void *stage_dst = nullptr;          // az_propose_stage_result_dev target
         size_t stage_cap = 0;
@@ -280,7 +297,7 @@ int ensure_geom(az_ctx *c)
         c->cnt = (AzCounts *)blk;
     }
     A(B[0], R * 4); A(B[1], R * 4); A(rois, R * 5); A(urois, R * 5); A(key, R); A(ckey, CH);
-    A(grp, R); A(index, R); A(inv, R); A(choff, R); A(bc_c, (R * AZ_NSUB + 255) / 256 + 1);
+    A(grp, R); A(index, R); A(inv, R); A(inv_odd, R); A(choff, R); A(bc_c, (R * AZ_NSUB + 255) / 256 + 1);
     A(bc_z, (R * AZ_NSUB + 255) / 256 + 1);
     A(first, CH > R ? CH : R); A(cflag, R * AZ_NSUB); A(zflag, R); A(keep_u, R * AZ_NSUB);
     A(ubox, R * 4); A(pred_u, R * AZ_NSUB * 4); A(Yall, CAND * 4); A(Z, R * 4); A(child, CH * 4);
@@ -438,12 +455,14 @@ int ev_grow(az_ctx *c, int i, void **slot, size_t bytes)
 
 void free_plan(az_ctx::StaticPlan *q)
 {
-    for (void *p : {(void *)q->urois, (void *)q->ubox, (void *)q->reg_u, (void *)q->cand_src, (void *)q->meta,
-                    (void *)q->htab, (void *)q->spec_map, (void *)q->full_meta, (void *)q->full_urois, (void *)q->full_ubox})
+    for (void *p : {(void *)q->urois, (void *)q->ubox, (void *)q->reg_u, (void *)q->cand_src, (void *)q->meta})
         if (p) hipFree(p);
     q->urois = nullptr; q->ubox = nullptr; q->reg_u = nullptr; q->cand_src = nullptr; q->meta = nullptr;
-    q->htab = nullptr; q->spec_map = nullptr; q->full_meta = nullptr; q->full_urois = nullptr; q->full_ubox = nullptr;
-    q->full_state = 0;
+    for (auto &f : q->fs) {
+        for (void *p : {(void *)f.htab, (void *)f.spec_map, (void *)f.full_meta, (void *)f.full_urois, (void *)f.full_ubox})
+            if (p) hipFree(p);
+        f = az_ctx::StaticPlan::FullSet();
+    }
 }
 
 int check_geom(az_ctx *c)
@@ -458,6 +477,25 @@ int check_ready(az_ctx *c, bool need_feat)
     if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "az_load_head has not been called");
     if (need_feat && !c->feat) return fail(c, AZ_ERR_STATE, "no feature map set");
     return AZ_OK;
+}
+
+// NMS results in host-mapped memory are polled by the host.  Words written by the GPU may become visible out of order
+// (posted PCIe writes), so each word carries the call's sequence number and is taken only once it shows it.
+unsigned nms_next_tag(az_ctx *c)
+{
+    do { ++c->nms_tag; } while (c->nms_tag == 0u || (c->nms_tag & 0x3FFFFFu) == 0u);
+    return c->nms_tag;
+}
+
+// true when every one of the n keep words shows `tag` (spins a bounded number of times on each)
+bool nms_keep_tagged(const long long *hk, int n, unsigned tag, long spins)
+{
+    for (int i = 0; i < n; ++i) {
+        const volatile long long *w = hk + i;
+        long k = 0;
+        while ((unsigned)((unsigned long long)*w >> 32) != tag) if (++k > spins) return false;
+    }
+    return true;
 }
 
 }  // namespace
@@ -700,22 +738,101 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
 }
 
 // Which form of the search a call takes.
-struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; bool full; };
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; int full; /* 0 / 1 tree rows / 2 closure */ };
 
-// Cost model of one head pass on the int6 GEMM (us), from the measured launch shapes (profiles/): weight-streaming
-// bound up to ~40 rows, then ~1.45 us per row; and what a head pass costs besides int6 (RoIPool, reduce, int7, heads,
-// the level's geometry kernel).
-// (int6 on the 16-bit matrix cores, az_set_gemm_mode 2 / 3: a row costs a fraction of that, a launch somewhat more)
-static double pass_us(double rows, int parts = 0)
+// Cost of one head pass (RoIPool, int6, reduce, int7, heads) at `rows` rois, in us: measured on this device at a few row
+// counts the first time the context launches a search (calibrate_passes) and interpolated; until then (or with
+// AZ_PASS_CAL=0) the figures of the round-3 profiles: weight-streaming bound up to ~40 rows, then ~1.4 us per row.
+// What a level costs besides its head pass (its geometry kernel and the kernel boundaries) is GEOM_US; a window lookup
+// stage LOOKUP_US.
+static double pass_us(const az_ctx *c, double rows)
 {
-    // (measured: two terms 100-113 us at 48 rows, 365 us at 670; three terms 125 us and 630 us)
-    if (parts == 2) { const double t = 85.0 + 0.42 * rows; return t < 100.0 ? 100.0 : t; }
-    if (parts == 3) { const double t = 110.0 + 0.78 * rows; return t < 130.0 ? 130.0 : t; }
-    const double t = 60.0 + 1.4 * rows;
-    return t < 92.0 ? 92.0 : t;
+    const auto &k = c->cal;
+    if (k.state == 1 && k.n >= 2) {
+        if (rows <= k.rows[0]) return k.us[0];
+        for (int i = 1; i < k.n; ++i)
+            if (rows <= k.rows[i] || i == k.n - 1)
+                return k.us[i - 1] + (k.us[i] - k.us[i - 1]) * (rows - k.rows[i - 1]) / (double)(k.rows[i] - k.rows[i - 1]);
+    }
+    // (int6 on the 16-bit matrix cores, az_set_gemm_mode 2 / 3: a row costs a fraction of that, a launch somewhat more.
+    //  Measured: two terms 100-113 us at 48 rows, 365 us at 670; three terms 125 us and 630 us -- int6 alone)
+    double t;
+    if (c->gemm_parts == 2) { t = 85.0 + 0.42 * rows; t = t < 100.0 ? 100.0 : t; }
+    else if (c->gemm_parts == 3) { t = 110.0 + 0.78 * rows; t = t < 130.0 ? 130.0 : t; }
+    else { t = 60.0 + 1.4 * rows; t = t < 92.0 ? 92.0 : t; }
+    return t + 50.0;
 }
-constexpr double PASS_OVERHEAD_US = 90.0, LOOKUP_US = 8.0;
+constexpr double PASS_OVERHEAD_US = 40.0, LOOKUP_US = 8.0;     // (PASS_OVERHEAD_US: the level's geometry kernel + boundaries)
 constexpr unsigned AZ_TAB_ROOT_HOST = 0x1FFFu;      // (az_geom_dev.h: AZ_TAB_ROOT)
+
+// Measure pass_us on this device: whole head passes over synthetic rois (a grid of ~64-px boxes on the current map) at a
+// few row counts, HIP events on the ctx stream, best of three each; ~10 ms, once per context, outside any capture and with
+// no search queued.  The forms' costs differ by tens of us per image and boxes of one pool differ by 5-10 %: literals tuned
+// on one box pick the wrong form on another.  AZ_PASS_CAL=0 keeps the literals.
+static int calibrate_passes(az_ctx *c)
+{
+    auto &k = c->cal;
+    if (k.state != 0) return AZ_OK;
+    { const char *e = getenv("AZ_PASS_CAL"); if (e && !atoi(e)) { k.state = -1; return AZ_OK; } }
+    if (!c->feat || !c->pend.empty() || c->d.H <= 0 || c->d.W <= 0) return AZ_OK;       // (next time)
+    k.state = -1;                                                                      // (any failure below: literals)
+    hipStream_t s = c->stream;
+    const int sizes[] = {48, 112, 176, 352, 704, 1408};
+    int nsz = 0;
+    for (int v : sizes) if (v + 1 < c->maxR) ++nsz;
+    if (nsz < 2) return AZ_OK;
+    const int maxrows = sizes[nsz - 1];
+    {   // rois: boxes of ~4 x 4 map cells walking over the map (what the deep levels look like)
+        std::vector<float> r((size_t)maxrows * 5);
+        const float fw = (float)c->d.W / c->spatial_scale, fh = (float)c->d.H / c->spatial_scale;
+        for (int i = 0; i < maxrows; ++i) {
+            const float x = fmodf(37.0f * i, fw > 80.f ? fw - 72.f : 1.f), y = fmodf(53.0f * i, fh > 80.f ? fh - 72.f : 1.f);
+            r[5 * (size_t)i] = 0.f; r[5 * (size_t)i + 1] = x; r[5 * (size_t)i + 2] = y;
+            r[5 * (size_t)i + 3] = x + 63.f; r[5 * (size_t)i + 4] = y + 63.f;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->urois, r.data(), r.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) {
+        if (ea) hipEventDestroy(ea);
+        (void)hipGetLastError();
+        return AZ_OK;
+    }
+    const int prof = c->profiling;
+    c->profiling = 0;
+    c->cand_n = -1;
+    bool ok = true;
+    for (int i = 0; i < nsz && ok; ++i) {
+        HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+        ok = set_count(c, &c->cnt->U[0], sizes[i]) == AZ_OK;
+        double best = 1e30;
+        for (int rep = 0; rep < 4 && ok; ++rep) {
+            prep_scale(c);
+            ok = hipEventRecord(ea, s) == hipSuccess;
+            launch_head(c, &c->cnt->U[0], 0, 1, 1, 0.0, c->zoom_u, c->score_u, c->delta_u, 0.0, false, 0, nullptr, nullptr, sizes[i]);
+            ok = ok && hipEventRecord(eb, s) == hipSuccess && hipEventSynchronize(eb) == hipSuccess;
+            float ms = 0.f;
+            ok = ok && hipEventElapsedTime(&ms, ea, eb) == hipSuccess;
+            if (rep > 0 && ms * 1e3 < best) best = ms * 1e3;
+        }
+        k.rows[i] = sizes[i]; k.us[i] = best;
+    }
+    hipEventDestroy(ea); hipEventDestroy(eb);
+    c->profiling = prof;
+    c->npass = 0;
+    (void)hipGetLastError();
+    if (!ok) return AZ_OK;
+    for (int i = 1; i < nsz; ++i) if (!(k.us[i] > k.us[i - 1])) k.us[i] = k.us[i - 1] + 1.0;    // (monotone)
+    k.n = nsz;
+    k.state = 1;
+    if (getenv("AZ_FULL_DEBUG")) {
+        fprintf(stderr, "az: head-pass cost on this device (rows: us):");
+        for (int i = 0; i < nsz; ++i) fprintf(stderr, " %d: %.1f", k.rows[i], k.us[i]);
+        fprintf(stderr, "\n");
+    }
+    return AZ_OK;
+}
 
 // Pair speculation: the head pass of level l also evaluates one row per distinct RoIPool window among ALL children of
 // its regions, so that level l+1 needs no pass of its own (az_level.hip).  Worth it when most regions zoom: the extra
@@ -739,8 +856,8 @@ static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool f
             // rows the speculation adds: what it added last time, else level l+1's unique rois scaled by parents / zoomed parents
             const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
                                                  : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
-            const double with = pass_us(c->hint_U[l] + S, c->gemm_parts) + PASS_OVERHEAD_US + LOOKUP_US;
-            const double without = pass_us(c->hint_U[l], c->gemm_parts) + pass_us(c->hint_U[l + 1], c->gemm_parts) + 2 * PASS_OVERHEAD_US;
+            const double with = pass_us(c, c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
+            const double without = pass_us(c, c->hint_U[l]) + pass_us(c, c->hint_U[l + 1]) + 2 * PASS_OVERHEAD_US;
             want = with < without && c->hint_U[l] + S + 2 < c->maxR;
         }
         if (want) { mask |= 1 << l; ++l; }          // level l+1 is looked up: it has no pass to carry rows
@@ -778,8 +895,8 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     q.pair_mask = pair_plan(c, p, nlev, q.n_spec, q.fused_lv, q.lv_limit);
     // whole-tree speculation (decided and prepared by az_propose_launch: full_prepare): one head pass over the rows of
     // the image shape's full tree, every level's outputs by window lookup -- no deferred root, no pair rows
-    q.full = c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit >= q.n_spec && c->plan &&
-             c->plan->full_state == 1 && plan_is_for(*c->plan, p, nlev);
+    q.full = (c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit >= q.n_spec && c->plan &&
+              c->plan->fs[c->full_now - 1].full_state == 1 && plan_is_for(*c->plan, p, nlev)) ? c->full_now : 0;
     if (q.full) { q.defer_root = false; q.pair_mask = 0; }
     return q;
 }
@@ -1017,85 +1134,171 @@ static void hint_store(az_ctx *c)
     slot->use = ++c->hint_clock;
 }
 
-// Whole-tree speculation: should this search evaluate the rows of the image shape's FULL tree in one head pass and find
-// every level's outputs by window lookup?  It pays when the tree the context saw last for this shape is dense: the
-// level-by-level forms stream the int6 weights once per pass and pay each pass's fixed cost (RoIPool, reduce, int7, heads,
-// a geometry kernel), the whole-tree pass pays the rows the tree does not have.  Builds what the form needs (the shape's
-// plan, the non-deferred speculative pre-pass, the window table, the row map) outside any graph capture; sets
-// c->full_now.  params.reserved bit 8: never, bit 9: whenever the shape allows (tests); AZ_FULL_SPEC=0 / 2 likewise.
+// Whole-tree speculation: should this search evaluate, in ONE head pass, a shape-static superset of the rows its tree can
+// need and find every level's outputs by window lookup?  Two supersets (StaticPlan::fs): the unique rois of the shape's FULL
+// tree (fewest rows; right only if the tree turns out full -- a pruned tree may keep another _sift_dup survivor, err bit
+// 256 -> the search is repeated level by level) and the CLOSURE over all survivor choices (~12 % more rows at 600x1000;
+// right for every tree).  It pays when the tree is dense: the level-by-level forms stream the int6 weights once per pass
+// and pay each pass's fixed cost (RoIPool, reduce, int7, heads, a geometry kernel), the whole-tree pass pays the rows the
+// tree does not have.  The decision is by ROW COUNTS: what the shape's previous search would have cost in the
+// level-by-level form the context would pick for it (pair_plan) against one pass of the superset's rows, with the pass
+// costs measured on this device (pass_us).  A full-tree history takes the tree rows, anything else the closure.
+// Builds what the form needs (the shape's plan, the non-deferred speculative pre-pass, the window table, the row map)
+// outside any graph capture; sets c->full_now.  params.reserved bit 8: never; bit 9: whenever the shape allows (tests) --
+// the tree rows, or with bit 10 the closure; AZ_FULL_SPEC=0 / 2 / 3 likewise (3 = closure whenever possible).
+static int build_full_set(az_ctx *c, const az_params *p, int nlev, int variant)
+{
+    az_ctx::StaticPlan &k = *c->plan;
+    az_ctx::StaticPlan::FullSet &f = k.fs[variant];
+    const auto &sp = c->spc[0];
+    hipStream_t s = c->stream;
+    auto grab = [&](void **q, size_t bytes) { return hipMalloc(q, bytes + 256) == hipSuccess; };
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        for (void *q : {(void *)f.htab, (void *)f.spec_map, (void *)f.full_meta, (void *)f.full_urois, (void *)f.full_ubox}) if (q) hipFree(q);
+        f = az_ctx::StaticPlan::FullSet();
+        f.full_state = -1;
+        return (int)AZ_OK;
+    };
+    if (sp.U > 64) return give_up();
+    const int root = k.Utot - 1;                   // the plan's last row
+    int base_rows = 0;                             // rows of the pass before the extra rows
+    struct Tmp { float *all = nullptr; int *newrow = nullptr; ~Tmp() { if (all) hipFree(all); if (newrow) hipFree(newrow); } } tmp;
+    int N = 0;
+    if (variant == 1) {
+        // every region any pruning can produce, level by level (no _sift_dup: whichever duplicate survives is among them)
+        const int capAll = (int)AZ_TAB_ROOT_HOST - 2;
+        if (!grab((void **)&tmp.all, (size_t)capAll * 5 * sizeof(float)) || !grab((void **)&tmp.newrow, (size_t)capAll * sizeof(int)))
+            return give_up();
+        const double rootb[4] = {0.0, 0.0, p->im_w - 1.0, p->im_h - 1.0};           // test.py:355
+        HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+        HIPCHK(c, hipMemcpyAsync(c->Z, rootb, sizeof(rootb), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));                                          // (`rootb` lives on this frame)
+        int n_cur = 1;
+        for (int l = 0; l < nlev; ++l) {
+            if (N + n_cur > capAll) return give_up();
+            azk_closure_rois(s, c->Z, n_cur, p->scale, tmp.all + (size_t)N * 5);
+            N += n_cur;
+            if (l + 1 == nlev) break;
+            int rc = set_count(c, &c->cnt->PZ[0], n_cur);
+            if (rc) return rc;
+            azk_divide(s, &c->cnt->PZ[0], &c->cnt->CH[0], &c->cnt->err, c->maxR, c->maxCh, c->Z, p->min_side, c->choff,
+                       c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
+            HIPCHK(c, hipMemcpyAsync(c->h_cnt, c->cnt, sizeof(AzCounts), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            const int n_next = c->h_cnt->CH[0];
+            if (c->h_cnt->err || n_next > c->maxR) {
+                HIPCHK(c, hipMemsetAsync(c->cnt, 0, sizeof(AzCounts), s));
+                return give_up();
+            }
+            if (n_next == 0) break;
+            HIPCHK(c, hipMemcpyAsync(c->Z, c->child, (size_t)n_next * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+            n_cur = n_next;
+        }
+    }
+    const int cap = (variant == 1 ? N : k.Utot) + sp.U + 1;
+    unsigned T = 64; while (T < 2u * (unsigned)cap) T <<= 1;
+    if (cap > c->maxR || cap >= (int)AZ_TAB_ROOT_HOST ||
+        !grab((void **)&f.htab, (size_t)T * 8) || !grab((void **)&f.spec_map, (size_t)sp.U * sizeof(int)) ||
+        !grab((void **)&f.full_meta, 16) || !grab((void **)&f.full_urois, (size_t)cap * 5 * sizeof(float)) ||
+        !grab((void **)&f.full_ubox, (size_t)cap * 4 * sizeof(double)))
+        return give_up();
+    f.hT = T;
+    HIPCHK(c, hipMemsetAsync(f.full_meta, 0, 16, s));
+    int h[4] = {0, 0, 0, 0};
+    if (variant == 1) {
+        azk_full_tab_build(s, tmp.all, N, 0, c->spatial_scale, f.htab, T, f.full_meta + 2);
+        azk_closure_compact(s, tmp.all, N, c->spatial_scale, f.htab, T, tmp.newrow, f.full_urois, f.full_ubox, f.full_meta + 3,
+                            f.full_meta + 2);
+        HIPCHK(c, hipMemcpyAsync(h, f.full_meta, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h[2]) return give_up();
+        base_rows = h[3];
+    } else {
+        HIPCHK(c, hipMemcpyAsync(f.full_urois, k.urois, (size_t)root * 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(f.full_ubox, k.ubox, (size_t)root * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        azk_full_tab_build(s, k.urois, k.Utot, root, c->spatial_scale, f.htab, T, f.full_meta + 2);
+        base_rows = root;
+    }
+    // every row of the speculative layout (levels 1-3) -> its row in this pass; windows the rows above lack become extra rows
+    azk_full_map(s, c->spec_urois[0], sp.U, c->spatial_scale, f.htab, T, base_rows, cap, f.full_urois, f.full_ubox, f.spec_map,
+                 f.full_meta + 1, f.full_meta + 2);
+    HIPCHK(c, hipMemcpyAsync(h, f.full_meta, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (h[2] || (variant == 1 && h[1] != 0)) return give_up();       // (the closure holds every speculative row by construction)
+    f.Ufull = base_rows + h[1] + 1;
+    // the root: the pass's last row (RoIPool treats the tail of a launch cooperatively)
+    HIPCHK(c, hipMemcpyAsync(f.full_urois + (size_t)(f.Ufull - 1) * 5, k.urois + (size_t)root * 5, 5 * sizeof(float),
+                             hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(f.full_ubox + (size_t)(f.Ufull - 1) * 4, k.ubox + (size_t)root * 4, 4 * sizeof(double),
+                             hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(f.full_meta, &f.Ufull, sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    f.full_state = 1;
+    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: whole-tree rows for (%dx%d), %s: %d (full tree %d, closure regions %d)\n",
+                                         p->im_h, p->im_w, variant ? "closure" : "tree", f.Ufull, k.Utot, N);
+    return AZ_OK;
+}
+
+// What the level-by-level form the context would pick for this shape (pair_plan on the same history) costs, in us.
+static double level_forms_cost(az_ctx *c, int nlev, int n_spec, int specU, int pair_mask)
+{
+    double t = pass_us(c, specU) + PASS_OVERHEAD_US;
+    for (int l = n_spec; l < nlev; ++l) {
+        if (c->hint_U[l] <= 0) break;
+        if ((pair_mask >> l) & 1) {
+            const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
+                                                 : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
+            t += pass_us(c, c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
+            ++l;
+        } else
+            t += pass_us(c, c->hint_U[l]) + PASS_OVERHEAD_US;
+    }
+    return t;
+}
+
 static int full_prepare(az_ctx *c, const az_params *p, int nlev, bool tune)
 {
-    c->full_now = false;
+    c->full_now = 0;
     if (tune || (p->reserved & (1 | 2 | 16 | 256)) || !p->fixed_num) return AZ_OK;
     if (c->full_env < 0) { const char *e = getenv("AZ_FULL_SPEC"); c->full_env = e ? atoi(e) : 1; }
-    const bool forced = (p->reserved & 512) || c->full_env == 2;
+    const bool forced = (p->reserved & 512) || c->full_env >= 2;
     if (!forced && c->full_env == 0) return AZ_OK;
-    const SearchPlan q0 = plan_search(c, p, nlev, tune);        // (full_now is false: the other form's plan)
+    const SearchPlan q0 = plan_search(c, p, nlev, tune);        // (full_now is 0: the other form's plan)
     if (!(q0.fused && q0.fused_lv && q0.n_spec == 3 && q0.lv_limit >= q0.n_spec && nlev > q0.n_spec)) return AZ_OK;
-    // By history: only when the previous search of this image shape walked the FULL tree (every region zoomed at every
-    // level but the last).  A pruned tree may keep another _sift_dup survivor than the full tree does (same 10-px hash,
-    // other coordinates, other RoIPool window): such a window is not among the pass's rows and the search has to be
-    // repeated level by level -- the closure over all survivor choices would be 773 rows instead of 688 at 600x1000.
-    bool have_hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
-    for (int l = 0; have_hist && l + 1 < nlev; ++l) have_hist = c->hint_P[l] > 0 && c->hint_PZ[l] == c->hint_P[l];
+    const bool have_hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
+    // the previous search of this shape walked the FULL tree (every region zoomed at every level but the last)?
+    bool full_hist = have_hist;
+    for (int l = 0; full_hist && l + 1 < nlev; ++l) full_hist = c->hint_P[l] > 0 && c->hint_PZ[l] == c->hint_P[l];
     if (!forced && !have_hist) return AZ_OK;
+    int variant = forced ? (((p->reserved & 1024) || c->full_env == 3) ? 1 : 0) : (full_hist ? 0 : 1);
     int rc;
     if ((rc = ensure_static_plan(c, p, nlev)) != AZ_OK) return rc;
     if (!static_plan_matches(c, p, nlev)) return AZ_OK;
     az_ctx::StaticPlan &k = *c->plan;
-    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: full_prepare (%dx%d) plan state %d\n", p->im_h, p->im_w, k.full_state);
-    if (k.full_state < 0) return AZ_OK;
+    if (k.fs[variant].full_state < 0) return AZ_OK;
+    double now = 0.0;
+    if (!forced) {
+        // cheapest the superset can be: the full tree's rows.  Not worth building anything if even that loses.
+        now = level_forms_cost(c, nlev, q0.n_spec, c->spc[q0.defer_root ? 1 : 0].h == p->im_h ? c->spc[q0.defer_root ? 1 : 0].U : 48,
+                               q0.pair_mask);
+        const double best = pass_us(c, k.Utot) + PASS_OVERHEAD_US + LOOKUP_US * (nlev - q0.n_spec);
+        if (!(best + 10.0 < now)) return AZ_OK;
+    }
     // the non-deferred layout of the speculative rows (the root is row 0 there; here it maps to the pass's last row)
     SearchPlan q1 = q0; q1.defer_root = false;
     if ((rc = ensure_spec_cache(c, p, q1)) != AZ_OK) return rc;
     const auto &sp = c->spc[0];
     if (!(sp.h == p->im_h && sp.w == p->im_w && sp.scale == p->scale && sp.min_side == p->min_side)) return AZ_OK;
-    if (k.full_state == 0) {
-        hipStream_t s = c->stream;
-        const int cap = k.Utot + sp.U + 1;
-        unsigned T = 64; while (T < 2u * (unsigned)cap) T <<= 1;
-        auto grab = [&](void **q, size_t bytes) { return hipMalloc(q, bytes + 256) == hipSuccess; };
-        if (cap > c->maxR || cap >= (int)AZ_TAB_ROOT_HOST || sp.U > 64 ||
-            !grab((void **)&k.htab, (size_t)T * 8) || !grab((void **)&k.spec_map, (size_t)sp.U * sizeof(int)) ||
-            !grab((void **)&k.full_meta, 16) || !grab((void **)&k.full_urois, (size_t)cap * 5 * sizeof(float)) ||
-            !grab((void **)&k.full_ubox, (size_t)cap * 4 * sizeof(double))) {
-            (void)hipGetLastError();
-            k.full_state = -1;
-            return AZ_OK;
-        }
-        k.hT = T;
-        const int root = k.Utot - 1;                   // the plan's last row
-        HIPCHK(c, hipMemsetAsync(k.full_meta, 0, 16, s));
-        HIPCHK(c, hipMemcpyAsync(k.full_urois, k.urois, (size_t)root * 5 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(k.full_ubox, k.ubox, (size_t)root * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
-        azk_full_tab_build(s, k.urois, k.Utot, root, c->spatial_scale, k.htab, T, k.full_meta + 2);
-        azk_full_map(s, c->spec_urois[0], sp.U, c->spatial_scale, k.htab, T, root, cap, k.full_urois, k.full_ubox, k.spec_map,
-                     k.full_meta + 1, k.full_meta + 2);
-        int h[4] = {0, 0, 0, 0};
-        HIPCHK(c, hipMemcpyAsync(h, k.full_meta, 16, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        if (h[2]) { k.full_state = -1; return AZ_OK; }
-        k.Ufull = root + h[1] + 1;
-        // the root: the pass's last row (RoIPool treats the tail of a launch cooperatively)
-        HIPCHK(c, hipMemcpyAsync(k.full_urois + (size_t)(k.Ufull - 1) * 5, k.urois + (size_t)root * 5, 5 * sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(k.full_ubox + (size_t)(k.Ufull - 1) * 4, k.ubox + (size_t)root * 4, 4 * sizeof(double),
-                                 hipMemcpyDeviceToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(k.full_meta, &k.Ufull, sizeof(int), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));
-        k.full_state = 1;
-    }
+    if (k.fs[variant].full_state == 0 && (rc = build_full_set(c, p, nlev, variant)) != AZ_OK) return rc;
+    if (k.fs[variant].full_state != 1) return AZ_OK;
     if (!forced) {
-        // the previous search of this shape: rows of the levels behind the speculative ones, passes they would take
-        int later = 0, lv = 0;
-        for (int l = q0.n_spec; l < nlev; ++l) { later += c->hint_U[l]; lv += c->hint_U[l] > 0; }
-        const double now = pass_us(sp.U, c->gemm_parts) + PASS_OVERHEAD_US +
-                           (lv ? pass_us(later, c->gemm_parts) + ((lv + 1) / 2) * PASS_OVERHEAD_US + LOOKUP_US : 0.0);
-        const double full = pass_us(k.Ufull, c->gemm_parts) + PASS_OVERHEAD_US + LOOKUP_US * (nlev - q0.n_spec);
+        const double full = pass_us(c, k.fs[variant].Ufull) + PASS_OVERHEAD_US + LOOKUP_US * (nlev - q0.n_spec);
         if (!(full + 10.0 < now)) return AZ_OK;
     }
-    c->full_now = true;
-    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: whole-tree pass on (%dx%d): %d rows (plan %d)\n", p->im_h, p->im_w, k.Ufull, k.Utot);
+    c->full_now = variant + 1;
+    if (getenv("AZ_FULL_DEBUG")) fprintf(stderr, "az: whole-tree pass on (%dx%d): %d rows (%s; plan %d)\n", p->im_h, p->im_w,
+                                         k.fs[variant].Ufull, variant ? "closure" : "tree rows", k.Utot);
     return AZ_OK;
 }
 
@@ -1168,8 +1371,11 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
                    c->choff_all, c->child, c->ckey, nullptr, nullptr, nullptr, 0, nullptr);
         azk_spec_rois(s, c->B[0], c->B[1], c->child, c->cnt, c->maxR, p->scale, c->urois);
     }
-    const bool full = plan.full;
-    const az_ctx::StaticPlan *fp = full ? c->plan : nullptr;
+    const bool full = plan.full != 0;
+    const az_ctx::StaticPlan::FullSet *fp = full ? &c->plan->fs[plan.full - 1] : nullptr;
+    // inv_index of level l (two buffers by level parity: k_level_geom's candidate-copy workgroup reads level l's while
+    // its chain workgroup writes level l+1's)
+    auto INV = [&](int l) { return (l & 1) ? c->inv_odd : c->inv; };
     // (whole-tree speculation: the *_v sets alternate by level -- a level's geometry kernel reads its own set while it
     //  writes the next level's)
     auto Vp = [&](int l) { return (full && (l & 1)) ? c->pred_w : c->pred_v; };
@@ -1192,7 +1398,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         AzFusedArgs a;
         a.cnt = c->cnt;
         a.B[0] = c->B[0]; a.B[1] = c->B[1]; a.srcB[0] = c->srcB[0]; a.srcB[1] = c->srcB[1];
-        a.index = c->index; a.inv = c->inv; a.zr = c->zr; a.choff = c->choff; a.csrc = c->csrc;
+        a.index = c->index; a.inv = INV(n_spec); a.zr = c->zr; a.choff = c->choff; a.csrc = c->csrc;
         const int dslot = defer_root ? 1 : 0;
         a.choff_all = c->spec_choff[dslot]; a.specB1 = c->specB1[dslot];
         a.reset = 1; a.specP1 = c->spc[dslot].P1; a.specCH = c->spc[dslot].CH; a.specU = c->spc[dslot].U;
@@ -1231,7 +1437,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             a.B = c->B[cur]; a.Bnext = c->B[cur ^ 1];
             a.pred_u = have_v ? Vp(l) : c->pred_u; a.score_u = have_v ? Vs(l) : c->score_u;
             a.zoom_u = have_v ? Vz(l) : c->zoom_u; a.keep_u = have_v ? Vk(l) : c->keep_u; a.Uptr = Uptr;
-            a.urois = c->urois; a.index = c->index; a.inv = c->inv; a.ubox = c->ubox;
+            a.urois = c->urois; a.index = c->index; a.inv = INV(l); a.inv_next = INV(l + 1); a.ubox = c->ubox;
             a.Yall = c->Yall; a.Sall = c->Sall;
             a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
             a.batch = p->batch_size; a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
@@ -1250,7 +1456,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         if (!fused_lv || l > plan.lv_limit) {   // (otherwise the fused predecessor -- spec_levels or level_geom -- has done this already)
           Timed t(c, "rois_dedup", l);
           azk_rois_dedup(s, c->B[cur], Pptr, c->maxR, p->scale, (float)p->dedup, p->batch_size, c->rois, c->key,
-                         c->grp, c->first, c->index, c->inv, c->urois, c->ubox, Uptr); }
+                         c->grp, c->first, c->index, INV(l), c->urois, c->ubox, Uptr); }
         // The last level of a default search with a fixed proposal count: its candidates, its counters and the final
         // top-k come from ONE launch (az_static.hip: k_final_select) instead of k_flags, k_compact, k_rank_count and
         // k_rank_scatter; the tail kernel emits the selection keys.  (params.reserved bits 1 / 3 keep the separate
@@ -1275,7 +1481,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         if (final_fused) {
             Timed t(c, "final_select", l);
             AzFinalArgs a;
-            a.cnt = c->cnt; a.level = l; a.inv = c->inv; a.key_u = have_v ? Vy(l) : c->key_u;
+            a.cnt = c->cnt; a.level = l; a.inv = INV(l); a.key_u = have_v ? Vy(l) : c->key_u;
             a.pred_u = have_v ? Vp(l) : c->pred_u;
             a.score_u = have_v ? Vs(l) : c->score_u; a.zoom_u = have_v ? Vz(l) : c->zoom_u;
             a.Yall = c->Yall; a.Sall = c->Sall; a.Tz = p->Tz;
@@ -1287,11 +1493,11 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         }
         if (tune) {
             Timed t(c, "record_anchors", l);
-            azk_record_anchors(s, c->cnt, l, c->maxR, c->capHis, c->B[cur], c->inv, c->zoom_u, c->hisB, c->hisZ,
+            azk_record_anchors(s, c->cnt, l, c->maxR, c->capHis, c->B[cur], INV(l), c->zoom_u, c->hisB, c->hisZ,
                                &c->cnt->nhis, &c->cnt->err);
         }
         { Timed t(c, "flags_compact", l);
-          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], c->inv, have_v ? Vp(l) : c->pred_u,
+          azk_flags_compact(s, c->cnt, l, c->maxR, c->maxCand, c->B[cur], INV(l), have_v ? Vp(l) : c->pred_u,
                             have_v ? Vs(l) : c->score_u,
                             have_v ? Vz(l) : c->zoom_u, (tune && l == 0) ? 0.0 : p->Tz, p->min_side, l == 0 && !tune, c->cflag,
                             c->zflag, c->bc_c, c->bc_z, c->Yall, c->Sall, c->Z, c->zr); }
@@ -1344,6 +1550,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipSetDevice(c->device));
     if (!(c->profiling & 4)) clear_events(c);
     c->cand_n = -1;
+    if (c->cal.state == 0 && (rc = calibrate_passes(c)) != AZ_OK) return rc;
     hint_load(c, p->im_h, p->im_w, nlev);          // what this shape's last search looked like (decides the form below)
     bool stat = static_wanted(c, p, tune);
     if (stat) {
@@ -1351,9 +1558,9 @@ int az_propose_launch(az_ctx *c, const az_params *p)
         stat = static_plan_matches(c, p, nlev);          // (a tree that outgrows the plan buffers: level loop)
     }
     c->last_static = stat ? 1 : 0;
-    c->full_now = false;
+    c->full_now = 0;
     if (!stat && (rc = full_prepare(c, p, nlev, tune)) != AZ_OK) return rc;
-    c->last_full = (!stat && plan_search(c, p, nlev, tune).full) ? 1 : 0;
+    c->last_full = !stat ? plan_search(c, p, nlev, tune).full : 0;
     if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
@@ -1419,6 +1626,7 @@ int az_propose_launch(az_ctx *c, const az_params *p)
     HIPCHK(c, hipGetLastError());
     az_ctx::PendingSearch q;
     q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
+    q.full = c->last_full;
     q.npass = c->npass;
     q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
     q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
@@ -1501,6 +1709,8 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
         st->spec_rows = h.specU;
         st->root_deferred = q.defer;
         st->static_plan = q.is_static;
+        st->search_form = q.is_static ? 4 : (q.full == 2 ? 3 : (q.full == 1 ? 2 : (q.pair_mask ? 1 : 0)));
+        st->n_reruns = q.reruns;
         const int *hc = reinterpret_cast<const int *>(&h);
         for (int i = 0; i < q.npass && i < AZ_MAX_LEVELS; ++i) {
             const int r = q.pass_src[i] >= 0 ? hc[q.pass_src[i]] : -q.pass_src[i] - 1;
@@ -1532,6 +1742,8 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
         c->feat = cur_feat; c->d.H = cur_H; c->d.W = cur_W;
         if (rc2) return rc2;
         c->pend.back().feat = q.feat; c->pend.back().fH = q.fH; c->pend.back().fW = q.fW;
+        c->pend.back().reruns = q.reruns + 1;
+        ++c->n_rerun_total;
         if (q.stage_dst && (rc2 = az_propose_stage_result_dev(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
         return fetch_entry(c, c->pend.size() - 1, boxes_out, scores_out, cap, n_out, st);
     };
@@ -1622,9 +1834,45 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
 int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_out, int cap, int *n_out,
                az_stats *st)
 {
+    // (launch + fetch of the SAME search: with another search still queued the fetch would return that one's result)
+    if (c && !c->pend.empty())
+        return fail(c, AZ_ERR_STATE, "az_propose: a search launched with az_propose_launch is still queued, fetch it first");
     int rc = az_propose_launch(c, p);
     if (rc) return rc;
     return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+}
+
+int az_measure_box(az_ctx *c, double *mfma_f32_tflops, double *copy_tb_per_s)
+{
+    if (!c) return AZ_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int rc = azk_measure_box(c->stream, mfma_f32_tflops, copy_tb_per_s, (size_t)1 << 30);
+    if (rc) { (void)hipGetLastError(); return fail(c, AZ_ERR_HIP, std::string("az_measure_box: ") + hipGetErrorString((hipError_t)rc)); }
+    return AZ_OK;
+}
+
+int az_set_pass_costs(az_ctx *c, int n, const int32_t *rows, const double *us)
+{
+    if (!c || n < 0 || n == 1 || n > 6 || (n && (!rows || !us))) return fail(c, AZ_ERR_INVALID, "az_set_pass_costs: 0 or 2..6 points");
+    for (int i = 0; i < n; ++i)
+        if (rows[i] <= 0 || !(us[i] > 0) || (i && (rows[i] <= rows[i - 1] || us[i] < us[i - 1])))
+            return fail(c, AZ_ERR_INVALID, "az_set_pass_costs: rows and costs must ascend");
+    c->cal = az_ctx::PassCal();
+    for (int i = 0; i < n; ++i) { c->cal.rows[i] = rows[i]; c->cal.us[i] = us[i]; }
+    c->cal.n = n;
+    c->cal.state = n ? 1 : 0;
+    return AZ_OK;
+}
+
+int az_get_pass_costs(az_ctx *c, int32_t *rows_out, double *us_out, int cap, int *n_out)
+{
+    if (!c || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_get_pass_costs: bad arguments");
+    const int n = c->cal.state == 1 ? c->cal.n : 0;
+    *n_out = n;
+    if (n > cap) return fail(c, AZ_ERR_CAPACITY, "az_get_pass_costs: cap too small");
+    for (int i = 0; i < n; ++i) { if (rows_out) rows_out[i] = c->cal.rows[i]; if (us_out) us_out[i] = c->cal.us[i]; }
+    return AZ_OK;
 }
 
 int az_result_record_layout(int k, size_t *bytes, size_t *n_off, size_t *boxes_off, size_t *scores_off)
@@ -1647,6 +1895,9 @@ int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
     if (!dst_dev || cap_bytes < bytes) return fail(c, AZ_ERR_INVALID, "az_propose_stage_result_dev: destination too small");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(dst_dev, c->cnt, bytes, hipMemcpyDeviceToDevice, c->stream));
+    // az_propose_fetch waits for the slot's event: recorded again HERE, behind the staging copy, so that "the record is
+    // staged when az_propose_fetch returns" holds (the launch recorded it behind the host copy only)
+    if (q.copied) HIPCHK(c, hipEventRecord(c->ev_res[q.slot], c->stream));
     q.stage_dst = dst_dev; q.stage_cap = cap_bytes;
     return AZ_OK;
 }
@@ -1865,26 +2116,31 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         long long *hk = (long long *)(c->h_nms + 5120);                 // [256] i64 = 2048 B, then the count
         int *hn = (int *)(c->h_nms + 5120 + 2048);
         std::memcpy(hd, dets, (size_t)n * 5 * sizeof(float));
-        *hn = -1;
+        const unsigned tag = nms_next_tag(c);
+        *hn = 0;
         if (!(c->profiling & 4)) clear_events(c);
         { Timed t(c, "nms", n);
-          azk_nms_one_small(s, hd, n, thresh, hk, hn); }
-        // The kernel writes the count last (behind a system-wide fence): poll it in the mapped block -- a stream
-        // synchronisation costs an interrupt round trip (~10-15 us) on top of a kernel of about that length.  The stream's
-        // own completion is picked up by whatever uses it next (same stream: ordered).  (AZ_NMS_POLL=0, profiling, or no
-        // answer within a millisecond: the plain wait.)
+          azk_nms_one_small(s, hd, n, thresh, hk, hn, tag); }
+        // Poll the result in the mapped block -- a stream synchronisation costs an interrupt round trip (~10-15 us) on top of
+        // a kernel of about that length.  Count and keep entries carry the call's tag (words may land out of order); the
+        // stream's own completion is picked up by whatever uses it next (same stream: ordered).  (AZ_NMS_POLL=0, profiling,
+        // or no answer within a millisecond: the plain wait, after which everything is visible.)
         static const bool poll = !(getenv("AZ_NMS_POLL") && !atoi(getenv("AZ_NMS_POLL")));
+        const unsigned want = tag & 0x3FFFFFu;
         bool got = false;
         if (poll && !c->profiling) {
             const volatile int *vn = hn;
-            for (int spin = 0; spin < 200000 && !got; ++spin) got = *vn >= 0;
+            for (int spin = 0; spin < 200000 && !got; ++spin) got = ((unsigned)*vn >> 9) == want;
+            if (got) got = nms_keep_tagged(hk, (int)((unsigned)*vn & 0x1FFu), tag, 200000);
         }
         if (!got) HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
-        const int nk = *(const volatile int *)hn;
-        if (nk < 0 || nk > n) return fail(c, AZ_ERR_HIP, "az_nms: the kernel left no result");
+        const unsigned word = (unsigned)*(const volatile int *)hn;
+        const int nk = (int)(word & 0x1FFu);
+        if ((word >> 9) != want || nk > n || !nms_keep_tagged(hk, nk, tag, 0))
+            return fail(c, AZ_ERR_HIP, "az_nms: the kernel left no result");
         *n_keep = nk;
-        for (int i = 0; i < nk; ++i) keep[i] = hk[i];
+        for (int i = 0; i < nk; ++i) keep[i] = (long long)(unsigned)(hk[i] & 0xFFFFFFFFll);
         return AZ_OK;
     }
     if (n > c->nms_cap) {
@@ -1917,18 +2173,22 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
             HIPCHK(c, hipHostMalloc((void **)&c->h_nmsg, need * 2, hipHostMallocMapped));
             c->h_nmsg_cap = need * 2;
         }
-        volatile int *hn = (volatile int *)c->h_nmsg;
-        long long *hk = (long long *)(c->h_nmsg + 64);
-        *hn = -1;
-        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, hk, (int *)c->h_nmsg);
+        volatile long long *hn = (volatile long long *)c->h_nmsg;      // (tag << 32) | count
+        long long *hk = (long long *)(c->h_nmsg + 64);                 // (tag << 32) | index
+        const unsigned tag = nms_next_tag(c);
+        *hn = 0;
+        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, hk, (int *)c->h_nmsg, tag);
         bool got = false;
-        for (long spin = 0; spin < 4000000 && !got; ++spin) got = *hn >= 0;
+        for (long spin = 0; spin < 4000000 && !got; ++spin) got = (unsigned)((unsigned long long)*hn >> 32) == tag;
+        if (got) got = nms_keep_tagged(hk, (int)(*hn & 0xFFFFFFFFll), tag, 200000);
         if (!got) HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
-        const int h_nk2 = *hn;
-        if (h_nk2 < 0 || h_nk2 > n) return fail(c, AZ_ERR_HIP, "az_nms: the kernels left no result");
+        const long long word = *hn;
+        const int h_nk2 = (int)(word & 0xFFFFFFFFll);
+        if ((unsigned)((unsigned long long)word >> 32) != tag || h_nk2 < 0 || h_nk2 > n || !nms_keep_tagged(hk, h_nk2, tag, 0))
+            return fail(c, AZ_ERR_HIP, "az_nms: the kernels left no result");
         *n_keep = h_nk2;
-        for (int i = 0; i < h_nk2; ++i) keep[i] = hk[i];
+        for (int i = 0; i < h_nk2; ++i) keep[i] = (long long)(unsigned)(hk[i] & 0xFFFFFFFFll);
         return AZ_OK;
     }
     { Timed t(c, "nms", n);
@@ -2164,18 +2424,32 @@ int az_nms_batched(az_ctx *c, const float *dets, const int32_t *offsets, int n_g
         std::memset(b + o_nk, 0, (size_t)n_groups * sizeof(int));
         volatile int *flag = (volatile int *)(b + o_flag);
         const int seq = ++c->nms_seq;
+        const unsigned tag = nms_next_tag(c), want = tag & 0x3FFFFFu;
         *flag = 0;
         azk_nms_small(s, (const float *)b, (const int *)(b + o_off), (const int *)(b + o_sel), (int)small.size(), thresh,
-                      (long long *)(b + o_keep), (int *)(b + o_nk), c->nms_done, (int *)(b + o_flag), seq);
+                      (long long *)(b + o_keep), (int *)(b + o_nk), c->nms_done, (int *)(b + o_flag), seq, tag);
+        // the flag says "all workgroups are done"; each count and keep word is still taken by its own tag (see nms_next_tag)
+        const long long *hk = (const long long *)(b + o_keep);
+        const volatile int *hn = (const volatile int *)(b + o_nk);
+        auto all_tagged = [&](long spins) {
+            for (int g : small) {
+                long k = 0;
+                while (((unsigned)hn[g] >> 9) != want) if (++k > spins) return false;
+                if (!nms_keep_tagged(hk + offsets[g], (int)((unsigned)hn[g] & 0x1FFu), tag, spins)) return false;
+            }
+            return true;
+        };
         bool got = false;
         for (int spin = 0; spin < 400000 && !got; ++spin) got = *flag == seq;
+        if (got) got = all_tagged(200000);
         if (!got) HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
-        const long long *hk = (const long long *)(b + o_keep);
-        const int *hn = (const int *)(b + o_nk);
+        if (!all_tagged(0)) return fail(c, AZ_ERR_HIP, "az_nms_batched: the kernel left no result");
         for (int g : small) {
-            n_keep[g] = hn[g];
-            for (int k = 0; k < hn[g]; ++k) keep[offsets[g] + k] = hk[(size_t)offsets[g] + k];
+            const int nk = (int)((unsigned)hn[g] & 0x1FFu);
+            if (nk > offsets[g + 1] - offsets[g]) return fail(c, AZ_ERR_HIP, "az_nms_batched: bad count");
+            n_keep[g] = nk;
+            for (int k = 0; k < nk; ++k) keep[offsets[g] + k] = (long long)(unsigned)(hk[(size_t)offsets[g] + k] & 0xFFFFFFFFll);
         }
     } else
     if (!small.empty()) {

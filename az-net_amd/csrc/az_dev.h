@@ -161,6 +161,10 @@ void azk_full_lookup(hipStream_t s, const int *Uptr, const float *urois, const d
                      unsigned char *keep_v, unsigned *key_v, int *err);
 void azk_full_map(hipStream_t s, const float *spec_urois, int n_spec, float ss, const unsigned long long *tab, unsigned T,
                   int base_extra, int cap_rows, float *urois_full, double *ubox_full, int *map, int *n_extra, int *err);
+// closure rows (az_static.hip): rois of n regions; window owners -> rows of the pass + table relabelled to those rows
+void azk_closure_rois(hipStream_t s, const double *regs, int n, double scale, float *out);
+void azk_closure_compact(hipStream_t s, const float *all, int N, float ss, unsigned long long *tab, unsigned T, int *newrow,
+                         float *urois_full, double *ubox_full, int *n_rows, int *err);
 void azk_static_candidates(hipStream_t s, const AzStaticArgs &a);
 // candidates + final top-k in one launch (fixed proposal count); false: the tree is too large for it
 bool azk_static_select(hipStream_t s, const AzStaticArgs &a);
@@ -208,7 +212,10 @@ struct AzLevelArgs {
     const double *pred_u;          // head outputs of this level's unique rois
     const float *score_u, *zoom_u;
     float *urois;                  // next level: unique rois
-    int *index, *inv;              // this level's inv_index on entry; the next level's index / inv_index on exit
+    int *index;                    // the next level's index on exit
+    const int *inv;                // this level's inv_index
+    int *inv_next;                 // the next level's inv_index (another buffer: the candidate-copy workgroup reads `inv`
+                                   // at its own pace, whenever it is dispatched)
     const unsigned char *keep_u;   // MIN_SIDE filter of this level's decoded boxes (tail kernel)
     const int *Uptr;               // unique rois of this level
     int root_row;                  // 1: the LAST row of this level's head pass (cnt->PR[level] - 1) is the deferred root (az_fused.hip)
@@ -325,15 +332,18 @@ void azk_thresh_select_full(hipStream_t s, const float *scores, const int *Nptr,
                             double *Yout, float *Sout);
 void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap, const double *Yall,
                     const float *Sall, double *Yout, float *Sout);
+// seq != 0 (keep / nkeep in host-mapped memory that the host polls): every keep entry is (seq << 32) | index and the count
+// word is 64 bits, (seq << 32) | n_kept -- the host accepts a word only when it carries the call's sequence number
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
-             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep);
+             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep, unsigned seq = 0);
 // many groups of <= azk_nms_small_max() boxes in one launch: group g = dets[goff[g] .. goff[g+1]); gsel lists
 // the groups to process; keep[goff[g] ..] gets the kept group-local indices, nkeep[g] their number
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
-                   long long *keep, int *nkeep, int *done_cnt = nullptr, int *done_flag = nullptr, int done_seq = 0);
+                   long long *keep, int *nkeep, int *done_cnt = nullptr, int *done_flag = nullptr, int done_seq = 0,
+                   unsigned seq = 0);     // seq != 0: keep entries (seq << 32) | index, counts (seq << 9) | n_kept
 int azk_nms_small_max();
 // one problem of n <= azk_nms_small_max() boxes in one launch (dets / keep / nkeep may be host-mapped)
-void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep);
+void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep, unsigned seq = 0);
 #define AZ_TOPK_MAX 4096
 
 // ---- launchers (az_eval.hip): front-end, recall evaluation, threshold tuner ----------------
@@ -350,3 +360,6 @@ void azk_pool_hist(hipStream_t s, const float *pool, long long n, unsigned int p
                    unsigned long long *hist);
 void azk_pool_keep(hipStream_t s, const float *pool, long long n, unsigned int kmin, float *dst,
                    unsigned long long *ndst);
+
+// ---- launcher (az_box.hip): what this box sustains (register-only fp32 MFMA loop on all SIMDs; float4 copy) ----------
+int azk_measure_box(hipStream_t s, double *mfma_tflops, double *copy_tbps, size_t copy_bytes);

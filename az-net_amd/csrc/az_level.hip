@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     // Two workgroups: workgroup 0 walks the critical chain (zoom selection, divide_region, _sift_dup, the next level's
     // rois, ...) and writes every counter; workgroup 1 copies this level's candidates to Y / aScores, which nothing
     // before the final selection reads -- ~10 us of dependent global round trips off the path to the next head pass.
-    // Both read the same inputs; neither reads anything the other writes.
+    // Both read the same inputs.  The chain writes the NEXT level's index / inv_index / rois / counters; the only one of
+    // those that shares a name with an input is inv_index, which is why a.inv (this level's) and a.inv_next are two
+    // buffers: the copier may be dispatched late (CUs held by another context's GEMM) and read a.inv at any time.
     const bool copier = gridDim.x == 1 || blockIdx.x == 1, chain = blockIdx.x == 0;
     const int P = cnt->P[l];
     const int U = *a.Uptr;
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     if (Pn > a.batch) { if (tid == 0) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }      // chunked dedup: multi-launch path
     int *sidx = reinterpret_cast<int *>(sbuf + W_SZR);                      // (szr is done) index[] of level l+1, in LDS
     const int Un = roi_dedup_sorted(sBn, Pn, a.scale, a.dedup, ssort, ssort + LV_R, sbins, s_mm, wsum, nullptr, a.index,
-                                    a.inv, a.urois, a.ubox, sidx);
+                                    a.inv_next, a.urois, a.ubox, sidx);
     if (tid == 0) cnt->U[l + 1] = Un;
     __syncthreads();
     TSTAMP();

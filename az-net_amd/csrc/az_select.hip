@@ -352,8 +352,12 @@ k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long 
 
 __global__ void __launch_bounds__(256)
 k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ order, int n,
-           unsigned long long *removed_g, long long *keep, int *nkeep)
+           unsigned long long *removed_g, long long *keep, int *nkeep, unsigned seq)
 {
+    // seq != 0: keep / nkeep are host-mapped memory the host polls.  Writes of one wave to host memory may land out of
+    // order (PCIe posted writes with relaxed ordering: a later word can pass an earlier one -- measured: a count visible
+    // before the last keep entries, 5 calls in 27 600), so nothing is inferred from ORDER: every word carries the call's
+    // sequence number in its upper half and the host takes a word only once it shows the current number.
     __shared__ unsigned long long s_kept;
     __shared__ int s_nk;
     extern __shared__ unsigned long long removed[];   // W words
@@ -382,7 +386,7 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
             const int nk = s_nk;
             if ((kept >> lane) & 1ull) {
                 const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-                keep[nk + pos] = order[row];
+                keep[nk + pos] = ((long long)seq << 32) | (unsigned)order[row];
             }
             if (lane == 0) { s_kept = kept; s_nk = nk + __popcll(kept); }
         }
@@ -410,10 +414,12 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
         }
         __syncthreads();
     }
-    // (the count is written LAST, behind a system-wide fence: az_nms polls it in host-mapped memory)
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) *nkeep = s_nk;
+    if (threadIdx.x == 0) {
+        if (seq) *reinterpret_cast<long long *>(nkeep) = ((long long)seq << 32) | (unsigned)s_nk;
+        else *nkeep = s_nk;
+    }
 }
 
 // ---- many small NMS problems in one launch (apply_nms: one per class per image) ---------------
@@ -426,8 +432,10 @@ constexpr int NMS_SMALL_NT = 1024;       // 16 waves: the suppression words are 
 __global__ void __launch_bounds__(NMS_SMALL_NT)
 k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const int *__restrict__ gsel,
             int n_single, double thresh, long long *__restrict__ keep, int *__restrict__ nkeep,
-            int *done_cnt, int *done_flag, int done_seq)
+            int *done_cnt, int *done_flag, int done_seq, unsigned seq)
 {
+    // seq != 0 (results in host-mapped memory, polled by the host): every keep entry carries seq in its upper half and the
+    // group's count is (seq << 9) | n_kept -- see k_nms_scan: the host trusts tags, never the order in which words land
     __shared__ float sd[NMS_SMALL][5];                     // sorted: x1, y1, x2, y2, area
     __shared__ int sorder[NMS_SMALL];
     __shared__ float ss[NMS_SMALL];
@@ -524,7 +532,7 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
                     if ((alive >> b) & 1ull) { kept |= (1ull << b); alive &= ~drow; }
                 }
                 const bool mine = (kept >> lane) & 1ull;
-                if (mine) keep[o + nk + __popcll(kept & ((1ull << lane) - 1ull))] = sorder[row];
+                if (mine) keep[o + nk + __popcll(kept & ((1ull << lane) - 1ull))] = ((long long)seq << 32) | (unsigned)sorder[row];
                 nk += __popcll(kept);
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -540,10 +548,8 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
                 }
             }
         }
-        // (the count is the LAST thing written: az_nms's small case polls it in host-mapped memory instead of waiting for
-        //  the stream's completion signal, so everything before it must be visible system-wide first)
         __threadfence_system();
-        if (lane == 0) nkeep[g] = nk;
+        if (lane == 0) nkeep[g] = seq ? (int)(((seq & 0x3FFFFFu) << 9) | (unsigned)nk) : nk;
         // (batched form on host-mapped memory: the LAST workgroup to finish raises the flag the host polls)
         if (done_flag && lane == 0) {
             __threadfence_system();
@@ -612,21 +618,21 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
 int azk_nms_small_max() { return NMS_SMALL; }
 
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,
-                   long long *keep, int *nkeep, int *done_cnt, int *done_flag, int done_seq)
+                   long long *keep, int *nkeep, int *done_cnt, int *done_flag, int done_seq, unsigned seq)
 {
     if (n_sel > 0)
         hipLaunchKernelGGL(k_nms_small, dim3(n_sel), dim3(NMS_SMALL_NT), 0, s, dets, goff, gsel, 0, thresh, keep, nkeep,
-                           done_cnt, done_flag, done_seq);
+                           done_cnt, done_flag, done_seq, seq);
 }
 
-void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep)
+void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, long long *keep, int *nkeep, unsigned seq)
 {
     hipLaunchKernelGGL(k_nms_small, dim3(1), dim3(NMS_SMALL_NT), 0, s, dets, (const int *)nullptr, (const int *)nullptr, n, thresh,
-                       keep, nkeep, (int *)nullptr, (int *)nullptr, 0);
+                       keep, nkeep, (int *)nullptr, (int *)nullptr, 0, seq);
 }
 
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
-             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep)
+             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep, unsigned seq)
 {
     if (n <= 0) { hipMemsetAsync(nkeep, 0, sizeof(int), s); return; }
     const int W = (n + 63) / 64;
@@ -634,5 +640,5 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
     hipLaunchKernelGGL(k_nms_rank, dim3(g > 1024 ? 1024 : g), dim3(256), 0, s, dets, n, order, sdets);
     hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask);
     hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)W * sizeof(unsigned long long), s, mask, order,
-                       n, removed, keep, nkeep);
+                       n, removed, keep, nkeep, seq);
 }

@@ -463,6 +463,75 @@ __global__ void k_full_map(const float *__restrict__ spec_urois, int n_spec, flo
 }
 }  // namespace
 
+// ---- the closure rows: every region ANY pruning of the tree can produce ---------------------------------------------------
+// B(l+1) = _sift_dup(divide_region(B(l)[zoom >= Tz])) (test.py:386-390, div.pyx:15-89): whatever the zoom scores, a region
+// of level l+1 is a child of a region of level l, and _sift_dup only ever DROPS children (which of several same-hash
+// children survives depends on which parents zoomed).  So C(0) = {root}, C(l+1) = all children of all of C(l) holds every
+// region a search of this image shape can meet; one row per distinct RoIPool window among them serves every Tz.
+namespace {
+__global__ void k_closure_rois(const double *__restrict__ regs, int n, double scale, float *__restrict__ out)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        out[5 * (size_t)i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[5 * (size_t)i + 1 + q] = (float)(regs[4 * (size_t)i + q] * scale);   // test.py:61-97
+    }
+}
+
+// The table was built over ALL closure rois with word = (window << 13) | smallest index holding that window (index 0 = the
+// root = AZ_TAB_ROOT).  Rows of the pass: the window owners other than the root, in index order.  One workgroup:
+// newrow[i] = row of owner i (-1: not an owner), the owners' rois gathered; *n_rows = number of rows.
+__global__ void __launch_bounds__(1024) k_closure_compact(const float *__restrict__ all, int N, float ss,
+                                                           const unsigned long long *__restrict__ tab, unsigned T,
+                                                           int *newrow, float *urois_full, double *ubox_full, int *n_rows)
+{
+    __shared__ int wsum[17];
+    int run = 0;
+    for (int base = 0; base < N; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        int head = 0;
+        if (i > 0 && i < N) head = az_tab_lookup(tab, T, all + 5 * (size_t)i, ss, -2) == i;
+        int tot;
+        const int ex = block_excl_scan(head, &tot, wsum);
+        if (i < N) newrow[i] = head ? run + ex : -1;
+        if (head) {
+            const size_t row = (size_t)(run + ex);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) urois_full[5 * row + q] = all[5 * (size_t)i + q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ubox_full[4 * row + q] = 0.0;      // (every level decodes against its own boxes)
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) *n_rows = run;
+}
+
+__global__ void k_closure_relabel(unsigned long long *tab, unsigned T, const int *__restrict__ newrow, int *err)
+{
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const unsigned long long w = tab[t];
+        if (w == ~0ull) continue;
+        const unsigned r = (unsigned)(w & 0x1FFFu);
+        if (r == AZ_TAB_ROOT) continue;
+        const int nr = newrow[r];
+        if (nr < 0 || nr >= (int)AZ_TAB_ROOT) { atomicOr(err, 1); continue; }
+        tab[t] = (w & ~0x1FFFull) | (unsigned)nr;
+    }
+}
+}  // namespace
+
+void azk_closure_rois(hipStream_t s, const double *regs, int n, double scale, float *out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_closure_rois, dim3((n + 255) / 256), dim3(256), 0, s, regs, n, scale, out);
+}
+
+void azk_closure_compact(hipStream_t s, const float *all, int N, float ss, unsigned long long *tab, unsigned T, int *newrow,
+                         float *urois_full, double *ubox_full, int *n_rows, int *err)
+{
+    hipLaunchKernelGGL(k_closure_compact, dim3(1), dim3(1024), 0, s, all, N, ss, tab, T, newrow, urois_full, ubox_full, n_rows);
+    hipLaunchKernelGGL(k_closure_relabel, dim3((T + 255) / 256), dim3(256), 0, s, tab, T, newrow, err);
+}
+
 namespace {
 // Whole-tree speculation, a level that runs on the multi-launch geometry kernels (more regions than the fused level kernel
 // holds): the head outputs of its unique rois by RoIPool window among the rows of the search's one pass -- the lookup

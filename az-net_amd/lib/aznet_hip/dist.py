@@ -149,9 +149,16 @@ class DeviceGather(object):
         pad = np.zeros(self.rec_bytes, dtype=np.uint8)
         pad[self.layout[1]:self.layout[1] + 4] = np.array([-1], dtype=np.int32).view(np.uint8)
         self._pad = torch.from_numpy(pad).to(device)
+        # the non-blocking form's side stream / pinned host buffers, and which buffer pair has an exchange in flight
+        self._side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self._host = None
+        self._busy = [False, False]
 
     def stage(self, j, buf=0):
         assert 0 <= j < self.rows
+        if self._busy[buf]:
+            raise RuntimeError("DeviceGather.stage: buffer pair %d still has an exchange in flight (gather_end it first, "
+                               "or stage into the other pair)" % buf)
         self.ctx.stage_result(self.bufs[buf][0].data_ptr() + j * self.rec_bytes, self.rec_bytes)
 
     def _exchange(self, n_local, buf):
@@ -160,9 +167,10 @@ class DeviceGather(object):
         if n_local < self.rows:
             send[n_local:] = self._pad
         if self.world > 1 or self.collective:
-            # stage() copies ran on the ctx stream and are complete (propose_fetch waited for the search behind which
-            # each was enqueued); the pad write above and the collective are ordered by torch's current stream, which
-            # all_gather_into_tensor joins with RCCL's stream on both sides (async_op=False)
+            # stage() copies ran on the ctx stream and are complete: az_propose_stage_result_dev re-records the event
+            # propose_fetch waits for BEHIND the staging copy, and the caller has fetched every search of the batch.  The
+            # pad write above and the collective are ordered by torch's current stream, which all_gather_into_tensor
+            # joins with RCCL's stream on both sides (async_op=False)
             dist.all_gather_into_tensor(recv, send, group=self.group)
             return recv, self.world
         return send, 1
@@ -183,20 +191,23 @@ class DeviceGather(object):
         result later (stage the next batch into the other pair meanwhile).  The collective and the device-to-host copy
         run on a side stream; nothing here blocks the host."""
         import torch
-        if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=self.device)
+        if self._busy[buf]:
+            raise RuntimeError("DeviceGather.gather_begin: buffer pair %d already has an exchange in flight" % buf)
+        if self._host is None:
             self._host = [torch.empty(self.bufs[0][1].shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
         host = self._host[buf]
+        self._busy[buf] = True
         ev = torch.cuda.Event()
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._side):
             src, w = self._exchange(n_local, buf)
             host[:src.shape[0]].copy_(src, non_blocking=True)
             ev.record(self._side)
-        return (ev, host, w)
+        return (ev, host, w, buf)
 
     def gather_end(self, handle):
-        ev, host, w = handle
+        ev, host, w, buf = handle
         ev.synchronize()
+        self._busy[buf] = False
         raw = host.numpy()[:w * self.rows].reshape(w, self.rows, self.rec_bytes)
         return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))

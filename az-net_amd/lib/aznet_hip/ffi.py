@@ -32,7 +32,8 @@ SYMBOLS = [
     "az_tune_top", "az_tune_push", "az_bbox_overlaps", "az_recall_match", "az_image_blob_size",
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
-    "az_propose_launch_on", "az_set_feature_map_dev_nhwc",
+    "az_propose_launch_on", "az_set_feature_map_dev_nhwc", "az_set_pass_costs", "az_get_pass_costs",
+    "az_measure_box",
 ]
 
 
@@ -53,7 +54,11 @@ class AzStats(ctypes.Structure):
                 ("level_zoomed", ctypes.c_int32 * AZ_MAX_LEVELS),
                 ("spec_rows", ctypes.c_int32), ("root_deferred", ctypes.c_int32),
                 ("static_plan", ctypes.c_int32), ("n_passes", ctypes.c_int32),
-                ("pass_rows", ctypes.c_int32 * AZ_MAX_LEVELS)]
+                ("pass_rows", ctypes.c_int32 * AZ_MAX_LEVELS),
+                ("search_form", ctypes.c_int32), ("n_reruns", ctypes.c_int32)]
+
+
+SEARCH_FORMS = {0: "level_loop", 1: "pair_speculation", 2: "whole_tree_pass", 3: "closure_pass", 4: "one_pass_plan"}
 
 
 class AzError(RuntimeError):
@@ -127,6 +132,9 @@ def load_library(path=None):
     L.az_last_kernel_times.argtypes = [vp, ctypes.c_char_p, fp, ip, ci, cip]
     L.az_stream.restype = vp
     L.az_stream.argtypes = [vp]
+    L.az_set_pass_costs.argtypes = [vp, ci, ip, dp]
+    L.az_get_pass_costs.argtypes = [vp, ip, dp, ci, cip]
+    L.az_measure_box.argtypes = [vp, dp, dp]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
@@ -282,14 +290,16 @@ class AzContext(object):
         eligible level (same bits in all three).
         full_spec: None = let the context decide from its previous search of this image shape whether the search's ONE
         head pass evaluates the rows of the shape's full tree, every level finding its outputs by RoIPool window (pays
-        for dense trees); False = never; True = whenever the shape allows (same bits in all three)."""
+        for dense trees: after a full tree the full tree's rows, otherwise the closure rows); False = never; True = the
+        full tree's rows whenever the shape allows; "closure" = the closure rows whenever the shape allows -- every region
+        any pruning of the tree can produce, so no Tz can miss a window (same bits in all four)."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
                         1 if fixed_num else 0,
                         (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0) |
                         (8 if radix_select else 0) | (0 if fused_levels else 16) | (0 if static_tree else 32) |
                         (0 if pair_spec is None else (128 if pair_spec else 64)) |
-                        (0 if full_spec is None else (512 if full_spec else 256)))
+                        (0 if full_spec is None else ((512 | 1024) if full_spec == "closure" else (512 if full_spec else 256))))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates
@@ -638,6 +648,32 @@ class AzContext(object):
     def set_graphs(self, on):
         """Replay the search's launch sequence as a hipGraph (same results, less host time)."""
         self._chk(self.L.az_set_graphs(self.h, 1 if on else 0))
+
+    # the round-3 profile's figures for the full head on one MI355X box: what tests pin the form choice to
+    REFERENCE_PASS_COSTS = ((40, 142.0), (704, 1096.0))
+
+    def set_pass_costs(self, table=None):
+        """table: ((rows, us), ...) ascending, 2..6 points -- the cost of one head pass the context chooses the search
+        form by (az_set_pass_costs); None / () = measure on the device at the next launch (the default)."""
+        t = list(table or ())
+        rows = np.ascontiguousarray([r for r, _ in t], dtype=np.int32)
+        us = np.ascontiguousarray([u for _, u in t], dtype=np.float64)
+        self._chk(self.L.az_set_pass_costs(self.h, len(t), _p(rows, ctypes.c_int32) if t else None,
+                                           _p(us, ctypes.c_double) if t else None))
+
+    def pass_costs(self):
+        """((rows, us), ...) in use; () before the first launch of a context that measures its own."""
+        rows = np.zeros(8, dtype=np.int32)
+        us = np.zeros(8, dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._chk(self.L.az_get_pass_costs(self.h, _p(rows, ctypes.c_int32), _p(us, ctypes.c_double), 8, ctypes.byref(n)))
+        return tuple((int(rows[i]), float(us[i])) for i in range(n.value))
+
+    def measure_box(self):
+        """(fp32 MFMA TFLOP/s this box sustains in a register-only loop, TB/s of a 1 GiB float4 copy) -- az_measure_box."""
+        a, b = ctypes.c_double(0), ctypes.c_double(0)
+        self._chk(self.L.az_measure_box(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return float(a.value), float(b.value)
 
     def last_kernel_times(self, cap=65536):
         names = ctypes.create_string_buffer(32 * cap)

@@ -255,12 +255,16 @@ def main():
             # this step's image: its map is handed over with the launch
             net.ctx.propose_launch(prm, fmap=convs[i % len(convs)], producer_done=True)
             if gat is not None:
+                # (the pair this batch stages into carried the batch before the previous one: its exchange, begun a whole
+                #  batch ago, is collected before the pair is written again)
+                while i % ge == 0 and inflight and inflight[0][2] == (i // ge) % 2:
+                    collect()
                 gat.stage(i % ge, buf=(i // ge) % 2)
 
         inflight = []
 
         def collect():
-            h, n_b = inflight.pop(0)
+            h, n_b, _ = inflight.pop(0)
             assert len(gat.gather_end(h)) == world * n_b
 
         def done(i):
@@ -274,7 +278,7 @@ def main():
                 else:
                     if inflight:
                         collect()
-                    inflight.append((gat.gather_begin(n_b, buf=(i // ge) % 2), n_b))
+                    inflight.append((gat.gather_begin(n_b, buf=(i // ge) % 2), n_b, (i // ge) % 2))
                 rccl["collectives"] += 1
             if i == nsteps - 1:
                 while inflight:

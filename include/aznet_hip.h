@@ -75,10 +75,13 @@ typedef struct {
                                  level also evaluates the rois of ALL children of its regions, a superset of the next
                                  level's, which then needs no pass of its own; same bits in all three);
                                  bit 8: no whole-tree speculation; bit 9: whole-tree speculation whenever the image
-                                 shape allows (by default, when the context's previous search of the shape walked
-                                 the FULL tree, the search's one head pass evaluates the full tree's unique rois and
-                                 every level finds its outputs by RoIPool window; a search that needs a window that
-                                 pass lacks is repeated level by level; same bits in all three)                    */
+                                 shape allows (by default the context decides from the row counts of its previous
+                                 search of the shape: a dense tree's ONE head pass evaluates a shape-static superset
+                                 of its rows and every level finds its outputs by RoIPool window -- after a full tree
+                                 the full tree's unique rois, where a search that needs a window the pass lacks is
+                                 repeated level by level; otherwise the closure rows, which hold every region any
+                                 pruning can produce; same bits in all three);
+                                 bit 10: with bit 9, the closure rows instead of the full tree's                    */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
@@ -101,6 +104,14 @@ typedef struct {
     int32_t pass_rows[AZ_MAX_LEVELS];     /* rois each of them evaluated (speculative rows included); a search in
                                              its whole-tree form: ONE pass of the image shape's full tree
                                              (pass_rows[0] > spec_rows, static_plan = 0)                   */
+    int32_t search_form;                  /* the form the search took (all forms give the same bits): 0 level by level, one
+                                             head pass per level (levels 1-3 in one speculative pass); 1 some passes also
+                                             carried the next level's rows (pair speculation); 2 ONE pass over the unique rois
+                                             of the image shape's full tree; 3 ONE pass over the closure rows (every region any
+                                             pruning of the shape's tree can produce); 4 the Tz <= 0 one-pass plan          */
+    int32_t n_reruns;                     /* times this search had to be run again in another form before it gave this
+                                             result (0 normally; e.g. a whole-tree pass over the full tree's rows that lacked
+                                             a window the pruned tree needed)                                               */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
@@ -297,6 +308,18 @@ int az_last_kernel_times(az_ctx *ctx, char *names_out, float *ms_out, int32_t *l
  * change, the host time inside az_propose_launch drops from ~110 us to ~17 us.  Default: the
  * AZ_GRAPH environment variable (off).  Ignored while kernel timing (az_set_profiling) is on. */
 int az_set_graphs(az_ctx *ctx, int on);
+/* What the context chooses between the forms of a search by (level by level / pair speculation / one whole-tree pass;
+ * all give the same bits): the cost in us of ONE head pass (RoIPool + int6 + reduce + int7 + heads) at a few row counts,
+ * ascending, linearly interpolated.  By default the context measures the table on its device the first time a search is
+ * launched (~10 ms, HIP events); az_set_pass_costs pins it (n >= 2; tests, or a deployment that has measured its boxes),
+ * n = 0 returns to measuring.  az_get_pass_costs reads the table in use (n_out = 0: none yet). */
+int az_set_pass_costs(az_ctx *ctx, int n, const int32_t *rows, const double *us);
+int az_get_pass_costs(az_ctx *ctx, int32_t *rows_out, double *us_out, int cap, int *n_out);
+/* What this box sustains, for reading a roofline fraction apart from the box it was measured on: the fp32-input MFMA rate
+ * (TFLOP/s) of a ~3 ms register-only v_mfma_f32_32x32x2_f32 loop on every SIMD, pseudo-random operands (the data-sheet
+ * peak, 157.3 TFLOP/s, assumes 2.4 GHz; boxes hold 5-10 % less and differ among themselves), and the rate (TB/s, bytes
+ * read + written) of a 1 GiB float4 copy through HBM.  ~40 ms; either output may be NULL.  Blocks until done. */
+int az_measure_box(az_ctx *ctx, double *mfma_f32_tflops, double *copy_tb_per_s);
 /* The HIP stream the ctx launches on (a hipStream_t). */
 void *az_stream(az_ctx *ctx);
 

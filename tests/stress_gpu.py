@@ -89,6 +89,18 @@ def run_case(net, case):
                 np.array_equal(e[0], b[0]), np.array_equal(e[1], b[1]), np.array_equal(Ye, Yb), np.array_equal(Se, Sb),
                 e[2].num_eval, b[2].num_eval, list(e[2].pass_rows[:e[2].n_passes]))
         desc += " wt-passes %d" % e[2].n_passes
+        # ... and over the closure rows (every region any pruning can produce): same bits, and NEVER a search run twice
+        pcl = ffi.AzContext.make_params(H, W, scale, Tz, full_spec="closure", **kw)
+        f = net.propose(pcl, want_scores=True, want_stats=True)
+        Yf, Sf = net.ctx.last_candidates()
+        ok = (np.array_equal(f[0], b[0]) and np.array_equal(f[1], b[1]) and np.array_equal(Yf, Yb) and
+              np.array_equal(Sf, Sb) and f[2].num_eval == b[2].num_eval and f[2].depth == b[2].depth and
+              list(f[2].level_unique) == list(b[2].level_unique) and list(f[2].level_zoomed) == list(b[2].level_zoomed))
+        if not ok or (f[2].search_form == 3 and f[2].n_reruns != 0):
+            return False, desc, "closure-vs-plain: Y %s S %s Yall %s Sall %s eval %d/%d passes %s form %d reruns %d" % (
+                np.array_equal(f[0], b[0]), np.array_equal(f[1], b[1]), np.array_equal(Yf, Yb), np.array_equal(Sf, Sb),
+                f[2].num_eval, b[2].num_eval, list(f[2].pass_rows[:f[2].n_passes]), f[2].search_form, f[2].n_reruns)
+        desc += " closure-form %d rows %d" % (f[2].search_form, f[2].pass_rows[0])
     if fixed:
         net.ctx.propose_launch(ffi.AzContext.make_params(H, W, scale, Tz, **kw))
         net.ctx.propose_launch(pp)

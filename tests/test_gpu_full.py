@@ -6,6 +6,8 @@ rows, plus the speculative rows whose window the plan lacks); every level then f
 RoIPool window (a roi's outputs are a function of its pooled window only) and decodes them against its own boxes.
 Valid for any Tz: a pruned tree may keep another _sift_dup survivor than the full tree (same 10-px hash, other
 coordinates, other window); a search that needs a window the pass did not evaluate is repeated level by level.
+The CLOSURE rows (full_spec="closure") hold one row per distinct window among ALL regions any pruning can produce
+(level l+1 = every child of every region of level l, no _sift_dup): that pass serves every Tz and is never repeated.
 Everything observable must equal the search without it, and the full-size search must equal the pure-CPU oracle."""
 import numpy as np
 import pytest
@@ -25,7 +27,11 @@ def mods():
 def small(mods):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
-    return HipAZNet(head, name="small_full"), head
+    net = HipAZNet(head, name="small_full")
+    # the form a search takes "by history" is decided from head-pass costs the context measures on its device; the tests
+    # that assert a form pin the table (the full head's figures) so that they do not depend on the box or the head size
+    net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)
+    return net, head
 
 
 def _scale(H, W):
@@ -83,6 +89,92 @@ def test_forced_whole_tree_pass_equals_plain_level_loop(small, mods, H, W):
                     assert full["st"].n_passes == 1, (full["st"].n_passes, list(full["st"].pass_rows[:4]))
 
 
+ONE_PASS_SHAPES = ((600, 1000), (375, 500), (480, 640), (600, 600))
+
+
+@pytest.mark.parametrize("H,W", SHAPES, ids=["%dx%d" % s for s in SHAPES])
+def test_forced_closure_pass_equals_plain_level_loop_and_is_never_repeated(small, mods, H, W):
+    """The closure rows serve EVERY Tz: same bits as the plain level loop, one head pass, no search run twice."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    scale = _scale(H, W)
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    if orc.num_levels(H, W) - 1 < 4:
+        pytest.skip("fewer than four levels: nothing behind the speculative ones")
+    rows = set()
+    for seed in (5, 6):
+        net.set_conv(synth.make_feature_map(seed, synth.SMALL_DIMS["C"], fh, fw))
+        z = _zooms(net, ffi, H, W, scale)
+        for Tz in (0.0, float(np.quantile(z, 0.1)), float(np.quantile(z, 0.3)), float(np.quantile(z, 0.6)),
+                   float(z[len(z) // 2]), 1.5):
+            for kw in ({}, {"dedup": 0.0}, {"num_proposals": 2000}):
+                plain = _run(net, ffi, H, W, scale, Tz, False, pair_spec=False, **kw)
+                clos = _run(net, ffi, H, W, scale, Tz, "closure", **kw)
+                _same(plain, clos)
+                assert clos["st"].n_reruns == 0 or clos["st"].search_form != 3
+                if (H, W) in ONE_PASS_SHAPES and not kw:
+                    st = clos["st"]
+                    assert st.search_form == 3 and st.n_passes == 1 and st.n_reruns == 0, \
+                        (Tz, st.search_form, st.n_passes, st.n_reruns, list(st.pass_rows[:4]))
+                    rows.add(int(st.pass_rows[0]))
+    if (H, W) in ONE_PASS_SHAPES:
+        assert len(rows) == 1                           # a property of the image shape, whatever the Tz
+        full = _run(net, ffi, H, W, scale, 0.0, True)
+        assert rows.pop() >= int(full["st"].pass_rows[0])       # the closure holds the full tree's rows
+
+
+def test_tree_rows_can_miss_a_window_that_the_closure_holds(small, mods):
+    """Why the closure exists: a pruned tree may keep a _sift_dup survivor the full tree drops (other coordinates, other
+    RoIPool window).  The pass over the full tree's rows then lacks a window and the search is run again level by level
+    (n_reruns = 1, same bits); the closure pass of the same search is not."""
+    ffi, synth, HipAZNet, orc = mods
+    net, head = small
+    H, W = 600, 1000
+    missed = 0
+    for seed in (5, 6, 7, 8):
+        net.set_conv(synth.make_feature_map(seed, synth.SMALL_DIMS["C"], 38, 63))
+        z = _zooms(net, ffi, H, W, 1.0)
+        for q in (0.02, 0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5):
+            Tz = float(np.quantile(z, q))
+            plain = _run(net, ffi, H, W, 1.0, Tz, False, pair_spec=False)
+            tree = _run(net, ffi, H, W, 1.0, Tz, True)
+            clos = _run(net, ffi, H, W, 1.0, Tz, "closure")
+            _same(plain, tree)
+            _same(plain, clos)
+            assert clos["st"].n_reruns == 0 and clos["st"].n_passes == 1 and clos["st"].search_form == 3
+            assert tree["st"].n_reruns in (0, 1)
+            missed += int(tree["st"].n_reruns)
+    assert missed > 0, "no pruned tree of these 32 needed a window the full tree's rows lack"
+
+
+def test_history_takes_the_closure_for_dense_pruned_trees_when_it_is_cheaper(mods):
+    """By history and row counts: after a pruned tree the candidate is the closure pass, taken when one pass of its rows
+    is cheaper than the passes the tree's rows would cost level by level -- here with a pinned cost table whose rows are
+    cheap (as with int6 on the 16-bit matrix cores), so that a dense pruned tree takes it."""
+    ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="hist_closure")
+    net.ctx.set_pass_costs(((40, 140.0), (704, 300.0)))
+    assert net.ctx.pass_costs() == ((40, 140.0), (704, 300.0))
+    H, W = 600, 1000
+    net.set_conv(synth.make_feature_map(9, synth.SMALL_DIMS["C"], 38, 63))
+    z = _zooms(net, ffi, H, W, 1.0)
+    pd = ffi.AzContext.make_params(H, W, 1.0, float(np.quantile(z, 0.1)), static_tree=False)
+    plain = net.propose(ffi.AzContext.make_params(H, W, 1.0, float(np.quantile(z, 0.1)), static_tree=False, full_spec=False,
+                                                  pair_spec=False), want_scores=True, want_stats=True)
+    a = net.propose(pd, want_scores=True, want_stats=True)
+    b = net.propose(pd, want_scores=True, want_stats=True)
+    assert plain[2].level_zoomed[2] < plain[2].level_regions[2] or plain[2].level_zoomed[3] < plain[2].level_regions[3]
+    assert b[2].search_form == 3 and b[2].n_passes == 1 and b[2].n_reruns == 0, (b[2].search_form, b[2].n_passes)
+    for r in (a, b):
+        assert np.array_equal(r[0], plain[0]) and np.array_equal(r[1], plain[1])
+    # ... and with rows at the fp32-MFMA price the same tree stays level by level (the closure's extra rows cost more
+    # than the pass they save)
+    net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)
+    c = net.propose(pd, want_scores=True, want_stats=True)
+    assert c[2].search_form in (0, 1) and np.array_equal(c[0], plain[0])
+
+
 def test_history_turns_it_on_for_dense_trees_only(small, mods):
     ffi, synth, HipAZNet, orc = mods
     net, head = small
@@ -119,19 +211,24 @@ def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods):
         Yref, tr = orc.im_propose(nets, (H, W), 1.0, orc.OracleCfg(Tz=Tz), return_trace=True)
         z = np.concatenate([lv["zoom"] for lv in tr["levels"]])
         assert np.abs(z - Tz).min() > 2e-4
-        Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz, static_tree=False, full_spec=True),
-                               want_scores=True, want_stats=True)
-        # (the pruned tree may need a window the full tree's rows lack: then the search was repeated level by level)
-        assert st.n_passes == 1 or Tz > 0.0
-        assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
-        for l, lev in enumerate(tr["levels"]):
-            assert st.level_regions[l] == lev["B"].shape[0]
-            assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"])
-            assert st.level_zoomed[l] == len(lev["indZ"])
-        Yall, Sall = net.ctx.last_candidates()
-        assert Yall.shape == tr["Y_all"].shape
-        assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
-        np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2)
+        for form in (True, "closure"):
+            Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz, static_tree=False, full_spec=form),
+                                   want_scores=True, want_stats=True)
+            # (the pruned tree may need a window the full tree's rows lack: then the search was repeated level by level;
+            #  the closure rows -- 773 at 600x1000 against the full tree's 688 -- serve every tree)
+            assert st.n_passes == 1 or (Tz > 0.0 and form is True)
+            if form == "closure":
+                assert st.search_form == 3 and st.n_reruns == 0 and st.n_passes == 1
+                assert 688 < st.pass_rows[0] < 900, st.pass_rows[0]
+            assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
+            for l, lev in enumerate(tr["levels"]):
+                assert st.level_regions[l] == lev["B"].shape[0]
+                assert st.level_unique[l] == sum(f["U"] for f in lev["fwd"])
+                assert st.level_zoomed[l] == len(lev["indZ"])
+            Yall, Sall = net.ctx.last_candidates()
+            assert Yall.shape == tr["Y_all"].shape
+            assert np.abs(Sall.astype(np.float64) - tr["aScores"]).max() <= 1e-4
+            np.testing.assert_allclose(Yall, tr["Y_all"], rtol=1e-4, atol=2e-2)
 
 
 def test_deep_tree_takes_the_whole_tree_pass_too(small, mods):
@@ -151,7 +248,11 @@ def test_deep_tree_takes_the_whole_tree_pass_too(small, mods):
     z = _zooms(net, ffi, H, W, scale)
     for q in (0.2, 0.5):
         Tz = float(np.quantile(z, q))
-        _same(_run(net, ffi, H, W, scale, Tz, False, pair_spec=False), _run(net, ffi, H, W, scale, Tz, True))
+        base = _run(net, ffi, H, W, scale, Tz, False, pair_spec=False)
+        _same(base, _run(net, ffi, H, W, scale, Tz, True))
+        clos = _run(net, ffi, H, W, scale, Tz, "closure")
+        _same(base, clos)
+        assert clos["st"].n_reruns == 0 or clos["st"].search_form != 3
 
 
 def test_history_is_kept_per_image_shape(small, mods):
@@ -160,6 +261,7 @@ def test_history_is_kept_per_image_shape(small, mods):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
     net = HipAZNet(head, name="mixed")
+    net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)
     shapes = [(600, 1000, 1.0), (375, 500, 1.6), (480, 640, 1.25)]
     maps = [synth.make_feature_map(50 + i, synth.SMALL_DIMS["C"], synth.conv_out_size(int(round(H * sc))),
                                    synth.conv_out_size(int(round(W * sc)))) for i, (H, W, sc) in enumerate(shapes)]

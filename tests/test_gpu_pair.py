@@ -97,6 +97,7 @@ def test_history_turns_pair_speculation_on(small, mods):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
     net = HipAZNet(head, name="hist")
+    net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)      # (the decision below: not by this box's clock)
     net.set_conv(synth.make_feature_map(41, synth.SMALL_DIMS["C"], 38, 63))
     first = _run(net, ffi, 600, 1000, 1.0, 0.0, None)
     assert first["st"].n_passes == 3 and list(first["st"].pass_rows[:3])[0] == 48

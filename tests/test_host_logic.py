@@ -82,8 +82,13 @@ def test_ffi_struct_layout_matches_header():
     import ctypes
     from aznet_hip import ffi
     assert ctypes.sizeof(ffi.AzParams) == 8 + 6 * 8 + 4 * 4
-    # + spec_rows, root_deferred, static_plan, n_passes, pass_rows[16]
-    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4
+    # + spec_rows, root_deferred, static_plan, n_passes, pass_rows[16], search_form, n_reruns
+    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4 + 2 * 4
+    hdr0 = open(os.path.join(os.path.dirname(__file__), "..", "include", "aznet_hip.h")).read()
+    st_body = hdr0[hdr0.index("typedef struct {", hdr0.index("} az_params;")):hdr0.index("} az_stats;")]
+    import re as _re
+    names = _re.findall(r"int32_t\s+(\w+)(?:\[\w+\])?;", st_body)
+    assert names == [f[0] for f in ffi.AzStats._fields_], (names, [f[0] for f in ffi.AzStats._fields_])
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.3, num_proposals=300, batch_size=1000, speculate=False)
     assert (p.im_h, p.im_w, p.Tz, p.batch_size, p.fixed_num, p.reserved) == (600, 1000, 0.3, 1000, 1, 1)
     # the flag bits of params.reserved (include/aznet_hip.h)
@@ -94,9 +99,10 @@ def test_ffi_struct_layout_matches_header():
     assert mk(pair_spec=False) == 64 and mk(pair_spec=True) == 128
     assert mk(full_spec=False) == 256 and mk(full_spec=True) == 512
     assert mk(pair_spec=False, full_spec=True, static_tree=False) == 64 + 512 + 32
+    assert mk(full_spec="closure") == 512 + 1024
     import re
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "aznet_hip.h")).read()
-    for bit in range(10):
+    for bit in range(11):
         assert re.search(r"bit %d\b" % bit, hdr), "params.reserved bit %d is not documented in the header" % bit
 
 
