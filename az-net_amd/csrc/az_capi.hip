@@ -179,6 +179,12 @@ struct az_ctx {
     void *ev_a = nullptr, *ev_b = nullptr, *ev_c = nullptr, *ev_d = nullptr, *ev_e = nullptr, *ev_f = nullptr,
          *ev_g = nullptr, *ev_h = nullptr;
     size_t ev_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // front-end on a caller's stream (az_image_blob_dev_on): two pinned host slots and two device slots for the uint8 image,
+    // used in turn; a slot's event says its last upload + kernel are done
+    unsigned char *io_host[2] = {nullptr, nullptr}, *io_dev[2] = {nullptr, nullptr};
+    size_t io_cap = 0;
+    hipEvent_t io_ev[2] = {nullptr, nullptr};
+    int io_turn = 0;
     // pinned host staging
     AzCounts *h_cnt = nullptr;
     double *h_Y = nullptr;
@@ -554,6 +560,11 @@ int az_destroy(az_ctx *c)
     for (int i = 0; i < 3; ++i) {
         if (c->h_res[i]) hipHostFree(c->h_res[i]);
         if (c->ev_res[i]) hipEventDestroy(c->ev_res[i]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->io_host[i]) hipHostFree(c->io_host[i]);
+        if (c->io_dev[i]) hipFree(c->io_dev[i]);
+        if (c->io_ev[i]) hipEventDestroy(c->io_ev[i]);
     }
     if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_nmsb) hipHostFree(c->h_nmsb);
@@ -2743,6 +2754,43 @@ int az_image_blob_dev(az_ctx *c, const uint8_t *im, int h, int w, const float *m
     return image_blob_common(c, im, h, w, means, scale, blob_dev, true, oh, ow);
 }
 
+
+int az_image_blob_dev_on(az_ctx *c, const uint8_t *im, int h, int w, const float *means, double scale, float *blob_dev,
+                         int oh, int ow, void *stream)
+{
+    int eh, ew;
+    if (!c || !im || !means || !blob_dev || az_image_blob_size(h, w, scale, &eh, &ew) != AZ_OK || eh != oh || ew != ow)
+        return fail(c, AZ_ERR_INVALID, "az_image_blob_dev_on: bad arguments (output size must come from az_image_blob_size)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const size_t nin = (size_t)h * w * 3;
+    if (nin > c->io_cap) {
+        // (grow: nothing may still be reading the old slots)
+        for (int i = 0; i < 2; ++i) if (c->io_ev[i]) HIPCHK(c, hipEventSynchronize(c->io_ev[i]));
+        for (int i = 0; i < 2; ++i) {
+            if (c->io_host[i]) hipHostFree(c->io_host[i]);
+            if (c->io_dev[i]) hipFree(c->io_dev[i]);
+            c->io_host[i] = nullptr; c->io_dev[i] = nullptr;
+        }
+        c->io_cap = 0;
+        const size_t cap = nin + nin / 4 + 256;
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(c, hipHostMalloc((void **)&c->io_host[i], cap));
+            HIPCHK(c, hipMalloc((void **)&c->io_dev[i], cap));
+            if (!c->io_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->io_ev[i], hipEventDisableTiming));
+        }
+        c->io_cap = cap;
+    }
+    const int t = c->io_turn;
+    c->io_turn ^= 1;
+    HIPCHK(c, hipEventSynchronize(c->io_ev[t]));            // (the slot's previous image: two uploads ago, long done)
+    std::memcpy(c->io_host[t], im, nin);                    // the caller's array may go away as soon as this returns
+    HIPCHK(c, hipMemcpyAsync(c->io_dev[t], c->io_host[t], nin, hipMemcpyHostToDevice, s));
+    azk_image_blob(s, c->io_dev[t], h, w, means, 1.0 / scale, 1.0 / scale, oh, ow, blob_dev);
+    HIPCHK(c, hipEventRecord(c->io_ev[t], s));
+    HIPCHK(c, hipGetLastError());
+    return AZ_OK;
+}
 
 int az_set_graphs(az_ctx *c, int on)
 {

@@ -33,7 +33,7 @@ SYMBOLS = [
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
     "az_propose_launch_on", "az_set_feature_map_dev_nhwc", "az_set_pass_costs", "az_get_pass_costs",
-    "az_measure_box",
+    "az_measure_box", "az_image_blob_dev_on",
 ]
 
 
@@ -148,6 +148,7 @@ def load_library(path=None):
     L.az_image_blob_size.argtypes = [ci, ci, cd, cip, cip]
     L.az_image_blob_host.argtypes = [vp, u8p, ci, ci, fp, cd, fp, ci, ci]
     L.az_image_blob_dev.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci]
+    L.az_image_blob_dev_on.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci, vp]
     for name in SYMBOLS:
         if name not in ("az_version", "az_last_error", "az_stream"):
             getattr(L, name).restype = ci
@@ -324,6 +325,14 @@ class AzContext(object):
             self._ext_stream = torch.cuda.ExternalStream(int(self.L.az_stream(self.h)),
                                                          device=torch.device("cuda", self.device))
         self._ext_stream.wait_event(event)
+
+    def record_event(self):
+        """A torch.cuda.Event recorded on the ctx stream now: behind everything launched so far (e.g. a queued search)."""
+        import torch
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(int(self.L.az_stream(self.h)),
+                                                         device=torch.device("cuda", self.device))
+        return self._ext_stream.record_event()
 
     def propose_launch(self, params, fmap=None, producer_done=False, producer_event=None):
         """fmap (a CUDA torch tensor [1,C,H,W] / [C,H,W] on this GPU): hand the image's map over in the same call
@@ -620,9 +629,11 @@ class AzContext(object):
             raise AzError(rc, "az_image_blob_size: bad arguments")
         return oh.value, ow.value
 
-    def image_blob(self, im, means, scale, out=None):
+    def image_blob(self, im, means, scale, out=None, stream=None):
         """uint8 BGR HWC image -> [1,3,oh,ow] f32 blob (mean-subtracted, cv2-style bilinear).
-        out: None -> NumPy array; a CUDA torch tensor of the right shape -> filled in place."""
+        out: None -> NumPy array; a CUDA torch tensor of the right shape -> filled in place.
+        stream (with a tensor `out`): a raw hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream -- upload and
+        kernel are only ENQUEUED there (az_image_blob_dev_on), ordered with whatever that stream runs next."""
         im = np.ascontiguousarray(im, dtype=np.uint8)
         assert im.ndim == 3 and im.shape[2] == 3
         h, w = im.shape[:2]
@@ -635,6 +646,10 @@ class AzContext(object):
                                                 float(scale), _p(blob, ctypes.c_float), oh, ow))
             return blob
         assert tuple(out.shape[-3:]) == (3, oh, ow) and out.is_contiguous() and out.is_cuda
+        if stream is not None:
+            self._chk(self.L.az_image_blob_dev_on(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float), float(scale),
+                                                  ctypes.c_void_p(out.data_ptr()), oh, ow, ctypes.c_void_p(int(stream))))
+            return out
         self._chk(self.L.az_image_blob_dev(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float),
                                            float(scale), ctypes.c_void_p(out.data_ptr()), oh, ow))
         return out

@@ -68,6 +68,15 @@ class HipAZNet(object):
         torch.cuda.current_stream(out.device).synchronize()
         return self.ctx.image_blob(im, pixel_means, scale, out=out)
 
+    def image_blob_enqueue(self, im, pixel_means, scale):
+        """As image_blob for a net with a backbone, without any host wait: upload and front-end kernel are enqueued on
+        torch's current stream (where the backbone runs next), az_image_blob_dev_on."""
+        import torch
+        oh, ow = self.ctx.image_blob_size(im.shape[0], im.shape[1], scale)
+        out = torch.empty((1, 3, oh, ow), dtype=torch.float32, device=self.backbone.device)
+        return self.ctx.image_blob(im, pixel_means, scale, out=out,
+                                   stream=torch.cuda.current_stream(out.device).cuda_stream)
+
     def compute_conv(self, data_blob):
         """Run the torch backbone on a [1,3,H,W] blob and hand conv5_3 to the HIP context."""
         if self.backbone is None:

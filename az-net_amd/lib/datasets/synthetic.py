@@ -18,7 +18,16 @@ class SyntheticImdb(imdb):
         self._classes = ["__background__"] + ["class%d" % i for i in range(1, 21)]   # VOC: 21
 
     def image_at(self, i):
-        return synth.make_image(self.image_index[i], self.height, self.width)
+        # (seeded generation takes ~10-20 ms per 600x1000 image, more than the GPU needs for it: an image is generated
+        #  once and kept, as a file would sit in the page cache; at most 256 images = 460 MB)
+        c = self.__dict__.setdefault("_im_cache", {})
+        k = self.image_index[i]
+        im = c.get(k)
+        if im is None:
+            im = synth.make_image(k, self.height, self.width)
+            if len(c) < 256:
+                c[k] = im
+        return im
 
     def image_path_at(self, i):
         return "synthetic://%d" % self.image_index[i]

@@ -52,7 +52,8 @@ def _defaults():
         MAX_SIZE=1000,       # long-side cap (experiments/cfgs/voc.yml:13 lowers it to 800)
         NMS=0.5,             # apply_nms threshold (post-detection only, test.py:467-484)
         SVM=False, BBOX_REG=True, DISPLAY=False,
-        NUM_PROPOSALS=300)
+        NUM_PROPOSALS=300,
+        PREFETCH=2)          # (not in the reference) images test_proposals reads ahead in a worker thread; 0: none
     # the 11 adjacency templates, relative to a region (config.py:149-154)
     subregion = [[0, 0, 1, 1],
                  [-0.5, 0, 0.5, 1], [0.5, 0, 1.5, 1], [0, -0.5, 1, 0.5], [0, 0.5, 1, 1.5],

@@ -124,6 +124,100 @@ def im_propose(net, im, return_conv=False, num_proposals=None, conv=None, stage=
     return Y
 
 
+# ---- the same search as two halves, so that a loop over images keeps the GPU fed -------------------------------------
+# im_propose is synchronous (the reference's contract): image -> blob -> backbone -> search -> boxes, the host waiting at
+# every arrow.  A dataset loop does not need the boxes of image i before it may START image i+1: _propose_start enqueues an
+# image's whole pipeline -- upload + front-end kernel + backbone on torch's stream, the search behind it on the ctx stream,
+# ordered on the device by events -- and returns; _propose_finish collects the boxes.  The GPU runs image after image
+# without waiting for Python; results are the same bits (same kernels, same order per image).
+def _can_queue(hnet, num_proposals=None):
+    fixed = not ((cfg.SEAR.FIXED_PROPOSAL_NUM is False) and (num_proposals is None))
+    return fixed and getattr(hnet, "backbone", None) is not None
+
+
+def _propose_start(net, im, num_proposals=None, after=None, stage=None):
+    """First half of im_propose.  after: a torch.cuda.Event the image's front-end + backbone wait for on the device (the
+    previous image's search: the two would only compete for the same CUs).  stage: see HipAZNet.propose."""
+    import torch
+    hnet = net["full"] if isinstance(net, dict) else net
+    scale = _im_scale(im.shape)
+    if len(scale) != 1:
+        raise NotImplementedError("one test scale (cfg.TEST.SCALES), as in every config of the reference")
+    params = _params(im.shape, scale[0], num_proposals)
+    dev = hnet.backbone.device
+    if after is not None:
+        torch.cuda.current_stream(dev).wait_event(after)
+    blob = hnet.image_blob_enqueue(_as_uint8(im), cfg.PIXEL_MEANS, scale[0])
+    conv_t = hnet.backbone(blob)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    hnet.ctx.propose_launch(params, fmap=conv_t, producer_event=ev)
+    hnet._conv = conv_t
+    if stage is not None:
+        stage()
+    return {"shape": im.shape, "conv": conv_t, "blob": blob, "done": hnet.ctx.record_event()}
+
+
+def _propose_finish(net, h, return_conv=False):
+    """Second half of im_propose: wait for the search launched by _propose_start, format as im_propose does."""
+    hnet = net["full"] if isinstance(net, dict) else net
+    Y, st = hnet.ctx.propose_fetch(want_stats=True)
+    shape = h["shape"]
+    if cfg.SEAR.APPEND_BOXES:
+        Y = _append_boxes(Y)
+        Y[:, 0::4] = np.maximum(Y[:, 0::4], 0)
+        Y[:, 1::4] = np.maximum(Y[:, 1::4], 0)
+        Y[:, 2::4] = np.minimum(Y[:, 2::4], shape[1] - 1)
+        Y[:, 3::4] = np.minimum(Y[:, 3::4], shape[0] - 1)
+    print('{0} proposals, evaluate {1} regions, reaches depth {2}.'
+          .format(Y.shape[0], st.num_eval, st.depth))
+    if return_conv:
+        return Y, {name: h["conv"] for name in cfg.SEAR.FRCNN_CONV}
+    return Y
+
+
+def _prefetched(imdb, indices, depth=2):
+    """imdb.image_at(i) for i in indices, in order, read up to `depth` images ahead by a worker thread (decoding a JPEG or
+    reading an .npy takes as long as the GPU needs for an image).  depth <= 0: read in the caller's thread."""
+    def load(i):
+        return imdb.image_at(i) if hasattr(imdb, "image_at") else np.load(imdb.image_path_at(i))
+    if depth <= 0 or len(indices) <= 1:
+        for i in indices:
+            yield load(i)
+        return
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    stop = threading.Event()
+
+    def worker():
+        try:
+            for i in indices:
+                if stop.is_set():
+                    return
+                q.put(("im", load(i)))
+            q.put(("end", None))
+        except BaseException as e:                                  # noqa: BLE001 -- handed to the consumer
+            q.put(("err", e))
+    th = threading.Thread(target=worker, name="az-image-prefetch", daemon=True)
+    th.start()
+    try:
+        while True:
+            kind, val = q.get()
+            if kind == "end":
+                return
+            if kind == "err":
+                raise val
+            yield val
+    finally:
+        stop.set()
+        while th.is_alive():                                        # (unblock a worker waiting on a full queue)
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                th.join(0.01)
+
+
 def _frcnn_forward(net, im, all_boxes, num_classes, conv=None):
     """Fast R-CNN head over proposals on the cached conv map (test.py:259-318): one az_detect
     call (roi projection + dedup, RoIPool, fc6/fc7, cls_score softmax, bbox_pred decode + clip for
@@ -190,14 +284,32 @@ def test_proposals(net, imdb):
         os.makedirs(output_dir)
     _t = {'im_prop': Timer()}
     num_boxes = 0.0
-    for i in range(num_images):
-        im = imdb.image_at(i) if hasattr(imdb, "image_at") else np.load(imdb.image_path_at(i))
+    images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
+    if _can_queue(hnet):
+        # One image ahead: while the GPU works on image i the host reads image i+1 and enqueues its whole pipeline behind
+        # it.  Same boxes, same printed lines in the same order; the timer counts from one finished image to the next
+        # (what a per-image tic/toc adds up to when nothing overlaps).
+        pend = None
         _t['im_prop'].tic()
-        prop_boxes[i] = im_propose(net, im)
-        _t['im_prop'].toc()
-        # (num_boxes stays 0.0: the reference's per-image bookkeeping is commented out, test.py:515-526,
-        #  so its "On average, 0.0 boxes per image are generated" line is reproduced as is)
-        print('im_prop: {:d}/{:d} {:.3f}s'.format(i + 1, num_images, _t['im_prop'].average_time))
+        for i in range(num_images + 1):
+            nxt = None
+            if i < num_images:
+                nxt = _propose_start(net, next(images), after=(pend["done"] if pend is not None else None))
+            if pend is not None:
+                prop_boxes[i - 1] = _propose_finish(net, pend)
+                _t['im_prop'].toc()
+                print('im_prop: {:d}/{:d} {:.3f}s'.format(i, num_images, _t['im_prop'].average_time))
+                _t['im_prop'].tic()
+            pend = nxt
+    else:
+        for i in range(num_images):
+            im = next(images)
+            _t['im_prop'].tic()
+            prop_boxes[i] = im_propose(net, im)
+            _t['im_prop'].toc()
+            # (num_boxes stays 0.0: the reference's per-image bookkeeping is commented out, test.py:515-526,
+            #  so its "On average, 0.0 boxes per image are generated" line is reproduced as is)
+            print('im_prop: {:d}/{:d} {:.3f}s'.format(i + 1, num_images, _t['im_prop'].average_time))
     recall = 0            # the reference's recall bookkeeping is commented out (test.py:515-531)
     prop = {'boxes': prop_boxes, 'time': _t['im_prop'].average_time, 'recall': recall}
     prop_file = os.path.join(output_dir, 'proposals.pkl')

@@ -65,7 +65,7 @@ def main():
     torch.cuda.set_device(device)
     from datasets.factory import get_imdb
     from detect.config import get_output_dir
-    from detect.test import test_proposals, im_propose
+    from detect.test import test_proposals, im_propose, _propose_start, _propose_finish, _prefetched, _can_queue
     net = load_net(args.caffemodel, device)
     nets = {"full": net, "fc": net}
     imdb = get_imdb(args.imdb_name)
@@ -101,12 +101,30 @@ def main():
     gat = azdist.DeviceGather(net.ctx, int(cfg.SEAR.NUM_PROPOSALS), rows, dev) if fixed else None
     t = Timer()
     local = []
-    for j, i in enumerate(mine):
-        im = imdb.image_at(i)
+    images = _prefetched(imdb, mine, depth=int(cfg.TEST.get("PREFETCH", 2)))
+    if fixed and _can_queue(net):
+        # one image ahead, as detect.test.test_proposals: image j+1's pipeline (and the staging of its record) is enqueued
+        # while the GPU works on image j
+        pend = None
         t.tic()
-        Y = im_propose(nets, im, stage=(lambda j=j: gat.stage(j)) if fixed else None)
-        t.toc()
-        local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
+        for j in range(len(mine) + 1):
+            nxt = None
+            if j < len(mine):
+                nxt = _propose_start(nets, next(images), after=(pend["done"] if pend is not None else None),
+                                     stage=(lambda j=j: gat.stage(j)))
+            if pend is not None:
+                Y = _propose_finish(nets, pend)
+                t.toc()
+                t.tic()
+                local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
+            pend = nxt
+    else:
+        for j, i in enumerate(mine):
+            im = next(images)
+            t.tic()
+            Y = im_propose(nets, im, stage=(lambda j=j: gat.stage(j)) if fixed else None)
+            t.toc()
+            local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
     allp = gat.gather(len(mine)) if fixed else azdist.gather_proposals(local, device=dev)
     assert len(allp) == n
     if rank == 0:

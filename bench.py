@@ -8,17 +8,23 @@ One step = one pass of the hot path over one image: az_propose on the cached VGG
 of lib/detect/test.py:346-414 (roi projection + dedup, RoIPool, fc head, decode, filter, zoom select,
 divide_region, ..., top-300), 300 proposals copied back to the host.  The conv5_3 map is resident in HBM when the
 timed region starts (it is the hot path's input); the PyTorch backbone is timed separately (`end_to_end`).
-`value` is the LEVEL-BY-LEVEL form of the search -- the form every Tz > 0 takes, i.e. what tools/prop_az.py runs
-(cfg_set_mode('Test', Tz), config.py:272-280) -- at the Tz given (default 0: every zoom test passes, the full,
-deterministic tree of SURVEY 8d).  The one-pass form that exists only for Tz <= 0 is reported as `one_pass`.
+`value` is the search as a caller with ANY Tz gets it -- no use of "Tz <= 0, so the tree is known" (that plan is the
+extra key `one_pass`) -- at the Tz given (default 0: SURVEY 8d's full, deterministic tree).  The context picks the form of
+that search from the row counts of its previous search of the image shape: at Tz = 0 the history is a FULL tree, so the
+search's one head pass evaluates the full tree's 688 unique rois and every level finds its outputs by RoIPool window
+(`config.search_form` says which form ran).  A pruned tree -- what tools/prop_az.py's cfg_set_mode('Test', Tz > 0),
+config.py:272-280, produces -- takes other forms: `tz_sweep` times the same image at Tz = the 0.1 / 0.3 / 0.5 / 0.7
+quantiles of its zoom scores, each with its regions per level, rows per head pass, fraction of its own floor and the
+number of searches that had to be run twice; `level_loop_without_whole_tree_pass` is Tz = 0 in the two-pass form.
 Images shard one-per-GPU (rank r owns image seeds r, r + N, ...; weak scaling); proposals are exchanged with one
 RCCL all-gather per batch of images -- also on ONE GPU (a one-rank "nccl" group), so that N = 1 times the same
 code path as N = 8.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (the
 fp32-MFMA fc GEMM, timed with HIP events on the ctx stream during the timed steps) and `cpu_baseline` (the
-oracle's NumPy/C/BLAS restatement on the host cores).  Extra keys: `one_pass`, `calibrated_tz`, `deep_tree`
-(BASELINE config 4), `shared_detection` (config 3), `nms`, `pipelined`, `end_to_end`, `end_to_end_pipelined`.
+oracle's NumPy/C/BLAS restatement on the host cores), and `box`: what THIS box sustains (register-only fp32 MFMA loop,
+float4 copy) with `roofline.frac_of_sustained` beside `roofline.frac`.  Extra keys: `one_pass`, `tz_sweep`,
+`calibrated_tz`, `deep_tree` (BASELINE config 4), `shared_detection` (config 3), `nms`, `pipelined`, `end_to_end`.
 """
 import argparse
 import json
@@ -137,6 +143,10 @@ def main():
     ap.add_argument("--no-level-loop", action="store_true", help="(with --one-pass) skip the extra level-by-level measurement")
     ap.add_argument("--no-calibrated", action="store_true",
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip tz_sweep (the same image at four quantiles of its zoom scores)")
+    ap.add_argument("--e2e-pipelined", action="store_true",
+                    help="also time backbone(i+1) overlapped with search(i) (measured slower than the serial order on most boxes)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration (sustained MFMA rate, copy bandwidth)")
     ap.add_argument("--no-extras", action="store_true", help="skip deep_tree / shared_detection / nms")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch group (perturbs timing)")
     ap.add_argument("--sync-gather", action="store_true", help="blocking all-gather + host copy inside the loop")
@@ -220,7 +230,9 @@ def main():
     params = mk(one_pass_main)
 
     def barrier():
-        if dist_on:
+        # (a barrier among ONE rank has nobody to wait for: only the device synchronisation is left of it -- RCCL's barrier
+        #  is an all-reduce launch plus a stream wait, ~0.3 ms, which a 20-step timed region would carry as 1 %)
+        if dist_on and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -293,7 +305,7 @@ def main():
                 t_i = time.perf_counter()
                 if ahead and i + 1 < nsteps:
                     launch(i + 1)
-                net.ctx.propose_fetch(want_scores=True)
+                reruns[0] += int(net.ctx.propose_fetch(want_scores=True, want_stats=True)[2].n_reruns)
                 done(i)
                 if not ahead and i + 1 < nsteps:
                     launch(i + 1)
@@ -311,6 +323,7 @@ def main():
         for m in q:
             m.ctx.propose_fetch(want_scores=True)
 
+    reruns = [0]                       # searches of the loop that had to be run twice (az_stats.n_reruns)
     ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
     step_trace = []                    # host-side wall time of every step of the loop (diagnostics: median / tail in the line)
 
@@ -322,28 +335,34 @@ def main():
     first_ms = (time.perf_counter() - t0) * 1e3
     for n in nets[1:]:
         n.propose(params)
-    run(args.warmup, params)
+    # (no garbage-collector pause inside a timed region: a generation-2 collection of this process -- torch, numpy, the
+    #  411 MB of head arrays -- takes 30-50 ms, i.e. +0.17 ms per step when it lands among 200 timed steps.  It is run
+    #  HERE, before the warm-up: 40 ms of idle GPU right in front of a timed region would start it at idle clocks.)
+    import gc
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     net.propose(params)
     steady_ms = (time.perf_counter() - t0) * 1e3
+    # The chip leaves its idle clocks only gradually: the first ~30 ms of work after an idle gap (the collection above) run
+    # ~3 % slow.  40 untimed steps bring it to the state a dataset run is in; then the W warm-up steps of the contract.
+    run(40, params)
+    run(args.warmup, params)           # the W untimed warm-up steps, right in front of the timed region
     rccl["collectives"] = 0
     for n in nets:
         n.ctx.set_profiling(0)
         n.ctx.set_profiling((2 if args.profile_all else 1) | 4)   # fc GEMM events, accumulated
     ev_every[0] = args.event_every if args.inflight == 1 else 0
-    # (no garbage-collector pause inside a timed region: a generation-2 collection of this process -- torch, numpy, the
-    #  411 MB of head arrays -- takes 30-50 ms, i.e. +0.17 ms per step when it lands among 200 timed steps)
-    import gc
-    gc.collect()
-    gc.disable()
     barrier()
     del step_trace[:]
+    reruns[0] = 0
     t0 = time.perf_counter()
     run(args.steps, params)
+    t_loop = time.perf_counter() - t0
     barrier()
     dt = maxr(time.perf_counter() - t0)
-    gc.enable()
+    reruns_timed = reruns[0]
     steps_ms = np.array(step_trace[:args.steps]) if step_trace else np.zeros(1)
     ev_every[0] = 0
     n_timed_steps = len(range(0, args.steps, args.event_every)) if args.inflight == 1 else args.steps
@@ -351,6 +370,19 @@ def main():
     for n in nets:
         ktimes += n.ctx.last_kernel_times()
         n.ctx.set_profiling(0)
+    # `value` is EXACTLY --steps steps (the contract); a short run (the driver's 20 steps are a 25 ms timed region) is
+    # backed by the same loop over 200 steps, reported beside it
+    long_run = None
+    if args.steps < 100 and args.inflight == 1:
+        barrier()
+        t0 = time.perf_counter()
+        run(200, params)
+        barrier()
+        d200 = maxr(time.perf_counter() - t0)
+        long_run = {"steps": 200, "ms_per_step": d200 / 200 * 1e3, "value": world * NUM_PROPOSALS * 200 / d200,
+                    "unit": "proposals/s", "note": "the same timed loop over 200 steps, right behind the --steps run"}
+    box = None
+    gc.enable()
     # every launch group of the search against ITS bound, from HIP events on a few extra, untimed steps (an event pair
     # per launch group perturbs the stream by ~7 us each, so these steps are not part of `value`)
     net.set_conv(conv)
@@ -452,12 +484,19 @@ def main():
                                frac=by / HBM_PEAK * 1e6 / us)
             kernel_table.append(ent)
         floor_us = t_min_us(uniq, fmap_elems)
-        form = ("Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows) if st.static_plan else \
-               ("level by level (the form every Tz > 0 takes; the context's last search of this shape having walked the "
-                "full tree, ONE head pass evaluates the full tree's unique rois and every level finds its outputs by RoIPool "
-                "window -- zoom selection, divide_region, _sift_dup, dedup all run): head passes of %s rows" % (prow if prow else "?")
-                if (prow and len(prow) == 1 and not st.static_plan and prow[0] > int(st.spec_rows) + 1) else
-                "level by level (the form every Tz > 0 takes): head passes of %s rows" % (prow if prow else "?"))
+        form_name = ffi.SEARCH_FORMS.get(int(st.search_form), "?")
+        form = {
+            "one_pass_plan": "Tz <= 0, every zoom test passes: the %d RoIs of all levels in ONE head pass" % spec_rows,
+            "whole_tree_pass": "search for any Tz; this context's previous search of the shape walked the FULL tree, so ONE head "
+                               "pass evaluates the full tree's unique rois and every level finds its outputs by RoIPool window -- "
+                               "zoom selection, divide_region, _sift_dup, dedup all run level by level; a pruned tree does not "
+                               "take this form (see tz_sweep): head passes of %s rows" % (prow if prow else "?"),
+            "closure_pass": "search for any Tz; ONE head pass over the closure rows (every region any pruning of the shape's tree "
+                            "can produce), every level finds its outputs by RoIPool window: head passes of %s rows" % (prow if prow else "?"),
+            "pair_speculation": "level by level, some head passes also carrying the next level's rows: head passes of %s rows"
+                                % (prow if prow else "?"),
+            "level_loop": "level by level: head passes of %s rows" % (prow if prow else "?"),
+        }.get(form_name, "?")
         out = {
             "metric": "AZ proposals/sec (600x1000 img)", "value": value, "unit": "proposals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -468,7 +507,8 @@ def main():
                                    "conv5_3 %s resident in HBM, %d distinct images rotated" %
                                    (args.tz, regions, uniq, form, NUM_PROPOSALS, st.n_candidates,
                                     [int(x) for x in conv.shape], len(convs)),
-                       "search_form": "one_pass" if st.static_plan else "level_loop",
+                       "search_form": form_name, "rows_per_head_pass": prow,
+                       "searches_run_twice_in_timed_region": reruns_timed,
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
                        "host_queue_ahead": (0 if args.no_queue_ahead else 1),
@@ -482,6 +522,7 @@ def main():
                                    "(int6 below, int7_1|int7_2); v_mfma_f32_32x32x2_f32",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "frac_of_sustained": (achieved / box["sustained_fp32_mfma_tflops"]) if box else None,
                          "flops_per_launch": flops_per_image / (n_launch / max(n_timed_steps, 1)),
                          "avg_launch_ms": gemm_ms_total / n_launch,
                          "launches_per_step": n_launch / max(n_timed_steps, 1),
@@ -493,6 +534,12 @@ def main():
             "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
                            "frac": floor_us / (ms_step * 1e3),
                            "note": "t_min = BASELINE.md section 3: sum over the levels of max(bytes / 8 TB/s, flops / 157.3 TF)"},
+            "timed_region_ms": {"total": dt * 1e3, "loop_of_this_rank": t_loop * 1e3, "closing_barrier": (dt - t_loop) * 1e3},
+            "value_200_steps": long_run,
+            "box": box,
+            "head_pass_costs_us": {"table": [list(x) for x in net.ctx.pass_costs()],
+                                   "note": "one head pass (RoIPool + int6 + reduce + int7 + heads) at these row counts, measured by "
+                                           "the context on this device at its first launch: what it chooses the search form by"},
             "plan_build_ms": {"first_call_ms": first_ms, "steady_call_ms": steady_ms, "one_time_ms": max(first_ms - steady_ms, 0.0),
                               "note": "one-time work per image shape (shape-dependent pre-pass / plan, first-use allocations), "
                                       "done before the warm-up and not part of `value`"},
@@ -509,9 +556,9 @@ def main():
         }
 
     def timed_loop(fn, n, warm=10):
-        fn(warm)
-        gc.collect()
+        gc.collect()                   # (before the warm-up: see the main loop)
         gc.disable()
+        fn(warm)
         barrier()
         t = time.perf_counter()
         fn(n)
@@ -540,7 +587,7 @@ def main():
     other_wanted = (args.tz <= 0.0) and not (args.no_level_loop if one_pass_main else args.no_one_pass)
     if other_wanted:
         po = mk(not one_pass_main)
-        n_o = max(20, args.steps // 2)
+        n_o = max(100, args.steps // 2)
         net.propose(po)
         d_o = timed_loop(simple_run(po), n_o)
         net.set_conv(conv)
@@ -567,7 +614,7 @@ def main():
             int(st.pass_rows[0]) > int(st.spec_rows) + 1):
         pw = ffi.AzContext.make_params(H_IM, W_IM, scale0, args.tz, num_proposals=NUM_PROPOSALS, static_tree=False,
                                        full_spec=False)
-        n_w = max(20, args.steps // 2)
+        n_w = max(100, args.steps // 2)
         net.propose(pw)
         d_w = timed_loop(simple_run(pw), n_w)
         net.set_conv(conv)
@@ -578,7 +625,9 @@ def main():
                 "value": world * NUM_PROPOSALS * n_w / d_w, "unit": "proposals/s", "ms_per_image": d_w / n_w * 1e3,
                 "rows_per_pass": rows_per_pass(stw),
                 "path_floor_frac": t_min_us([int(stw.level_unique[l]) for l in range(stw.n_levels)], fmap_elems) / (d_w / n_w * 1e6),
-                "note": "the form a pruned tree takes (and round 3's `value` before the whole-tree pass): bit-identical results"}
+                "search_form": ffi.SEARCH_FORMS.get(int(stw.search_form), "?"),
+                "note": "Tz = 0 without the whole-tree pass: speculative rows, then level 4 + all children of level 4 -- the "
+                        "form a dense pruned tree takes; bit-identical results"}
     # ---- same work with three images in flight per GPU (three contexts / streams), for context ------
     if not args.no_pipelined and args.inflight == 1:
         NFL = 3
@@ -587,7 +636,7 @@ def main():
         for n in nets2[1:]:
             n.set_conv(conv)
             n.propose(params)
-        n_p = max(20, args.steps // 2)
+        n_p = max(100, args.steps // 2)
 
         def run2(k):
             q = []
@@ -640,7 +689,7 @@ def main():
             nf = HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096, gemm_mode=gm)
             nf.set_conv(conv)
             ent = {"dtype": label, "max_abs_err_vs_f64": err_vs_f64(nf), "fp32_mfma_path_err_vs_f64": e0}
-            n_f = max(20, args.steps // 2)
+            n_f = max(60, args.steps // 2)
             for key, prm in (("level_loop", mk(False)), ("one_pass", mk(True))):
                 if args.tz > 0 and key == "one_pass":
                     continue
@@ -711,7 +760,7 @@ def main():
         pc = ffi.AzContext.make_params(H_IM, W_IM, scale0, tz_c, num_proposals=NUM_PROPOSALS)
         Yc, stc = net.propose(pc, want_stats=True)
 
-        n_c = max(10, args.steps // 2)
+        n_c = max(100, args.steps // 2)
         # (the calibrated threshold belongs to convs[0]'s image: that map only)
         convs_keep = convs[:]
         del convs[1:]
@@ -725,9 +774,68 @@ def main():
                 "ms_per_image": dc / n_c * 1e3,
                 "regions_per_level": [int(stc.level_regions[l]) for l in range(stc.n_levels)],
                 "unique_per_level": uc, "rows_per_pass": rows_per_pass(stc),
+                "search_form": ffi.SEARCH_FORMS.get(int(stc.search_form), "?"),
                 "path_floor": {"t_min_us_per_image": fl_c, "frac": fl_c / (dc / n_c * 1e6)},
                 "note": "same image and weights, zoom threshold at the median zoom score of the regions of levels "
                         "2-3: a partially expanded, data-dependent tree"}
+    # ---- the searches a tuned Tz > 0 produces: the same image at four quantiles of its own zoom scores ----------------
+    if not args.no_sweep:
+        net.set_conv(conv)
+        net.propose(ffi.AzContext.make_params(H_IM, W_IM, scale0, 0.0, num_proposals=NUM_PROPOSALS, tune=True))
+        zz = np.sort(net.ctx.last_anchors()[1].astype(np.float64)[1:])        # every region of the full tree but the root
+        convs_keep = convs[:]
+        del convs[1:]                                    # (the thresholds belong to convs[0]'s image)
+        n_s = max(100, args.steps // 2)
+        pts = []
+        for q in (0.1, 0.3, 0.5, 0.7):
+            tz_q = float(np.quantile(zz, q))
+            pq = ffi.AzContext.make_params(H_IM, W_IM, scale0, tz_q, num_proposals=NUM_PROPOSALS)
+            net.set_conv(conv)
+            for _ in range(3):                           # (the context's history of this shape now is THIS tree)
+                net.propose(pq)
+            cnt_r = [0]
+
+            def fq(k, pq=pq):
+                if k > 0:
+                    net.ctx.propose_launch(pq, fmap=convs[0], producer_done=True)
+                for i in range(k):
+                    if i + 1 < k:
+                        net.ctx.propose_launch(pq, fmap=convs[0], producer_done=True)
+                    cnt_r[0] += int(net.ctx.propose_fetch(want_stats=True)[1].n_reruns)
+            gc.collect(); gc.disable()
+            fq(5)
+            cnt_r[0] = 0
+            barrier()
+            t = time.perf_counter()
+            fq(n_s)
+            barrier()
+            dq = maxr(time.perf_counter() - t)
+            gc.enable()
+            net.set_conv(conv)
+            Yq, stq = net.propose(pq, want_stats=True)
+            uq = [int(stq.level_unique[l]) for l in range(stq.n_levels)]
+            flq = t_min_us(uq, fmap_elems)
+            pts.append({"quantile": q, "Tz": tz_q, "ms_per_image": dq / n_s * 1e3,
+                        "value": world * Yq.shape[0] * n_s / dq, "unit": "proposals/s",
+                        "regions_per_level": [int(stq.level_regions[l]) for l in range(stq.n_levels)],
+                        "zoomed_per_level": [int(stq.level_zoomed[l]) for l in range(stq.n_levels)],
+                        "unique_per_level": uq, "rows_per_pass": rows_per_pass(stq),
+                        "search_form": ffi.SEARCH_FORMS.get(int(stq.search_form), "?"),
+                        "path_floor": {"t_min_us_per_image": flq, "frac": flq / (dq / n_s * 1e6)},
+                        "searches_run_twice": cnt_r[0], "timed_images": n_s})
+        convs[:] = convs_keep
+        net.set_conv(conv)
+        for _ in range(3):
+            net.propose(params)                          # (back to `value`'s tree as the shape's history)
+        if rank == 0:
+            out["tz_sweep"] = {"points": pts,
+                               "note": "convs[0]'s image, Tz at quantiles of the zoom scores of ALL regions of its full tree (untrained "
+                                       "weights: the scores drift with region size, so a quantile can empty the deep levels). Each "
+                                       "point: 3 untimed searches (the context's history of the shape becomes this tree), then "
+                                       "timed_images searches, queue-ahead, one image at a time.  path_floor = BASELINE.md section "
+                                       "3's per-level floor for THIS tree (every level one weight stream at 8 TB/s or its flops at "
+                                       "157.3 TF): a tree of a few dozen rois per level is five 54.6 us weight streams there, "
+                                       "which two head passes replace"}
     # ---- BASELINE configs 3 and 4 and the NMS kernel under this run's clock (kernel time from HIP events) -----------
     if not args.no_extras and rank == 0:
         out.update(extras(net, head, ffi, synth, HipDetNet, torch, args))
@@ -775,7 +883,7 @@ def main():
                 ev.record()
                 net.ctx.propose_fetch(want_scores=True)
             torch.cuda.synchronize()
-        dpp = timed_loop(run_e2e_pipe, n_e2e, warm=3)
+        dpp = timed_loop(run_e2e_pipe, n_e2e, warm=3) if args.e2e_pipelined else None
         if rank == 0:
             out["end_to_end"] = {"value": world * NUM_PROPOSALS * n_e2e / de, "unit": "proposals/s",
                                  "ms_per_image": de / n_e2e * 1e3,
@@ -787,13 +895,58 @@ def main():
                                          "weights and activations; its channels_last conv5_3 is borrowed in place); "
                                          "from_host_image also uploads the uint8 image over PCIe and runs the "
                                          "front-end kernel (az_image_blob_dev)"}
-            out["end_to_end_pipelined"] = {
+            if dpp is not None:
+              out["end_to_end_pipelined"] = {
                 "value": world * NUM_PROPOSALS * n_e2e / dpp, "unit": "proposals/s", "ms_per_image": dpp / n_e2e * 1e3,
                 "vs_serial": (de / n_e2e) / (dpp / n_e2e),
                 "note": "backbone of image i+1 (torch stream, channels-last output borrowed in place) enqueued while the "
                         "search of image i runs (ctx stream); the hand-over is an event wait on the device.  Measured for the "
                         "record: both saturate the GPU, and the search's persistent one-workgroup-per-CU GEMM shares the "
                         "CUs badly with MIOpen's kernels -- vs_serial < 1 means the serial order (end_to_end) is the faster one"}
+    # ---- the CLI's loop: detect.test.test_proposals over a synthetic imdb (what tools/prop_az.py runs) ----------------
+    if not args.no_e2e and rank == 0:
+        import contextlib
+        import io as _io
+        import pickle as _pickle
+        from datasets.factory import get_imdb
+        from detect import config as dcfg
+        from detect import test as dtest
+        dcfg.cfg_set_mode("Test", args.tz)
+        dcfg.cfg.EXP_DIR = "bench_cli_%d" % os.getpid()
+        imdb_cli = get_imdb("synthetic_%dx%d_64" % (H_IM, W_IM))
+        for i in range(len(imdb_cli.image_index)):
+            imdb_cli.image_at(i)                         # (generated once; a dataset's files would be in the page cache)
+        times = []
+        for rep in range(2):                             # (the first pass of a shape builds its plan: not counted)
+            with contextlib.redirect_stdout(_io.StringIO()):
+                pf = dtest.test_proposals({"full": net, "fc": net}, imdb_cli)
+            with open(pf, "rb") as f:
+                times.append(float(_pickle.load(f)["time"]))
+        try:
+            os.remove(pf)
+        except OSError:
+            pass
+        out["cli"] = {"ms_per_image": times[-1] * 1e3, "proposals_per_s": NUM_PROPOSALS / times[-1],
+                      "first_pass_ms_per_image": times[0] * 1e3, "images": len(imdb_cli.image_index),
+                      "vs_end_to_end": (out["end_to_end"]["from_host_image_ms"] / (times[-1] * 1e3)) if "end_to_end" in out else None,
+                      "note": "seconds per image as detect.test.test_proposals reports them (proposals.pkl['time']) over "
+                              "synthetic_600x1000_64: image from the imdb (read ahead by a worker thread), PCIe upload + "
+                              "front-end kernel + VGG16 + search enqueued one image ahead of the GPU, boxes to the host, the "
+                              "reference's per-image print lines.  vs_end_to_end = end_to_end.from_host_image_ms over this "
+                              "(> 1: the harness loop is faster than the one-image-at-a-time sequence timed there)"}
+        net.set_conv(conv)
+    # what this box holds under the matrix pipe and through HBM (register-only MFMA loop, float4 copy);
+    # measured LAST: 40 ms of a saturated matrix pipe and HBM leave the chip ~8 % slower for the next tens of ms
+    if not args.no_box:
+        mf, cp = net.ctx.measure_box()
+        box = {"sustained_fp32_mfma_tflops": mf, "copy_tb_per_s": cp,
+               "data_sheet_fp32_mfma_tflops": PEAK_F32_MFMA_TFLOPS, "data_sheet_hbm_tb_per_s": HBM_PEAK / 1e12,
+               "note": "az_measure_box: ~3 ms register-only v_mfma_f32_32x32x2_f32 loops on all SIMDs, pseudo-random "
+                       "operands (median of 7); best median of three float4-copy launch shapes over 1 GiB, bytes read + "
+                       "written.  frac_of_sustained = roofline.achieved over the MFMA figure"}
+    if rank == 0 and box is not None:
+        out["box"] = box
+        out["roofline"]["frac_of_sustained"] = out["roofline"]["achieved"] / box["sustained_fp32_mfma_tflops"]
     if rank == 0 and not args.no_cpu_baseline:
         fm = conv.detach().cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(head, fm, args.tz)

@@ -133,7 +133,8 @@ int az_set_limits(az_ctx *ctx, int max_regions, int max_candidates);
  *                (measured: tests/test_gpu_gemm_modes.py), at 3/16 of the matrix-pipe cost;
  *   3            fp32 operands as THREE bf16 terms (24 mantissa bits: every fp32 value exactly), six bf16 MFMAs per
  *                product (all cross terms of order <= 2), fp32 accumulation: nothing of fp32's precision or range is
- *                given up; 6/16 of the matrix-pipe cost.
+ *                given up; 6/16 of the matrix-pipe cost.  (Operands must be finite and below bf16's largest value,
+ *                3.39e38: the terms of an inf are (inf, inf - inf), i.e. NaN where fp32 arithmetic gives +-inf.)
  * In modes 2 and 3 every launch, whatever its row count, uses the same per-row arithmetic (a roi's bits do not
  * depend on its batch), and int6 is the only layer that changes.  Any other value is AZ_ERR_INVALID. */
 int az_set_gemm_mode(az_ctx *ctx, int parts);
@@ -294,6 +295,13 @@ int az_image_blob_host(az_ctx *ctx, const uint8_t *im, int h, int w, const float
                        double scale, float *blob_out, int oh, int ow);
 int az_image_blob_dev(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means,
                       double scale, float *blob_dev, int oh, int ow);
+
+/* As az_image_blob_dev, as ONE step of a pipelined harness: the upload and the kernel are only enqueued -- on `stream`
+ * (a hipStream_t, e.g. the stream the backbone runs on; NULL: the ctx stream) -- and the call returns; `im` is copied to
+ * pinned staging before that, so the caller's array may be reused at once.  Whatever is enqueued on `stream` afterwards
+ * (the backbone) finds the blob complete; nothing else is synchronised. */
+int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means, double scale,
+                         float *blob_dev, int oh, int ow, void *stream);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /

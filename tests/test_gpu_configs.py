@@ -28,10 +28,10 @@ def mods():
 
 
 @pytest.fixture(scope="module")
-def full(mods):
+def full(mods, gemm_mode):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    return HipAZNet(head, name="full_cfg", max_regions=4096), head
+    return HipAZNet(head, name="full_cfg", max_regions=4096, gemm_mode=gemm_mode), head
 
 
 def _calibrated_tz(zs, q):

@@ -195,10 +195,10 @@ def test_history_turns_it_on_for_dense_trees_only(small, mods):
     assert e[2].n_passes == 1 and np.array_equal(e[0], a[0]) and np.array_equal(d[0], a[0])
 
 
-def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods):
+def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods, gemm_mode):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    net = HipAZNet(head, name="full_whole", max_regions=4096)
+    net = HipAZNet(head, name="full_whole", max_regions=4096, gemm_mode=gemm_mode)
     H, W = 600, 1000
     fmap = synth.make_feature_map(31, 512, 38, 63)
     net.set_conv(fmap)

@@ -29,10 +29,10 @@ def mods():
 
 
 @pytest.fixture(scope="module")
-def full(mods):
+def full(mods, gemm_mode):
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    net = HipAZNet(head, name="full", max_regions=4096)
+    net = HipAZNet(head, name="full", max_regions=4096, gemm_mode=gemm_mode)
     fmap = synth.make_feature_map(4, 512, 38, 63)
     net.set_conv(fmap)
     return net, head, fmap

@@ -154,3 +154,92 @@ def test_mode_values(mods):
     for bad in (1, 4, 5):
         with pytest.raises(ValueError):
             ffi.AzContext(0, gemm_mode=bad)
+
+
+# ---- adversarial operands for the exact three-bf16-term split (mode 3) against the fp32-MFMA path (mode 0) ---------------
+# A head built so that int6's PRE-activation sums come out of az_head_forward untouched: W6 holds 44 weight rows w_j and
+# their negatives, int7_1 is the identity on those 88 units and adj_bbox_j = relu(y_j) - relu(-y_j) = y_j (one of the two is
+# 0; every other weight is 0.0, and x + 0 is exact), so adj_bbox IS x . W6^T as the GEMM computed it.
+def _probe_head(w_rows):
+    n6, n71, n72 = 128, 88, 4
+    K6 = w_rows.shape[1]
+    W6 = np.zeros((n6, K6), np.float32)
+    W6[0:88:2] = w_rows
+    W6[1:88:2] = -w_rows
+    W71 = np.zeros((n71, n6), np.float32)
+    W71[np.arange(88), np.arange(88)] = 1.0
+    Wab = np.zeros((44, n71), np.float32)
+    Wab[np.arange(44), 2 * np.arange(44)] = 1.0
+    Wab[np.arange(44), 2 * np.arange(44) + 1] = -1.0
+    z = lambda *s: np.zeros(s, np.float32)          # noqa: E731
+    return {"W6": W6, "b6": z(n6), "W71": W71, "b71": z(n71), "W72": z(n72, n6), "b72": z(n72), "Was": z(11, n71),
+            "bas": z(11), "Wab": Wab, "bab": z(44), "Wz": z(1, n72), "bz": z(1)}
+
+
+def _probe_rois(n, seed, hw=256):
+    rng = np.random.RandomState(seed)
+    x1 = rng.uniform(0, hw - 80, n); y1 = rng.uniform(0, hw - 80, n)
+    return np.stack([np.zeros(n), x1, y1, x1 + rng.uniform(16, 70, n), y1 + rng.uniform(16, 70, n)], 1).astype(np.float32)
+
+
+def _int6_sums(HipAZNet, head, fmap, rois, mode):
+    net = HipAZNet(head, name="probe%d" % mode, gemm_mode=mode)
+    net.set_conv(fmap)
+    p5 = net.ctx.roi_pool(rois)                                     # (bit-exact kernel: the GEMM's A operand)
+    return net.ctx.head_forward(rois)[2].astype(np.float64), p5.astype(np.float64)
+
+
+def test_exact_split_on_adversarial_operands_is_as_good_as_fp32_mfma(mods):
+    """|x| and |w| spanning 2^+-60 (products of order one), subnormal activations, rows built to cancel: the error of the
+    three-bf16-term path against an f64 evaluation, relative to sum |w||x| (the forward-error scale of a dot product), is
+    of the size of the fp32-MFMA path's on the same operands -- the split gives up neither mantissa bits nor exponent
+    range.  (Mode 2's fp16 terms have no such range: it is not in this test.)"""
+    ffi, synth, HipAZNet, orc = mods
+    C, HW = 16, 16
+    rng = np.random.RandomState(11)
+    fmap = rng.standard_normal((1, C, HW, HW)).astype(np.float32)
+    w = rng.standard_normal((44, C, 49)).astype(np.float32)
+    big, tiny = np.float32(2.0 ** 60), np.float32(2.0 ** -60)
+    fmap[0, 0:4] *= big; w[:, 0:4] *= tiny                          # huge activations, tiny weights
+    fmap[0, 4:8] *= tiny; w[:, 4:8] *= big                          # and the other way round
+    fmap[0, 12] = np.abs(fmap[0, 12]) * np.float32(1e6)             # channels 12 / 13: equal activations, opposite weights --
+    fmap[0, 13] = fmap[0, 12]                                       # 1e6-sized terms that cancel to nothing
+    w[:, 13] = -w[:, 12]
+    fmap[0, 14:16] = (np.abs(fmap[0, 14:16]) * np.float32(1e-39)).astype(np.float32)     # subnormal activations
+    assert 0 < fmap[0, 14].max() < np.finfo(np.float32).tiny
+    head = _probe_head(w.reshape(44, C * 49))
+    rois = _probe_rois(40, 5)
+    err = {}
+    for mode in (0, 3):
+        y, p5 = _int6_sums(HipAZNet, head, fmap, rois, mode)
+        W = head["W6"][0:88:2].astype(np.float64)
+        truth = p5 @ W.T
+        scale = np.abs(p5) @ np.abs(W).T
+        assert np.isfinite(y).all() and (scale > 0).all()
+        err[mode] = float((np.abs(y - truth) / scale).max())
+    # (fp32 accumulation of 784 terms: a few 1e-7 of the scale either way)
+    assert err[0] < 2e-6 and err[3] < 2e-6, err
+    assert err[3] <= 2.0 * err[0] + 2.0 ** -22, err
+
+
+def test_a_non_finite_activation_stays_in_the_rois_that_see_it(mods):
+    """An inf or NaN in the map (a conv5_3 map is finite; this is the guard rail): on both paths every roi whose windows do
+    not hold the cell is bit-identical to the same map without it.  What the rois that DO see it get differs and is not part of
+    the contract: fp32 arithmetic carries +-inf through int6, the terms of a split inf are (inf, inf - inf = NaN), and the
+    ReLU behind int6 is an fmax, which returns the other operand for a NaN -- documented in include/aznet_hip.h."""
+    ffi, synth, HipAZNet, orc = mods
+    C, HW = 16, 16
+    rng = np.random.RandomState(12)
+    base = np.abs(rng.standard_normal((1, C, HW, HW))).astype(np.float32)
+    head = _probe_head(rng.standard_normal((44, C * 49)).astype(np.float32))
+    rois = _probe_rois(40, 6)
+    for bad in (np.inf, np.nan):
+        fmap = base.copy()
+        fmap[0, 9, 5, 7] = bad                                       # one cell of one channel
+        for mode in (0, 3):
+            y, p5 = _int6_sums(HipAZNet, head, fmap, rois, mode)
+            y0, _ = _int6_sums(HipAZNet, head, base, rois, mode)
+            hit = ~np.isfinite(p5).all(axis=1)
+            assert 0 < hit.sum() < len(rois)
+            assert np.isfinite(y0).all()
+            assert np.array_equal(y[~hit], y0[~hit]), (bad, mode)

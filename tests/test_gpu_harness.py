@@ -64,9 +64,12 @@ class _MapBackbone(object):
         self.torch, self.synth, self.C, self.fh, self.fw = torch, synth, C, fh, fw
         self.device = torch.device("cuda", 0)
         self.cur = 0
+        self.served = []          # images the imdb handed out, oldest first (the harness may read ahead of the backbone)
 
     def __call__(self, blob):
         assert tuple(blob.shape[:2]) == (1, 3)
+        if self.served:
+            self.cur = self.served.pop(0)
         m = self.synth.make_feature_map(40 + self.cur, self.C, self.fh, self.fw)
         return self.torch.from_numpy(m).to(self.device)
 
@@ -83,7 +86,7 @@ def _stub_imdb(synth, g, backbone):
             self.nms_dets = None
 
         def image_at(self, i):
-            backbone.cur = i
+            backbone.served.append(i)
             return synth.make_image(i, H, W)
 
         def image_path_at(self, i):

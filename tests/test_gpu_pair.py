@@ -115,12 +115,12 @@ def test_history_turns_pair_speculation_on(small, mods):
     assert sp2["st"].n_passes <= sp3["st"].n_passes
 
 
-def test_pair_speculation_full_head_vs_cpu_oracle_and_plain(mods):
+def test_pair_speculation_full_head_vs_cpu_oracle_and_plain(mods, gemm_mode):
     """Config A at the full head (25088 -> 4096 -> ...): the pair-speculation search equals the plain level loop bit
     for bit (all 8129 candidates) and the pure-CPU oracle within tolerance; a calibrated Tz as well."""
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    net = HipAZNet(head, name="full_pair", max_regions=4096)
+    net = HipAZNet(head, name="full_pair", max_regions=4096, gemm_mode=gemm_mode)
     fmap = synth.make_feature_map(4, 512, 38, 63)
     net.set_conv(fmap)
     onet = orc.OracleNet(head, feat_fn=lambda d: fmap)

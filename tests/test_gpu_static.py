@@ -153,12 +153,12 @@ def test_static_plan_with_graphs_and_staged_result(small, mods):
         net.ctx.set_graphs(False)
 
 
-def test_full_head_one_pass_bits_equal_level_loop(mods):
+def test_full_head_one_pass_bits_equal_level_loop(mods, gemm_mode):
     """Config A at the full head: the one-pass search (int6 through the 12-wave many-row GEMM of az_head12.hip) and the
     level loop (k_fc_splitk at 48 / 131 / 517 rows) give the same bits -- proposals, scores, all 8129 candidates."""
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    net = HipAZNet(head, name="full", max_regions=4096)
+    net = HipAZNet(head, name="full", max_regions=4096, gemm_mode=gemm_mode)
     net.set_conv(synth.make_feature_map(4, 512, 38, 63))
     a, b = _both(net, ffi, 600, 1000, 1.0, 0.0)
     assert a["st"].static_plan == 1 and a["st"].spec_rows == 688 and b["st"].static_plan == 0
