@@ -15,7 +15,7 @@
 
 #define AZ_VERSION_STR "aznet_hip 0.1 (gfx950)"
 
-struct AzEventRec { std::string name; int level; hipEvent_t a, b; };
+struct AzEventRec { std::string name; int level; hipEvent_t a, b; int slot; /* >= 0: an in-kernel span (a, b unused) */ };
 
 constexpr size_t RES_HDR = 1024;    // AzCounts, padded, at the head of the result block
 static_assert(sizeof(AzCounts) <= RES_HDR, "AzCounts outgrew its slot");
@@ -133,6 +133,13 @@ struct az_ctx {
     int last_full = 0;
     // the closure's rows of the shape last looked at by the cost model (0: not built): what the one pass would cost
     int n_rerun_total = 0;                    // searches this context has had to run twice (any reason) since it was created
+    // Two lanes (az_set_lanes): a second stream with its own per-search buffers (`twin`, an az_ctx of its own that shares
+    // this context's head weights) takes every other queued search, so that consecutive images overlap on the GPU -- one
+    // image's single-workgroup geometry kernels and its small head kernels run beside the other image's GEMM.
+    az_ctx *twin = nullptr, *owner = nullptr;
+    int lanes = 1, lane_next = 0, last_fetch_lane = 0;
+    std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
+    hipEvent_t ev_hand = nullptr;             // (in a twin) orders the lane behind the owner's stream when it reads the owner's map
     // cost of one head pass (RoIPool + int6 + reduce + int7 + heads) at a few row counts, measured on THIS device with HIP
     // events the first time a search is launched (calibrate_passes): what the choice between the search forms goes by
     struct PassCal { int state = 0; int n = 0; int rows[6] = {0}; double us[6] = {0}; } cal;   // state 0: not yet, 1: measured, -1: off
@@ -235,6 +242,12 @@ struct az_ctx {
     int profiling = 0;
     int event_errors = 0;              // hipEvent* calls that failed while profiling
     std::vector<AzEventRec> events;
+    // profiling bit 3: the fc GEMM launches time THEMSELVES (AzSpan: first workgroup in, last workgroup out on the 100 MHz
+    // clock) into slots of this ring -- exact also when another lane's kernels delay the launch, and free of the ~7 us of
+    // stream time an event pair costs
+    unsigned long long *span_ring = nullptr;
+    int span_next = 0;
+    static constexpr int SPAN_SLOTS = 32768;
     std::vector<hipEvent_t> event_pool;   // recycled events
     std::vector<void *> allocs;        // head-sized buffers (az_load_head)
     std::vector<void *> allocs_geom;   // geometry buffers (first use)
@@ -318,6 +331,11 @@ int ensure_geom(az_ctx *c)
     A(pred_w, R * AZ_NSUB * 4); A(score_w, R * AZ_NSUB); A(zoom_w, R); A(keep_w, R * AZ_NSUB); A(key_w, R * AZ_NSUB);
 #undef A
     if (hipMemset(c->ubox, 0, R * 4 * sizeof(double)) != hipSuccess) return fail(c, AZ_ERR_HIP, "hipMemset failed");
+    // (a search whose fused level kernel overflows is rerun by the host, but the kernels already enqueued behind it still
+    //  run, on whatever the level's inv_index buffer holds: it must always hold valid rows)
+    if (hipMemset(c->inv, 0, R * sizeof(int)) != hipSuccess || hipMemset(c->inv_odd, 0, R * sizeof(int)) != hipSuccess ||
+        hipMemset(c->index, 0, R * sizeof(int)) != hipSuccess)
+        return fail(c, AZ_ERR_HIP, "hipMemset failed");
     c->geom_ready = true;
     return AZ_OK;
 }
@@ -332,8 +350,12 @@ struct Timed {
         if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); return true; }
         return hipEventCreate(e) == hipSuccess;
     }
+    // AZ_TRACE=1 (debugging): every launch group is announced on stderr and waited for, so a faulting kernel is the one
+    // named last
+    static bool trace() { static const bool t = getenv("AZ_TRACE") && atoi(getenv("AZ_TRACE")); return t; }
     Timed(az_ctx *c_, const char *n, int l, int cls = 2) : c(c_), name(n), level(l)
     {
+        if (trace()) { fprintf(stderr, "az[%p]: %s L%d ...", (void *)c_, n, l); fflush(stderr); }
         on = (c_->profiling & 2) || ((c_->profiling & 1) && cls == 1);
         if (!on) return;
         // a failed event call drops this measurement (and is reported by az_last_kernel_times), never the search
@@ -343,15 +365,17 @@ struct Timed {
     }
     ~Timed()
     {
+        if (trace()) { const hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
         if (!on) return;
         if (hipEventRecord(b, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); ++c->event_errors; return; }
-        c->events.push_back({name, level, a, b});
+        c->events.push_back({name, level, a, b, -1});
     }
 };
 
 void clear_events(az_ctx *c)
 {
     for (auto &e : c->events) {
+        if (e.slot >= 0) continue;
         for (hipEvent_t ev : {e.a, e.b}) {
             if (c->event_pool.size() < 4096) c->event_pool.push_back(ev); else hipEventDestroy(ev);
         }
@@ -414,6 +438,16 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
                    azk_act_plane_elems(c->maxR, d.K6), c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
+    // (profiling bit 3: the fp32 GEMM launches record their own span instead of an event pair)
+    auto span_slot = [&](const char *name) -> unsigned long long * {
+        if (!(c->profiling & 8) || !c->span_ring || c->span_next >= az_ctx::SPAN_SLOTS) return nullptr;
+        const int sl = c->span_next++;
+        c->events.push_back({name, level, nullptr, nullptr, sl});
+        return c->span_ring + 2 * (size_t)sl;
+    };
+    const int prof_keep = c->profiling;
+    unsigned long long *ts6 = c->gemm_parts ? nullptr : span_slot("fc6_gemm");
+    if (ts6) c->profiling &= ~(1 | 2);                     // (no event pair around a launch that times itself)
     { Timed t(c, "fc6_gemm", level, 1);
       if (c->gemm_parts)
           azk_fc_gemm_terms(c->stream, c->pool5p, d.K6, azk_act_plane_elems(c->maxR, d.K6), c->W6p, d.K6, azk_weight_plane_elems(d.n6, d.K6), Uptr,
@@ -425,20 +459,24 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
           if (can12 && rows_hint >= c->gemm12_min_rows)
               // the caller knows the row count on the host (a one-pass plan): many rows -> one weight tile per 12 strips
               azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
-                            azk_fc_chunk(d.K6, c->S6), c->part);
+                            azk_fc_chunk(d.K6, c->S6), c->part, 0, ts6);
           else if (can12 && rows_hint == -1)
               // only the device knows the row count, and the last search had many rows at this level: the many-row
               // kernel takes the launch.  Both kernels are correct (and bit-identical) for any row count; a wrong guess
               // costs efficiency, never a result.
               azk_fc_gemm12(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6,
-                            azk_fc_chunk(d.K6, c->S6), c->part);
+                            azk_fc_chunk(d.K6, c->S6), c->part, 0, ts6);
           else
-              azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part);
+              azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part, 1 << 30, ts6);
       } }
+    c->profiling = prof_keep;
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
+    unsigned long long *ts7 = span_slot("fc7_gemm");
+    if (ts7) c->profiling &= ~(1 | 2);
     { Timed t(c, "fc7_gemm", level, 1);
-      azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part); }
+      azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part, 1 << 30, ts7); }
+    c->profiling = prof_keep;
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
       azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
                eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side,
@@ -532,9 +570,12 @@ int az_create(int device, az_ctx **out)
     return AZ_OK;
 }
 
+static void destroy_twin(az_ctx *c);
+
 int az_destroy(az_ctx *c)
 {
     if (!c) return AZ_ERR_INVALID;
+    destroy_twin(c);
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     clear_events(c);
@@ -566,6 +607,8 @@ int az_destroy(az_ctx *c)
         if (c->io_dev[i]) hipFree(c->io_dev[i]);
         if (c->io_ev[i]) hipEventDestroy(c->io_ev[i]);
     }
+    if (c->ev_hand) hipEventDestroy(c->ev_hand);
+    if (c->span_ring) hipFree(c->span_ring);
     if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_nmsb) hipHostFree(c->h_nmsb);
     if (c->h_nmsg) hipHostFree(c->h_nmsg);
@@ -611,6 +654,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         return fail(c, AZ_ERR_INVALID, "az_load_head: n71 + n72 too large for the tail kernel's LDS tile");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
     free_all(c);
     c->head_loaded = false;
     {
@@ -1533,7 +1577,10 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     return AZ_OK;
 }
 
-int az_propose_launch(az_ctx *c, const az_params *p)
+static int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes);
+
+// One search enqueued on THIS context's stream (the public az_propose_launch picks the lane first).
+static int launch_impl(az_ctx *c, const az_params *p)
 {
     int rc = check_ready(c, true);
     if (rc) return rc;
@@ -1666,13 +1713,6 @@ int az_set_feature_map_dev_nhwc(az_ctx *c, const float *dev_ptr, int C, int H, i
     return AZ_OK;
 }
 
-int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W, int channels_last)
-{
-    int rc = channels_last ? az_set_feature_map_dev_nhwc(c, dev_map, C, H, W)
-                           : set_feature_map_common(c, dev_map, false, C, H, W, false);
-    if (rc) return rc;
-    return az_propose_launch(c, p);
-}
 
 // Collect the result of the search at position `idx` of the pending queue (0 = the oldest; a fallback rerun sits at
 // the back) and remove it from the queue.
@@ -1749,13 +1789,13 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
         const float *cur_feat = c->feat;
         const int cur_H = c->d.H, cur_W = c->d.W;
         c->feat = q.feat; c->d.H = q.fH; c->d.W = q.fW;
-        int rc2 = az_propose_launch(c, &p2);
+        int rc2 = launch_impl(c, &p2);
         c->feat = cur_feat; c->d.H = cur_H; c->d.W = cur_W;
         if (rc2) return rc2;
         c->pend.back().feat = q.feat; c->pend.back().fH = q.fH; c->pend.back().fW = q.fW;
         c->pend.back().reruns = q.reruns + 1;
         ++c->n_rerun_total;
-        if (q.stage_dst && (rc2 = az_propose_stage_result_dev(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
+        if (q.stage_dst && (rc2 = stage_impl(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
         return fetch_entry(c, c->pend.size() - 1, boxes_out, scores_out, cap, n_out, st);
     };
     if ((h.err & 32) && q.is_static) {
@@ -1835,22 +1875,161 @@ static int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_o
     return AZ_OK;
 }
 
+// ---- lanes ----------------------------------------------------------------------------------------------------------
+static void destroy_twin(az_ctx *c)
+{
+    if (!c || !c->twin) return;
+    az_ctx *t = c->twin;
+    c->twin = nullptr;
+    // (the twin's allocation lists hold only its own buffers: the head's weights belong to the owner)
+    az_destroy(t);
+    c->lane_order.clear();
+    c->lane_next = 0;
+}
+
+// The second lane: an az_ctx with its own stream, staging and per-search buffers that READS this context's weights.
+static int ensure_twin(az_ctx *c)
+{
+    if (c->twin) return AZ_OK;
+    if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "two lanes need a loaded head");
+    az_ctx *t = nullptr;
+    int rc = az_create(c->device, &t);
+    if (rc) return fail(c, rc, "az_set_lanes: could not create the second lane");
+    t->owner = c;
+    t->maxR = c->maxR; t->maxCand = c->maxCand; t->maxCh = c->maxCh;
+    auto bail = [&](int code, const char *msg) { c->err = t->err.empty() ? msg : t->err; az_destroy(t); return code; };
+    if ((rc = ensure_geom(t)) != AZ_OK) return bail(rc, "second lane: geometry buffers");
+    t->d = c->d; t->d.H = t->d.W = 0;
+    t->S6 = c->S6; t->S7 = c->S7; t->gemm_parts = c->gemm_parts; t->w6_scale = c->w6_scale; t->spatial_scale = c->spatial_scale;
+    t->W6 = c->W6; t->b6 = c->b6; t->W7 = c->W7; t->b7 = c->b7; t->Wt = c->Wt; t->bt = c->bt; t->W6p = c->W6p;
+    const size_t R = (size_t)t->maxR;
+    const AzHeadDims &d = t->d;
+#define A(p, n) if ((rc = dalloc(t, &t->p, (n))) != AZ_OK) return bail(rc, "second lane: head buffers")
+    A(pool5, R * d.K6);
+    {
+        const size_t p6 = (size_t)t->S6 * R * d.n6, p7 = (size_t)t->S7 * R * d.n7;
+        A(part, p6 > p7 ? p6 : p7);
+    }
+    A(h6, R * d.n6); A(h7, R * d.n7);
+    if (t->gemm_parts) {
+        A(pool5p, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
+        if (hipMemsetAsync(t->pool5p, 0, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, t->stream) != hipSuccess ||
+            hipMemsetAsync(t->gscale, 0, 4 * sizeof(float), t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess)
+            return bail(AZ_ERR_HIP, "second lane: clearing the operand planes");
+    }
+#undef A
+    t->gemm12_env = c->gemm12_env; t->gemm12_min_rows = c->gemm12_min_rows; t->gemm12_dual_rows = c->gemm12_dual_rows;
+    t->head_loaded = true;
+    t->profiling = c->profiling; t->use_graphs = c->use_graphs; t->cal = c->cal;
+    c->twin = t;
+    return AZ_OK;
+}
+
+int az_set_lanes(az_ctx *c, int lanes)
+{
+    if (!c || c->owner || (lanes != 1 && lanes != 2)) return fail(c, AZ_ERR_INVALID, "az_set_lanes: 1 or 2");
+    if (!c->lane_order.empty() || !c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_set_lanes: searches are still queued");
+    c->lanes = lanes;
+    c->lane_next = 0;
+    return AZ_OK;
+}
+
+// The context (lane) the next search launched through the public entry points runs on.
+static az_ctx *next_lane(az_ctx *c, const az_params *p, int *lane_out, int *rc_out)
+{
+    *lane_out = 0; *rc_out = AZ_OK;
+    // (only searches that can be queued take turns: fixed proposal count, not the tuner's variant)
+    if (!c || c->owner || c->lanes != 2 || !c->head_loaded || (p && (!p->fixed_num || (p->reserved & 4)))) return c;
+    if (c->lane_next == 0) return c;
+    if ((*rc_out = ensure_twin(c)) != AZ_OK) return nullptr;
+    *lane_out = 1;
+    return c->twin;
+}
+
+void *az_last_stream(az_ctx *c)
+{
+    if (!c) return nullptr;
+    az_ctx *t = (!c->owner && !c->lane_order.empty() && c->lane_order.back() == 1 && c->twin) ? c->twin : c;
+    return (void *)t->stream;
+}
+
+void *az_next_stream(az_ctx *c)
+{
+    if (!c) return nullptr;
+    int lane, rc;
+    az_ctx *t = next_lane(c, nullptr, &lane, &rc);
+    return (void *)(t ? t->stream : c->stream);
+}
+
+static int launch_routed(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W, int channels_last)
+{
+    if (!c) return AZ_ERR_INVALID;
+    int lane, rc;
+    az_ctx *t = next_lane(c, p, &lane, &rc);
+    if (!t) return rc;
+    if (dev_map) {
+        // the map is handed to the lane that runs the search: an NCHW map is transposed on THAT lane's stream into that
+        // lane's copies, a channel-last one is borrowed
+        rc = channels_last ? az_set_feature_map_dev_nhwc(t, dev_map, C, H, W) : set_feature_map_common(t, dev_map, false, C, H, W, false);
+        if (rc) { if (t != c) c->err = t->err; return rc; }
+    } else if (t != c) {
+        // the map was set on the context itself: the lane reads it where it lies, behind whatever the context's stream
+        // still has to do to it (an un-awaited transpose)
+        t->feat = c->feat; t->d.H = c->d.H; t->d.W = c->d.W;
+        if (!t->ev_hand) HIPCHK(c, hipEventCreateWithFlags(&t->ev_hand, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(t->ev_hand, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(t->stream, t->ev_hand, 0));
+    }
+    if (t != c) {
+        if (t->cal.state == 0 && c->cal.state != 0) t->cal = c->cal;
+        t->profiling = c->profiling; t->use_graphs = c->use_graphs;
+    }
+    rc = launch_impl(t, p);
+    if (rc) { if (t != c) c->err = t->err; return rc; }
+    if (t == c && c->cal.state == 1 && c->twin && c->twin->cal.state == 0) c->twin->cal = c->cal;
+    c->lane_order.push_back(lane);
+    if (c->lanes == 2 && p->fixed_num && !(p->reserved & 4)) c->lane_next ^= 1;
+    return AZ_OK;
+}
+
+int az_propose_launch(az_ctx *c, const az_params *p)
+{
+    if (c && c->owner) return launch_impl(c, p);
+    return launch_routed(c, p, nullptr, 0, 0, 0, 0);
+}
+
+int az_propose_launch_on(az_ctx *c, const az_params *p, const float *dev_map, int C, int H, int W, int channels_last)
+{
+    if (!dev_map) return fail(c, AZ_ERR_INVALID, "az_propose_launch_on: null map");
+    return launch_routed(c, p, dev_map, C, H, W, channels_last);
+}
+
 int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
 {
-    if (!c || c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");
+    if (!c || c->lane_order.empty()) return fail(c, AZ_ERR_STATE, "az_propose_fetch without az_propose_launch");
     if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_propose_fetch: bad arguments");
-    return fetch_entry(c, 0, boxes_out, scores_out, cap, n_out, st);
+    const int lane = c->lane_order.front();
+    c->lane_order.pop_front();
+    az_ctx *t = lane ? c->twin : c;
+    if (!t || t->pend.empty()) return fail(c, AZ_ERR_STATE, "az_propose_fetch: the lane's queue is empty");
+    c->last_fetch_lane = lane;
+    const int rc = fetch_entry(t, 0, boxes_out, scores_out, cap, n_out, st);
+    if (rc && t != c) c->err = t->err;
+    return rc;
 }
 
 int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_out, int cap, int *n_out,
                az_stats *st)
 {
-    // (launch + fetch of the SAME search: with another search still queued the fetch would return that one's result)
-    if (c && !c->pend.empty())
+    // (launch + fetch of the SAME search, on the context's own lane: with another search still queued the fetch would
+    //  return that one's result)
+    if (c && (!c->lane_order.empty() || !c->pend.empty()))
         return fail(c, AZ_ERR_STATE, "az_propose: a search launched with az_propose_launch is still queued, fetch it first");
-    int rc = az_propose_launch(c, p);
+    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_propose: bad arguments");
+    int rc = launch_impl(c, p);
     if (rc) return rc;
-    return az_propose_fetch(c, boxes_out, scores_out, cap, n_out, st);
+    if (c) c->last_fetch_lane = 0;
+    return fetch_entry(c, 0, boxes_out, scores_out, cap, n_out, st);
 }
 
 int az_measure_box(az_ctx *c, double *mfma_f32_tflops, double *copy_tb_per_s)
@@ -1873,6 +2052,7 @@ int az_set_pass_costs(az_ctx *c, int n, const int32_t *rows, const double *us)
     for (int i = 0; i < n; ++i) { c->cal.rows[i] = rows[i]; c->cal.us[i] = us[i]; }
     c->cal.n = n;
     c->cal.state = n ? 1 : 0;
+    if (c->twin) c->twin->cal = c->cal;
     return AZ_OK;
 }
 
@@ -1899,6 +2079,16 @@ int az_result_record_layout(int k, size_t *bytes, size_t *n_off, size_t *boxes_o
 int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
 {
     // (applies to the search launched last: call it right behind az_propose_launch)
+    if (!c) return AZ_ERR_INVALID;
+    az_ctx *t = (!c->owner && !c->lane_order.empty() && c->lane_order.back() == 1) ? c->twin : c;
+    if (!t) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev without az_propose_launch");
+    const int rc = stage_impl(t, dst_dev, cap_bytes);
+    if (rc && t != c) c->err = t->err;
+    return rc;
+}
+
+static int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes)
+{
     if (!c || c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev without az_propose_launch");
     az_ctx::PendingSearch &q = c->pend.back();
     if (!q.p.fixed_num) return fail(c, AZ_ERR_STATE, "az_propose_stage_result_dev: fixed proposal count only");
@@ -1915,6 +2105,12 @@ int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
 
 int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out)
 {
+    if (c && !c->owner && c->last_fetch_lane == 1 && c->twin) {
+        // (the search fetched last ran on the second lane: its candidates are in that lane's buffers)
+        const int r2 = az_last_candidates(c->twin, boxes_out, scores_out, cap, n_out);
+        if (r2) c->err = c->twin->err;
+        return r2;
+    }
     int rc = check_ready(c, false);
     if (rc) return rc;
     if (!n_out) return AZ_ERR_INVALID;
@@ -2222,8 +2418,8 @@ int az_load_det_head(az_ctx *c, int C, int n6, int n7, int ncls, const float *W6
 {
     if (!c) return AZ_ERR_INVALID;
     if (!W6 || !b6 || !W7 || !b7 || !Wc || !bc || !Wb || !bb) return fail(c, AZ_ERR_INVALID, "az_load_det_head: null pointer");
-    if (C <= 0 || (C & 3) || n6 <= 0 || (n6 & 3) || n7 <= 0 || (n7 & 3) || ncls < 2 || ncls > 64)
-        return fail(c, AZ_ERR_INVALID, "az_load_det_head: C, n6, n7 multiples of 4; 2 <= ncls <= 64");
+    if (C <= 0 || (C & 3) || n6 <= 0 || (n6 & 3) || n7 <= 0 || (n7 & 3) || ncls < 2 || ncls > 256)
+        return fail(c, AZ_ERR_INVALID, "az_load_det_head: C, n6, n7 multiples of 4; 2 <= ncls <= 256");
     if (c->head_loaded && C != c->d.C) return fail(c, AZ_ERR_INVALID, "az_load_det_head: C differs from the AZ head's");
     int rc = ensure_geom(c);
     if (rc) return rc;
@@ -2802,8 +2998,23 @@ int az_set_graphs(az_ctx *c, int on)
 int az_set_profiling(az_ctx *c, int on)
 {
     if (!c) return AZ_ERR_INVALID;
+    if (on & 8) {
+        // every slot starts as (first-in = ~0, last-out = 0); a slot is used once between two calls of this function
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!c->span_ring) HIPCHK(c, hipMalloc((void **)&c->span_ring, (size_t)az_ctx::SPAN_SLOTS * 16));
+        std::vector<unsigned long long> init((size_t)az_ctx::SPAN_SLOTS * 2);
+        for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
+        HIPCHK(c, hipMemcpy(c->span_ring, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+        // (spans recorded so far are gone with the slots)
+        std::vector<AzEventRec> keep;
+        for (auto &e : c->events) if (e.slot < 0) keep.push_back(e);
+        c->events.swap(keep);
+        c->span_next = 0;
+    }
     c->profiling = on;
     if (!on) clear_events(c);
+    if (c->twin) az_set_profiling(c->twin, on);
     return AZ_OK;
 }
 
@@ -2819,8 +3030,20 @@ int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *lev
         c->event_errors = 0;
         return fail(c, AZ_ERR_HIP, "az_last_kernel_times: " + std::to_string(ne) + " hipEvent call(s) failed while profiling");
     }
+    std::vector<unsigned long long> spans;
+    if (c->span_ring && c->span_next > 0) {
+        spans.resize((size_t)c->span_next * 2);
+        HIPCHK(c, hipMemcpy(spans.data(), c->span_ring, spans.size() * 8, hipMemcpyDeviceToHost));
+    }
     for (int i = 0; i < n && i < cap; ++i) {
         float ms = 0.f;
+        const int sl = c->events[i].slot;
+        if (sl >= 0) {
+            // 100 MHz ticks; a launch that left at once (another kernel owned it) or has not run reads as 0
+            const unsigned long long t0 = (size_t)sl * 2 + 1 < spans.size() ? spans[(size_t)sl * 2] : ~0ull;
+            const unsigned long long t1 = (size_t)sl * 2 + 1 < spans.size() ? spans[(size_t)sl * 2 + 1] : 0ull;
+            ms = (t0 != ~0ull && t1 > t0) ? (float)((double)(t1 - t0) * 1e-5) : 0.f;
+        } else
         if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess)
             return fail(c, AZ_ERR_HIP, "az_last_kernel_times: hipEventElapsedTime failed");
         if (ms_out) ms_out[i] = ms;
@@ -2829,6 +3052,15 @@ int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *lev
             std::memset(names_out + 32 * i, 0, 32);
             std::strncpy(names_out + 32 * i, c->events[i].name.c_str(), 31);
         }
+    }
+    if (c->twin) {
+        // the second lane's launches behind this lane's
+        const int n0 = n < cap ? n : cap;
+        int n2 = 0;
+        const int rc = az_last_kernel_times(c->twin, names_out ? names_out + 32 * (size_t)n0 : nullptr, ms_out ? ms_out + n0 : nullptr,
+                                            level_out ? level_out + n0 : nullptr, cap - n0, &n2);
+        if (rc) { c->err = c->twin->err; return rc; }
+        *n_out = n + n2;
     }
     return AZ_OK;
 }

@@ -81,6 +81,20 @@ static __device__ __forceinline__ unsigned score_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// A launch's own span on the constant 100 MHz clock (s_memrealtime): thread 0 of every workgroup folds its entry time
+// into ts[0] (min) and its exit time into ts[1] (max); ts == nullptr: nothing.  The host initialises a slot to (~0, 0).
+struct AzSpan {
+    unsigned long long *ts;
+    __device__ __forceinline__ explicit AzSpan(unsigned long long *t) : ts(t)
+    {
+        if (ts && threadIdx.x == 0) atomicMin(&ts[0], (unsigned long long)wall_clock64());
+    }
+    __device__ __forceinline__ ~AzSpan()
+    {
+        if (ts && threadIdx.x == 0) atomicMax(&ts[1], (unsigned long long)wall_clock64());
+    }
+};
+
 // ---- launchers (az_geom.hip) -----------------------------------------------------------
 void azk_init_root(hipStream_t s, AzCounts *cnt, double *B0, int im_h, int im_w);
 void azk_rois_keys(hipStream_t s, const double *B, const int *Pptr, int cap, double scale, float dedup,
@@ -261,10 +275,11 @@ void azk_tile_weights(hipStream_t s, const float *rowmajor, float *tiled, int N,
 // min_rows > 0: the kernel leaves at once when *Mptr is smaller (a launch whose row count only the device knows is
 // sent to both kernels, azk_fc_gemm with max_strips = (min_rows - 1) / 32).
 int azk_fc_gemm12_prepare();      // per device, with that device current; != 0: keep azk_fc_gemm for every launch
+// ts (may be NULL): two words the launch folds its own span into (AzSpan)
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
-                   int K, int S, int Kc, float *part, int min_rows = 0);
+                   int K, int S, int Kc, float *part, int min_rows = 0, unsigned long long *ts = nullptr);
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
-                 int N, int K, int S, float *part, int max_strips = 1 << 30);
+                 int N, int K, int S, float *part, int max_strips = 1 << 30, unsigned long long *ts = nullptr);
 int azk_fc_chunk(int K, int S);
 int azk_gemm_grid();
 // ---- int6 on the 16-bit matrix cores (az_head_terms.hip): operands as `parts` planes of 16-bit terms ----

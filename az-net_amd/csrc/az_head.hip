@@ -626,7 +626,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 __global__ void __launch_bounds__(256, 2)
 k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw,
             const int *Mptr, int capM, int N, int K, int S, int Kc, float *__restrict__ part, int max_strips,
-            int half_enabled)
+            int half_enabled, unsigned long long *ts)
 {
     __shared__ __attribute__((aligned(16))) float sA[2][BM * LDT];
     __shared__ __attribute__((aligned(16))) float sB[2][BN * LDT];
@@ -634,6 +634,9 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     const int M = *Mptr;
     if (M <= 0) return;
     if (((M + 31) >> 5) > max_strips) return;   // larger launches of this layer belong to another kernel
+    // ts (profiling): the launch's own span on the 100 MHz clock -- first workgroup in (ts[0], min), last workgroup out
+    // (ts[1], max) -- which an event pair cannot give when another stream's kernels hold the CUs the launch waits for
+    AzSpan span(ts);
     const int nt = (N + BN - 1) / BN;
     const int G = nt * S;                       // (n-tile, k-chunk) groups
     // With at least one group per workgroup, a workgroup owns whole groups and walks their
@@ -915,7 +918,8 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
 // the stacked [5*ncls, n7] weights; this finishes them per unique roi: slab sum + bias, Softmax
 // over the classes (Caffe: subtract the max, exp, sum in channel order, divide -- all f32), and
 // _bbox_pred + _clip_boxes of every class box against the roi's own anchor.
-// One wave per roi; lane c handles class c (ncls <= 64).
+// One wave per roi; lane l handles classes l, l + 64, l + 128, l + 192 (ncls <= 256: VOC's 21, COCO's 81 --
+// models/COCO/VGG16/frcnn/test_fc.prototxt:97-135).
 // ======================================================================================
 __global__ void __launch_bounds__(256)
 k_det_epilogue(const float *__restrict__ part, int capM, int S, int ncls, const float *__restrict__ bt,
@@ -927,6 +931,7 @@ k_det_epilogue(const float *__restrict__ part, int capM, int S, int ncls, const 
     const size_t slab = (size_t)capM * NO;
     const int lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int nslot = (ncls + 63) >> 6;                    // classes per lane (wave-uniform, <= 4)
     for (int u = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; u < U; u += nwaves) {
         const float *row = part + (size_t)u * NO;
         auto out = [&](int o) {
@@ -934,23 +939,38 @@ k_det_epilogue(const float *__restrict__ part, int capM, int S, int ncls, const 
             for (int s = 1; s < S; ++s) a += row[o + s * slab];
             return a + bt[o];
         };
-        const bool live = lane < ncls;
-        const float x = live ? out(lane) : -FLT_MAX;
-        float m = x;
+        float x[4], e[4];
+        float m = -FLT_MAX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            x[q] = (q < nslot && c < ncls) ? out(c) : -FLT_MAX;
+            m = x[q] > m ? x[q] : m;
+        }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { const float t = __shfl_xor(m, d, 64); m = t > m ? t : m; }
-        const float e = live ? expf(x - m) : 0.f;
-        float sum = 0.f;                                   // channel order, like Caffe's gemv with ones
-        for (int c = 0; c < ncls; ++c) sum += __shfl(e, c, 64);
-        if (live) {
-            prob_u[(size_t)u * ncls + lane] = e / sum;
-            float d4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                d4[q] = out(ncls + 4 * lane + q);
-                delta_u[(size_t)u * 4 * ncls + 4 * lane + q] = d4[q];
+        for (int q = 0; q < 4; ++q) e[q] = (q < nslot && lane + 64 * q < ncls) ? expf(x[q] - m) : 0.f;
+        float sum = 0.f;                                   // channel order, like Caffe's gemv with ones
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < nslot) {
+                const int cend = min(64, ncls - 64 * q);
+                for (int c = 0; c < cend; ++c) sum += __shfl(e[q], c, 64);
             }
-            az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * ncls + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = lane + 64 * q;
+            if (q < nslot && c < ncls) {
+                prob_u[(size_t)u * ncls + c] = e[q] / sum;
+                float d4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    d4[k] = out(ncls + 4 * c + k);
+                    delta_u[(size_t)u * 4 * ncls + 4 * c + k] = d4[k];
+                }
+                az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pred_u + ((size_t)u * ncls + c) * 4);
+            }
         }
     }
 }
@@ -1003,7 +1023,10 @@ void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW)
 // Fixed number of K chunks per layer (independent of M; see the header comment).
 int azk_fc_split(int K)
 {
-    if (K >= 16384) return 16;
+    // (AZ_SPLIT_BIG: measurements -- the number of chunks is part of a row's bits, so it is one per process)
+    static int big = -1;
+    if (big < 0) { const char *e = getenv("AZ_SPLIT_BIG"); big = (e && atoi(e) > 0) ? atoi(e) : 16; }
+    if (K >= 16384) return big;
     if (K >= 2048) return 8;
     if (K >= 512) return 2;
     return 1;
@@ -1017,7 +1040,7 @@ static int fc_chunk(int K, int S)
 }
 
 void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM,
-                 int N, int K, int S, float *part, int max_strips)
+                 int N, int K, int S, float *part, int max_strips, unsigned long long *ts)
 {
     static int half = -1;                  // AZ_GEMM_HALF=0: pad the last rows to a full strip instead (measurements)
     if (half < 0) {
@@ -1025,7 +1048,7 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
         half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0) | ((g && !atoi(g)) ? 8 : 0);
     }
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
-                       fc_chunk(K, S), part, max_strips, half);
+                       fc_chunk(K, S), part, max_strips, half, ts);
 }
 
 int azk_fc_chunk(int K, int S) { return fc_chunk(K, S); }

@@ -331,12 +331,13 @@ __device__ __forceinline__ int tile12(const float *__restrict__ X, int ldx, cons
 
 __global__ void __launch_bounds__(W_NT)
 k_fc_splitk12(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, int ldw, const int *Mptr, int capM,
-              int N, int K, int S, int Kc, float *__restrict__ part, int min_rows, int pair_mode)
+              int N, int K, int S, int Kc, float *__restrict__ part, int min_rows, int pair_mode, unsigned long long *ts)
 {
     extern __shared__ __attribute__((aligned(16))) float lds12[];
     float *sA = lds12, *sB = lds12 + 2 * W_BM * W_LDT;
     const int M = *Mptr;
     if (M <= 0 || M < min_rows) return;      // (fewer rows: k_fc_splitk, launched beside this kernel, owns the launch)
+    AzSpan span(ts);                         // (profiling: first workgroup in, last workgroup out -- az_dev.h)
     // strip slots: full strips, then (<= 16 trailing rows) one half-strip slot, the last slot of the last m-tile
     const bool has_half = (M & 31) != 0 && (M & 31) <= 16;
     const int strips = (M + 31) >> 5;
@@ -421,11 +422,11 @@ int azk_fc_gemm12_prepare()
 }
 
 void azk_fc_gemm12(hipStream_t s, const float *x, int ldx, const float *W, int ldw, const int *Mptr, int capM, int N,
-                   int K, int S, int Kc, float *part, int min_rows)
+                   int K, int S, int Kc, float *part, int min_rows, unsigned long long *ts)
 {
     static int grid = -1, pair = -1;    // AZ_GEMM12_GRID, AZ_GEMM12_PAIR=0: environment switches, the same for every device
     if (grid < 0) { const char *e = getenv("AZ_GEMM12_GRID"); grid = e ? atoi(e) : 256; }
     if (pair < 0) { const char *e = getenv("AZ_GEMM12_PAIR"); pair = (e && !atoi(e)) ? 0 : 1; }
     hipLaunchKernelGGL(k_fc_splitk12, dim3(grid), dim3(W_NT), lds12_bytes(), s, x, ldx, W, ldw, Mptr, capM, N, K, S, Kc, part, min_rows,
-                       pair);
+                       pair, ts);
 }

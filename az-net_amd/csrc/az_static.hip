@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
     __shared__ int part[16][SEL_I];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.cnt->err & 8) return;        // a fused level overflowed: its outputs are not there, the host reruns the search
     const int P = a.cnt->P[a.level], prev = a.cnt->ytot[a.level];
     const int Ns = P * AZ_NSUB, Nv = prev + Ns;
     if ((int)blockIdx.x < nbC) {

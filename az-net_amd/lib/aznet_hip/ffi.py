@@ -33,7 +33,7 @@ SYMBOLS = [
     "az_image_blob_host", "az_image_blob_dev", "az_nms_batched", "az_set_graphs",
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
     "az_propose_launch_on", "az_set_feature_map_dev_nhwc", "az_set_pass_costs", "az_get_pass_costs",
-    "az_measure_box", "az_image_blob_dev_on",
+    "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
 ]
 
 
@@ -135,6 +135,11 @@ def load_library(path=None):
     L.az_set_pass_costs.argtypes = [vp, ci, ip, dp]
     L.az_get_pass_costs.argtypes = [vp, ip, dp, ci, cip]
     L.az_measure_box.argtypes = [vp, dp, dp]
+    L.az_set_lanes.argtypes = [vp, ci]
+    L.az_next_stream.restype = vp
+    L.az_next_stream.argtypes = [vp]
+    L.az_last_stream.restype = vp
+    L.az_last_stream.argtypes = [vp]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
@@ -150,7 +155,7 @@ def load_library(path=None):
     L.az_image_blob_dev.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci]
     L.az_image_blob_dev_on.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci, vp]
     for name in SYMBOLS:
-        if name not in ("az_version", "az_last_error", "az_stream"):
+        if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream"):
             getattr(L, name).restype = ci
     if path is None:
         _lib = L
@@ -317,22 +322,29 @@ class AzContext(object):
             out.append(st)
         return out[0] if len(out) == 1 else tuple(out)
 
-    def wait_event(self, event):
-        """Make the ctx stream wait (on the device, no host synchronisation) for a torch.cuda.Event -- e.g. the one
-        recorded behind the backbone's last kernel on torch's stream."""
+    def _ext(self, handle):
+        """torch view of one of the context's HIP streams (by raw handle)."""
         import torch
-        if getattr(self, "_ext_stream", None) is None:
-            self._ext_stream = torch.cuda.ExternalStream(int(self.L.az_stream(self.h)),
-                                                         device=torch.device("cuda", self.device))
-        self._ext_stream.wait_event(event)
+        cache = self.__dict__.setdefault("_ext_streams", {})
+        s = cache.get(int(handle))
+        if s is None:
+            s = cache[int(handle)] = torch.cuda.ExternalStream(int(handle), device=torch.device("cuda", self.device))
+        return s
+
+    def wait_event(self, event):
+        """Make the stream the NEXT launched search runs on wait (on the device, no host synchronisation) for a
+        torch.cuda.Event -- e.g. the one recorded behind the backbone's last kernel on torch's stream."""
+        self._ext(self.L.az_next_stream(self.h)).wait_event(event)
+
+    def set_lanes(self, lanes):
+        """2: queued searches take turns between two streams of this context, so consecutive images overlap on the GPU
+        (az_set_lanes); 1: one stream (the default)."""
+        self._chk(self.L.az_set_lanes(self.h, int(lanes)))
+        self.lanes = int(lanes)
 
     def record_event(self):
-        """A torch.cuda.Event recorded on the ctx stream now: behind everything launched so far (e.g. a queued search)."""
-        import torch
-        if getattr(self, "_ext_stream", None) is None:
-            self._ext_stream = torch.cuda.ExternalStream(int(self.L.az_stream(self.h)),
-                                                         device=torch.device("cuda", self.device))
-        return self._ext_stream.record_event()
+        """A torch.cuda.Event recorded now on the stream of the search launched last: behind that search."""
+        return self._ext(self.L.az_last_stream(self.h)).record_event()
 
     def propose_launch(self, params, fmap=None, producer_done=False, producer_event=None):
         """fmap (a CUDA torch tensor [1,C,H,W] / [C,H,W] on this GPU): hand the image's map over in the same call
@@ -372,8 +384,9 @@ class AzContext(object):
             torch.cuda.current_stream(dev).synchronize()
         self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(ptr), C, H, W, cl))
         self._queued.append(params)
-        # (two searches may be queued: the previous one's map stays referenced until its fetch)
-        self._feat_keepalive_prev = self._feat_keepalive
+        # (up to four searches may be queued -- two per lane: their maps stay referenced until they are long fetched)
+        import collections
+        self.__dict__.setdefault("_feat_keep", collections.deque(maxlen=6)).append(fmap)
         self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
 

@@ -182,6 +182,18 @@ int az_propose_launch_on(az_ctx *ctx, const az_params *p, const float *dev_map, 
                          int channels_last);
 int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out,
                      az_stats *stats);
+/* Two lanes (default 1).  With 2, the searches launched through az_propose_launch(_on) take turns between the context's
+ * stream and a second stream with per-search buffers of its own (the head's weights are shared): while one image's GEMM holds
+ * the matrix cores, the other image's single-workgroup geometry kernels and small head kernels run beside it, so a loop that
+ * keeps two searches queued gets consecutive images OVERLAPPED on the GPU (~6 % more images per second at 600x1000).  Results,
+ * order of az_propose_fetch (oldest first) and every other call are unchanged; a lane queues up to two searches; the
+ * synchronous az_propose, the tuner's variant and variable proposal counts stay on the first lane.  Costs the second lane's
+ * buffers (pool5, split-K slabs, geometry: ~1.5 GB at max_regions 4096).  Call with nothing queued.
+ * az_next_stream: the hipStream_t the NEXT az_propose_launch(_on) will run on (make it wait for the map's producer there);
+ * az_last_stream: the one the most recently launched search runs on (record "search done" events there). */
+int az_set_lanes(az_ctx *ctx, int lanes);
+void *az_next_stream(az_ctx *ctx);
+void *az_last_stream(az_ctx *ctx);
 /* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size
  * records; the reference itself is single-process).  A fixed-count search (params.fixed_num) leaves
  * its result in HBM as ONE record of az_result_record_layout(k) bytes: int32 n at n_offset,
@@ -238,7 +250,8 @@ int az_nms_batched(az_ctx *ctx, const float *dets, const int32_t *offsets, int n
 /* ---- Fast R-CNN head on the shared conv map (BASELINE config 3) ---------------------- */
 /* Replaces caffe.Net(frcnn/test_fc.prototxt, caffemodel) (tools/test_shared.py): the detection
  * head models/Pascal/VGG16/frcnn/test_fc.prototxt:14-145 -- fc6 [n6, C*49], fc7 [n7, n6],
- * cls_score [ncls, n7] (+Softmax), bbox_pred [4*ncls, n7]; Caffe [out, in] layout. */
+ * cls_score [ncls, n7] (+Softmax), bbox_pred [4*ncls, n7]; Caffe [out, in] layout.  2 <= ncls <= 256 (VOC: 21;
+ * COCO, models/COCO/VGG16/frcnn/test_fc.prototxt:97-135: 81). */
 int az_load_det_head(az_ctx *ctx, int C, int n6, int n7, int ncls, const float *W6, const float *b6,
                      const float *W7, const float *b7, const float *Wc, const float *bc,
                      const float *Wb, const float *bb);
@@ -307,6 +320,10 @@ int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const flo
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /
  * az_head_forward.  mode bits: 1 = time only the fc GEMM launches, 2 = time every launch
  * group, 4 = keep accumulating across calls until read (otherwise each call starts afresh);
+ * 8 = the fp32 fc GEMM launches time THEMSELVES instead (first workgroup in to last workgroup out on the GPU's constant
+ * 100 MHz clock, written by the kernels: no event pair on the stream -- an event pair costs ~7 us of stream time and, with
+ * two lanes, also spans the time a launch waits for the other lane's GEMM to release the CUs); 32768 launches per call of
+ * az_set_profiling, which resets them;
  * 0 = off.  names_out: `cap` slots of 32 chars. */
 int az_set_profiling(az_ctx *ctx, int mode);
 int az_last_kernel_times(az_ctx *ctx, char *names_out, float *ms_out, int32_t *level_out,

@@ -239,15 +239,17 @@ def test_last_candidates_survives_counter_reuse_but_not_buffer_reuse(small, mods
 
 
 # ---------------------------------------------------------------- config 3 at its real size
-def test_full_size_det_head_vs_cpu_oracle(full, mods):
-    """Fast R-CNN head at the size of models/Pascal/VGG16/frcnn/test_fc.prototxt (fc6/fc7 4096, 21 classes)
+@pytest.mark.parametrize("ncls", [21, 81], ids=["voc21", "coco81"])
+def test_full_size_det_head_vs_cpu_oracle(full, mods, ncls):
+    """Fast R-CNN head at the size of models/Pascal/VGG16/frcnn/test_fc.prototxt (fc6/fc7 4096, 21 classes) and of
+    models/COCO/VGG16/frcnn/test_fc.prototxt:97-135 (81 classes: cls_score 81, bbox_pred 324)
     on the 300 proposals of a config-A search, vs the CPU oracle: cls_prob 1e-4, bbox_pred deltas 1e-4;
     az_detect (dedup + decode + un-dedup) vs oracle.frcnn_forward."""
     ffi, synth, HipAZNet, orc = mods
     from aznet_hip.net import HipDetNet
     net, head, fmap = full
     net.set_conv(fmap)
-    dhead = synth.make_det_head(seed=4242, **synth.FULL_DET_DIMS)
+    dhead = synth.make_det_head(seed=4242, **dict(synth.FULL_DET_DIMS, ncls=ncls))
     dnet = HipDetNet(dhead, net)
     H, W = 600, 1000
     props = net.propose(ffi.AzContext.make_params(H, W, 1.0, 0.0))
@@ -260,10 +262,41 @@ def test_full_size_det_head_vs_cpu_oracle(full, mods):
     np.testing.assert_allclose(b, br, rtol=1e-4, atol=1e-4)
     s, bx = net.ctx.detect(props, 1.0, H, W)
     odet = orc.OracleDetNet(dhead)
-    sr, bxr = orc.frcnn_forward({"fc": odet}, (H, W), 1.0, props, 21, {"conv5_3": fmap}, orc.OracleCfg())
-    assert s.shape == (300, 21) and bx.shape == (300, 84)
+    sr, bxr = orc.frcnn_forward({"fc": odet}, (H, W), 1.0, props, ncls, {"conv5_3": fmap}, orc.OracleCfg())
+    assert s.shape == (300, ncls) and bx.shape == (300, 4 * ncls)
+    assert np.abs(s.sum(axis=1) - 1.0).max() <= 1e-5
     assert np.abs(s - sr).max() <= 1e-4
     np.testing.assert_allclose(bx, bxr, rtol=1e-4, atol=2e-2)
+
+
+@pytest.mark.parametrize("ncls", [2, 63, 64, 65, 128, 129, 256])
+def test_det_head_class_counts_across_the_lane_boundaries(small, mods, ncls):
+    """k_det_epilogue gives a lane the classes l, l + 64, ...: class counts at and around the multiples of 64, softmax sum in
+    channel order, every class box decoded -- vs the CPU oracle at the small head; more than 256 classes is refused."""
+    ffi, synth, HipAZNet, orc = mods
+    from aznet_hip.net import HipDetNet
+    net, head = small
+    fmap = synth.make_feature_map(14, synth.SMALL_DIMS["C"], 38, 63)
+    net.set_conv(fmap)
+    dhead = synth.make_det_head(seed=7, **dict(synth.SMALL_DET_DIMS, ncls=ncls))
+    dnet = HipDetNet(dhead, net)
+    rng = np.random.RandomState(ncls)
+    x1 = rng.uniform(0, 900, 70); y1 = rng.uniform(0, 500, 70)
+    props = np.stack([x1, y1, x1 + rng.uniform(16, 90, 70), y1 + rng.uniform(16, 90, 70)], 1)
+    rois = orc.get_rois_blob(props, 1.0)
+    p, b = net.ctx.det_forward(rois)
+    pr, br = orc.det_head_forward(dhead, fmap[0], rois)
+    assert p.shape == (70, ncls) and b.shape == (70, 4 * ncls)
+    assert np.abs(p - pr).max() <= 1e-5
+    np.testing.assert_allclose(b, br, rtol=1e-4, atol=1e-5)
+    s, bx = net.ctx.detect(props, 1.0, 600, 1000)
+    sr, bxr = orc.frcnn_forward({"fc": orc.OracleDetNet(dhead)}, (600, 1000), 1.0, props, ncls, {"conv5_3": fmap}, orc.OracleCfg())
+    assert np.abs(s - sr).max() <= 1e-5
+    np.testing.assert_allclose(bx, bxr, rtol=1e-4, atol=2e-3)
+    if ncls == 256:
+        with pytest.raises(ffi.AzError):
+            HipDetNet(synth.make_det_head(seed=7, **dict(synth.SMALL_DET_DIMS, ncls=257)), net)
+        HipDetNet(dhead, net)
 
 
 def test_channels_last_map_is_borrowed_and_equal(small, mods):

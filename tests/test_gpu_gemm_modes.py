@@ -240,6 +240,10 @@ def test_a_non_finite_activation_stays_in_the_rois_that_see_it(mods):
             y, p5 = _int6_sums(HipAZNet, head, fmap, rois, mode)
             y0, _ = _int6_sums(HipAZNet, head, base, rois, mode)
             hit = ~np.isfinite(p5).all(axis=1)
+            if bad is np.nan:
+                # (RoIPool's max is `if (x > best)`, as Caffe's: a NaN cell never wins a bin -- nothing non-finite gets out)
+                assert hit.sum() == 0 and np.isfinite(y).all()
+                continue
             assert 0 < hit.sum() < len(rois)
             assert np.isfinite(y0).all()
             assert np.array_equal(y[~hit], y0[~hit]), (bad, mode)

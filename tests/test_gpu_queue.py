@@ -132,3 +132,142 @@ def test_rerun_under_graph_replay_with_a_staged_record(mods, kind):
         torch.cuda.synchronize()
         rec = azdist.unpack_device_record(buf.cpu().numpy(), layout, k)
         assert rec is not None and np.array_equal(rec[0], Yw) and np.array_equal(rec[1], Sw), (kind, rnd)
+
+
+# ---- two lanes (az_set_lanes): queued searches take turns between two streams of ONE context and overlap on the GPU --------
+@pytest.mark.parametrize("nan_zoom", [False, True])
+def test_two_lanes_equal_one_lane_bit_for_bit(mods, nan_zoom):
+    """Same sequence as test_queue_ahead_equals_alternating with az_set_lanes(2): mixed shapes, forms and reruns (NaN zoom
+    under the one-pass plan; a level that outgrows the fused kernels), results oldest first, equal to the one-at-a-time
+    context.  Then depth: each lane queues two searches, so four may be pending."""
+    import torch
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    if nan_zoom:
+        head["bz"] = np.full(1, np.nan, dtype=np.float32)
+    cases = _cases(ffi, synth)
+    maps = [torch.from_numpy(m).cuda() for _, m in cases]
+    ref_net = HipAZNet(head, name="l_ref")
+    want = []
+    for (p, _), m in zip(cases, maps):
+        ref_net.set_conv(m)
+        want.append(ref_net.propose(p, want_scores=True, want_stats=True))
+    net = HipAZNet(head, name="l_two")
+    net.ctx.set_lanes(2)
+    seq = list(range(len(cases))) * 3
+    for depth in (2, 4):
+        got, q = [], 0
+        for j in range(len(seq) + depth - 1):
+            if j < len(seq):
+                net.ctx.propose_launch(cases[seq[j]][0], fmap=maps[seq[j]])
+                q += 1
+            if q == depth or j >= len(seq):
+                got.append(net.ctx.propose_fetch(want_scores=True, want_stats=True))
+                q -= 1
+        assert len(got) == len(seq)
+        for j, i in enumerate(seq):
+            Y, S, st = got[j]
+            Yw, Sw, stw = want[i]
+            assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (depth, j, i)
+            assert st.num_eval == stw.num_eval and list(st.level_regions) == list(stw.level_regions)
+    with pytest.raises(ffi.AzError):
+        net.ctx.propose_fetch()
+
+
+def test_two_lanes_candidates_sync_calls_and_lane_switching(mods):
+    import torch
+    ffi, synth, HipAZNet = mods
+    net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="l_misc")
+    maps = [torch.from_numpy(synth.make_feature_map(3 + i, synth.SMALL_DIMS["C"], 38, 63)).cuda() for i in range(3)]
+    p = ffi.AzContext.make_params(600, 1000, 1.0, 0.2, static_tree=False)
+    ref = []
+    for m in maps:
+        net.set_conv(m)
+        Y, S = net.propose(p, want_scores=True)
+        ref.append((Y, S) + net.ctx.last_candidates())
+    net.ctx.set_lanes(2)
+    # the candidate list of the search fetched last, whichever lane ran it
+    for rnd in range(2):
+        for i, m in enumerate(maps):
+            net.ctx.propose_launch(p, fmap=m)
+            Y, S = net.ctx.propose_fetch(want_scores=True)
+            Ya, Sa = net.ctx.last_candidates()
+            assert np.array_equal(Y, ref[i][0]) and np.array_equal(Ya, ref[i][2]) and np.array_equal(Sa, ref[i][3]), (rnd, i)
+    # a synchronous call between queued ones is refused while something is queued, fine otherwise (first lane)
+    net.ctx.propose_launch(p, fmap=maps[0])
+    with pytest.raises(ffi.AzError):
+        net.propose(p)
+    with pytest.raises(ffi.AzError):
+        net.ctx.set_lanes(1)
+    net.ctx.propose_fetch()
+    net.set_conv(maps[1])
+    Y, S = net.propose(p, want_scores=True)
+    assert np.array_equal(Y, ref[1][0]) and np.array_equal(net.ctx.last_candidates()[0], ref[1][2])
+    # the map set on the context itself (not handed over with the launch) is read by whichever lane takes the search
+    net.set_conv(maps[2])
+    net.ctx.propose_launch(p)
+    net.ctx.propose_launch(p)
+    a = net.ctx.propose_fetch(want_scores=True)
+    b = net.ctx.propose_fetch(want_scores=True)
+    assert np.array_equal(a[0], ref[2][0]) and np.array_equal(b[0], ref[2][0]) and np.array_equal(b[1], ref[2][1])
+    # kernel times of both lanes come back together
+    net.ctx.set_profiling(2 | 4)
+    net.ctx.propose_launch(p, fmap=maps[0]); net.ctx.propose_launch(p, fmap=maps[1])
+    net.ctx.propose_fetch(); net.ctx.propose_fetch()
+    kt = net.ctx.last_kernel_times()
+    net.ctx.set_profiling(0)
+    assert sum(1 for n, l, ms in kt if n == "final_select" or n == "select") == 2
+    # back to one lane, a new head: the second lane goes away and comes back
+    net.ctx.set_lanes(1)
+    net.ctx.propose_launch(p, fmap=maps[0]); net.ctx.propose_launch(p, fmap=maps[1])
+    assert np.array_equal(net.ctx.propose_fetch(), ref[0][0]) and np.array_equal(net.ctx.propose_fetch(), ref[1][0])
+    net.ctx.set_lanes(2)
+    net.ctx.load_head(synth.make_head(seed=77, **synth.SMALL_DIMS))
+    net.ctx.propose_launch(p, fmap=maps[0]); net.ctx.propose_launch(p, fmap=maps[1]); net.ctx.propose_launch(p, fmap=maps[2])
+    for i in range(3):
+        assert np.array_equal(net.ctx.propose_fetch(), ref[i][0])
+
+
+@pytest.mark.parametrize("kind", ["nan_premise", "whole_tree_miss"])
+def test_two_lanes_rerun_with_a_staged_record(mods, kind):
+    """test_rerun_under_graph_replay_with_a_staged_record on both lanes: the search that is repeated inside propose_fetch and
+    its restaged record, whichever lane it ran on, with another search queued on the other lane."""
+    import torch
+    from aznet_hip import dist as azdist
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    if kind == "nan_premise":
+        head["bz"] = np.full(1, np.nan, dtype=np.float32)
+    fmap = torch.from_numpy(synth.make_feature_map(5, synth.SMALL_DIMS["C"], 38, 63)).cuda()
+    k = 300
+    ref = HipAZNet(head, name="lg_ref")
+    ref.set_conv(fmap)
+    if kind == "nan_premise":
+        p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k)
+        pref = ffi.AzContext.make_params(600, 1000, 1.0, 0.0, num_proposals=k, static_tree=False, full_spec=False)
+    else:
+        ref.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0, tune=True))
+        z = np.sort(ref.ctx.last_anchors()[1].astype(np.float64))
+        Tz = float(z[int(0.3 * (len(z) - 1))])
+        p = ffi.AzContext.make_params(600, 1000, 1.0, Tz, num_proposals=k, static_tree=False, full_spec=True)
+        pref = ffi.AzContext.make_params(600, 1000, 1.0, Tz, num_proposals=k, static_tree=False, full_spec=False,
+                                         pair_spec=False)
+    Yw, Sw = ref.propose(pref, want_scores=True)
+    net = HipAZNet(head, name="lg_run")
+    net.ctx.set_lanes(2)
+    net.ctx.set_graphs(True)
+    layout = ffi.AzContext.result_record_layout(k)
+    bufs = [torch.zeros(layout[0], dtype=torch.uint8, device="cuda") for _ in range(2)]
+    for rnd in range(4):
+        for b in bufs:
+            b.zero_()
+        for b in bufs:
+            net.ctx.propose_launch(p, fmap=fmap, producer_done=True)
+            net.ctx.stage_result(b.data_ptr(), layout[0])
+        for b in bufs:
+            Y, S = net.ctx.propose_fetch(want_scores=True)
+            assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (kind, rnd)
+        torch.cuda.synchronize()
+        for b in bufs:
+            rec = azdist.unpack_device_record(b.cpu().numpy(), layout, k)
+            assert rec is not None and np.array_equal(rec[0], Yw) and np.array_equal(rec[1], Sw), (kind, rnd)
