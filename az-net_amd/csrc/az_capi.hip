@@ -140,6 +140,12 @@ struct az_ctx {
     int lanes = 1, lane_next = 0, last_fetch_lane = 0;
     std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
     hipEvent_t ev_hand = nullptr;             // (in a twin) orders the lane behind the owner's stream when it reads the owner's map
+    void *comm = nullptr;                     // ncclComm_t of az_rccl_init
+    int comm_ranks = 0, comm_rank = 0;
+    // the collective runs on a stream of its own, behind events of the lanes: in a lane's stream it would hold that lane's
+    // next search back until the collective's kernel finds free CUs, i.e. until the OTHER lane's GEMM is done
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ev[2] = {nullptr, nullptr};
     // cost of one head pass (RoIPool + int6 + reduce + int7 + heads) at a few row counts, measured on THIS device with HIP
     // events the first time a search is launched (calibrate_passes): what the choice between the search forms goes by
     struct PassCal { int state = 0; int n = 0; int rows[6] = {0}; double us[6] = {0}; } cal;   // state 0: not yet, 1: measured, -1: off
@@ -576,6 +582,9 @@ int az_destroy(az_ctx *c)
 {
     if (!c) return AZ_ERR_INVALID;
     destroy_twin(c);
+    if (c->comm) { if (c->comm_stream) hipStreamSynchronize(c->comm_stream); azk_rccl_destroy(c->comm); c->comm = nullptr; }
+    if (c->comm_stream) { hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    for (auto &e : c->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     clear_events(c);
@@ -2065,6 +2074,56 @@ int az_get_pass_costs(az_ctx *c, int32_t *rows_out, double *us_out, int cap, int
     for (int i = 0; i < n; ++i) { if (rows_out) rows_out[i] = c->cal.rows[i]; if (us_out) us_out[i] = c->cal.us[i]; }
     return AZ_OK;
 }
+
+// ---- the exchange step of an image-sharded run, natively (az_rccl.hip) ------------------------------------------------
+int az_rccl_unique_id(void *id_out, size_t cap)
+{
+    if (!id_out || cap < 128) return AZ_ERR_INVALID;
+    std::string why;
+    return azk_rccl_unique_id(id_out, &why) ? AZ_ERR_HIP : AZ_OK;
+}
+
+int az_rccl_init(az_ctx *c, const void *id, size_t id_bytes, int nranks, int rank)
+{
+    if (!c || c->owner || !id || id_bytes < 128 || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(c, AZ_ERR_INVALID, "az_rccl_init: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    for (auto &e : c->comm_ev) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (c->comm) { HIPCHK(c, hipStreamSynchronize(c->comm_stream)); azk_rccl_destroy(c->comm); c->comm = nullptr; }
+    std::string why;
+    if (azk_rccl_init(id, nranks, rank, &c->comm, &why)) return fail(c, AZ_ERR_HIP, "az_rccl_init: " + why);
+    c->comm_ranks = nranks; c->comm_rank = rank;
+    return AZ_OK;
+}
+
+int az_gather_records(az_ctx *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank)
+{
+    if (!c || c->owner || !send_dev || !recv_dev || !bytes_per_rank) return fail(c, AZ_ERR_INVALID, "az_gather_records: bad arguments");
+    if (!c->comm) return fail(c, AZ_ERR_STATE, "az_gather_records: no communicator (az_rccl_init)");
+    HIPCHK(c, hipSetDevice(c->device));
+    // the records were staged on the lanes' streams: the collective's stream waits, on the device, for what both have
+    // queued so far
+    HIPCHK(c, hipEventRecord(c->comm_ev[0], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_ev[0], 0));
+    if (c->twin) {
+        HIPCHK(c, hipEventRecord(c->comm_ev[1], c->twin->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_ev[1], 0));
+    }
+    std::string why;
+    if (azk_rccl_all_gather(c->comm, c->comm_stream, send_dev, recv_dev, bytes_per_rank, &why))
+        return fail(c, AZ_ERR_HIP, "az_gather_records: " + why);
+    return AZ_OK;
+}
+
+int az_rccl_destroy(az_ctx *c)
+{
+    if (!c) return AZ_ERR_INVALID;
+    if (c->comm) { hipSetDevice(c->device); hipStreamSynchronize(c->comm_stream); azk_rccl_destroy(c->comm); c->comm = nullptr; }
+    return AZ_OK;
+}
+
+void *az_comm_stream(az_ctx *c) { return c ? (void *)c->comm_stream : nullptr; }
 
 int az_result_record_layout(int k, size_t *bytes, size_t *n_off, size_t *boxes_off, size_t *scores_off)
 {

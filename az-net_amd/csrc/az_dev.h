@@ -378,3 +378,10 @@ void azk_pool_keep(hipStream_t s, const float *pool, long long n, unsigned int k
 
 // ---- launcher (az_box.hip): what this box sustains (register-only fp32 MFMA loop on all SIMDs; float4 copy) ----------
 int azk_measure_box(hipStream_t s, double *mfma_tflops, double *copy_tbps, size_t copy_bytes);
+
+// ---- az_rccl.hip: RCCL bound at run time (the process's own librccl.so); 0 = ok, else *why ---------------------------------
+#include <string>
+int azk_rccl_unique_id(void *id128, std::string *why);
+int azk_rccl_init(const void *id128, int nranks, int rank, void **comm_out, std::string *why);
+int azk_rccl_all_gather(void *comm, hipStream_t s, const void *send, void *recv, size_t bytes, std::string *why);
+void azk_rccl_destroy(void *comm);

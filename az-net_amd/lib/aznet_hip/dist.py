@@ -130,11 +130,16 @@ class DeviceGather(object):
     There are TWO buffer pairs (`buf` = 0 / 1): a caller that launches the first search of the next batch before it
     gathers the current one (propose_launch queues up to two searches) stages that search into the other pair."""
 
-    def __init__(self, ctx, num_proposals, rows, device, group=None, always_collective=None):
+    def __init__(self, ctx, num_proposals, rows, device, group=None, always_collective=None, native=False):
+        """native=True: the exchange is ONE ncclAllGather issued by the library itself on the ctx stream
+        (az_gather_records; the communicator is made here -- rank 0's id reaches the others through torch.distributed,
+        the control plane -- and bound to the RCCL this process already holds); False: torch.distributed's
+        all_gather_into_tensor on torch's stream."""
         import torch
         import torch.distributed as dist
         from aznet_hip import ffi
         self.ctx, self.k, self.rows, self.group = ctx, int(num_proposals), int(rows), group
+        self.native = bool(native)
         # a process group of ONE rank still runs the collective (RCCL on the one GPU) unless told otherwise: the
         # single-GPU run then exercises the code path the 8-GPU run takes
         self.collective = dist.is_initialized() if always_collective is None else bool(always_collective)
@@ -153,6 +158,13 @@ class DeviceGather(object):
         self._side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._host = None
         self._busy = [False, False]
+        if self.native:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+            uid = [ffi.AzContext.rccl_unique_id() if rank == 0 else None]
+            if dist.is_initialized() and self.world > 1:
+                dist.broadcast_object_list(uid, src=0, group=group)
+            ctx.rccl_init(uid[0], self.world, rank)
+            self.collective = True
 
     def stage(self, j, buf=0):
         assert 0 <= j < self.rows
@@ -166,6 +178,16 @@ class DeviceGather(object):
         send, recv = self.bufs[buf]
         if n_local < self.rows:
             send[n_local:] = self._pad
+        if self.native:
+            # the pad write (torch's current stream) before the collective (the context's collective stream), the collective
+            # before whoever reads `recv` on torch's current stream: two event waits on the device, nothing on the host
+            import torch
+            cur = torch.cuda.current_stream(send.device)
+            ms = self.ctx.comm_stream()
+            ms.wait_stream(cur)
+            self.ctx.gather_records(send.data_ptr(), recv.data_ptr(), self.rows * self.rec_bytes)
+            cur.wait_stream(ms)
+            return recv, self.world
         if self.world > 1 or self.collective:
             # stage() copies ran on the ctx stream and are complete: az_propose_stage_result_dev re-records the event
             # propose_fetch waits for BEHIND the staging copy, and the caller has fetched every search of the batch.  The

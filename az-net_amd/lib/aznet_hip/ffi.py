@@ -34,6 +34,7 @@ SYMBOLS = [
     "az_set_feature_map_dev_async", "az_result_record_layout", "az_propose_stage_result_dev",
     "az_propose_launch_on", "az_set_feature_map_dev_nhwc", "az_set_pass_costs", "az_get_pass_costs",
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
+    "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
 ]
 
 
@@ -136,6 +137,12 @@ def load_library(path=None):
     L.az_get_pass_costs.argtypes = [vp, ip, dp, ci, cip]
     L.az_measure_box.argtypes = [vp, dp, dp]
     L.az_set_lanes.argtypes = [vp, ci]
+    L.az_rccl_unique_id.argtypes = [vp, ctypes.c_size_t]
+    L.az_rccl_init.argtypes = [vp, vp, ctypes.c_size_t, ci, ci]
+    L.az_gather_records.argtypes = [vp, vp, vp, ctypes.c_size_t]
+    L.az_rccl_destroy.argtypes = [vp]
+    L.az_comm_stream.restype = vp
+    L.az_comm_stream.argtypes = [vp]
     L.az_next_stream.restype = vp
     L.az_next_stream.argtypes = [vp]
     L.az_last_stream.restype = vp
@@ -155,7 +162,7 @@ def load_library(path=None):
     L.az_image_blob_dev.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci]
     L.az_image_blob_dev_on.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci, vp]
     for name in SYMBOLS:
-        if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream"):
+        if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream", "az_comm_stream"):
             getattr(L, name).restype = ci
     if path is None:
         _lib = L
@@ -416,6 +423,33 @@ class AzContext(object):
         if rc != AZ_OK:
             raise AzError(rc, "az_result_record_layout(%r)" % (num_proposals,))
         return tuple(int(x.value) for x in v)
+
+    # ---- the exchange step, natively (one ncclAllGather on the ctx stream) ---------------------------------------------
+    @staticmethod
+    def rccl_unique_id():
+        """128 bytes (made on rank 0, handed to the other ranks by the launcher) for rccl_init."""
+        L = load_library()
+        buf = ctypes.create_string_buffer(128)
+        rc = L.az_rccl_unique_id(buf, 128)
+        if rc != AZ_OK:
+            raise AzError(rc, "az_rccl_unique_id: no usable librccl.so in this process")
+        return bytes(buf.raw)
+
+    def rccl_init(self, uid, nranks, rank):
+        assert len(uid) == 128
+        self._chk(self.L.az_rccl_init(self.h, ctypes.create_string_buffer(uid, 128), 128, int(nranks), int(rank)))
+
+    def gather_records(self, send_ptr, recv_ptr, bytes_per_rank):
+        """ncclAllGather of this rank's staged records (az_gather_records): enqueued on the ctx stream."""
+        self._chk(self.L.az_gather_records(self.h, ctypes.c_void_p(int(send_ptr)), ctypes.c_void_p(int(recv_ptr)),
+                                           int(bytes_per_rank)))
+
+    def rccl_destroy(self):
+        self._chk(self.L.az_rccl_destroy(self.h))
+
+    def comm_stream(self):
+        """torch view of the stream az_gather_records runs on (exists after rccl_init)."""
+        return self._ext(self.L.az_comm_stream(self.h))
 
     def stage_result(self, dst_ptr, cap_bytes):
         """Between propose_launch and propose_fetch: enqueue a device-to-device copy of the result

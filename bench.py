@@ -128,6 +128,9 @@ def main():
     ap.add_argument("--launcher", action="store_true",
                     help="start the ranks through torch.distributed.run also for --gpus 1 (the plumbing N > 1 uses)")
     ap.add_argument("--no-rccl", action="store_true", help="single GPU: no process group, no gather in the timed loop")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="the batch exchange as the library's own ncclAllGather on the ctx stream (az_gather_records) instead "
+                         "of torch.distributed's all_gather_into_tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--inflight", type=int, default=1,
@@ -249,7 +252,7 @@ def main():
             return float(tt.item())
         return x
 
-    gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev) if dist_on else None
+    gat = azdist.DeviceGather(net.ctx, NUM_PROPOSALS, args.gather_every, dev, native=args.native_gather) if dist_on else None
     # extra contexts for pipelining independent images on one GPU (same weights, same map)
     nets = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
                     for _ in range(args.inflight - 1)]
@@ -527,7 +530,7 @@ def main():
                        "images_overlapping_on_the_gpu": (2 if (args.lanes == 2 and not args.no_queue_ahead) else 1) * args.inflight,
                        "gather": ("RCCL all_gather every %d images/rank (in the timed loop)" % args.gather_every)
                                  if gat is not None else "none"},
-            "rccl": dict(rccl, world=world,
+            "rccl": dict(rccl, world=world, native_gather=bool(args.native_gather),
                          note="one process per GPU; a one-rank group still builds an RCCL communicator and runs the "
                               "all-gather on the GPU, so N = 1 times the code path of N = 8"),
             "roofline": {"bound": "mfma",

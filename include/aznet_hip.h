@@ -204,6 +204,20 @@ void *az_last_stream(az_ctx *ctx);
 int az_result_record_layout(int num_proposals, size_t *bytes, size_t *n_offset, size_t *boxes_offset,
                             size_t *scores_offset);
 int az_propose_stage_result_dev(az_ctx *ctx, void *dst_dev, size_t cap_bytes);
+/* The exchange itself as ONE ncclAllGather over RCCL / xGMI, no framework in between: every rank
+ * contributes `bytes_per_rank` bytes at send_dev (its staged records, padding rows included) and receives all ranks' blocks
+ * in rank order at recv_dev (nranks * bytes_per_rank bytes).  It runs on a stream of the context's own
+ * (az_comm_stream: a hipStream_t; make it wait for whoever wrote padding rows, make readers of recv_dev wait for it),
+ * device-ordered behind everything both lanes have queued when the call is made -- so it may be issued right behind the
+ * batch's last az_propose_launch -- and holds neither lane back.  RCCL is bound at run time to the librccl.so the process
+ * already holds (PyTorch-ROCm's), else ROCm's.  az_rccl_unique_id: 128 bytes made on rank 0 and handed to every rank by
+ * the launcher's own means (a file, torch.distributed's store, MPI); az_rccl_init: collective over the nranks processes,
+ * one per GPU.  The reference is single-process: this replaces nothing there. */
+int az_rccl_unique_id(void *id_out, size_t cap);
+int az_rccl_init(az_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank);
+int az_gather_records(az_ctx *ctx, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+int az_rccl_destroy(az_ctx *ctx);
+void *az_comm_stream(az_ctx *ctx);
 /* All candidates of the last az_propose, before selection (Y / aScores of test.py:380-381). */
 int az_last_candidates(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out);
 

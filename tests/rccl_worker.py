@@ -66,7 +66,11 @@ def main():
         #  for the first time inside launch / stage / fetch, where a fallback rerun has to restage the record)
         refs = {k: HipAZNet(h, device=local, name="ref_" + k) for k, h in heads.items()}
         k = 300
-        gats = {key: azdist.DeviceGather(n.ctx, k, rows, dev, always_collective=True) for key, n in nets.items()}
+        # (AZ_TEST_NATIVE_GATHER=1: the library's own ncclAllGather on the ctx stream; AZ_TEST_LANES=2: two lanes)
+        native = os.environ.get("AZ_TEST_NATIVE_GATHER", "0") == "1"
+        for n in nets.values():
+            n.ctx.set_lanes(int(os.environ.get("AZ_TEST_LANES", "1")))
+        gats = {key: azdist.DeviceGather(n.ctx, k, rows, dev, always_collective=True, native=native) for key, n in nets.items()}
         assert all(g.collective for g in gats.values())
 
         def fmap_of(i):

@@ -94,3 +94,60 @@ def test_device_record_layout_and_unpack():
     assert azdist.unpack_device_record(raw, layout, k) is None
     with pytest.raises(ffi.AzError):
         ffi.AzContext.result_record_layout(0)
+
+
+# ---- world 8 (the node size of BASELINE config 5), ragged image counts, the DEVICE-record path on CPU tensors ---------------
+def _worker8(rank, world, port, num_images, k, q):
+    """What tools/prop_az.py does on every rank: rows = ceil(n / world) record slots, this rank's images staged into its
+    slots (here: written by hand in the device-record layout), short ranks padded, ONE all-gather, rank-interleaved
+    unpack -- over gloo with CPU tensors, through the same DeviceGather object the GPUs use."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aznet_hip import ffi
+        mine = azdist.shard_indices(num_images, rank, world)
+        rows = (num_images + world - 1) // world
+
+        class NoCtx(object):          # (records are written below, not staged from a search)
+            def stage_result(self, *a):
+                raise AssertionError("not used")
+        g = azdist.DeviceGather(NoCtx(), k, rows, "cpu")
+        nbytes, n_off, b_off, s_off = g.layout
+        ok = True
+        for buf in (0, 1):            # both buffer pairs
+            send = g.bufs[buf][0]
+            send.zero_()
+            for j, i in enumerate(mine):
+                b, s = _fake(i, k)
+                raw = np.zeros(nbytes, dtype=np.uint8)
+                raw[n_off:n_off + 4] = np.array([b.shape[0]], dtype=np.int32).view(np.uint8)
+                raw[b_off:b_off + 32 * b.shape[0]] = b.reshape(-1).view(np.uint8)
+                raw[s_off:s_off + 4 * b.shape[0]] = s.view(np.uint8)
+                send[j] = torch.from_numpy(raw)
+            allp = g.gather(len(mine), buf=buf)
+            ok = ok and len(allp) == num_images
+            for i, (b, s) in enumerate(allp):
+                rb, rs = _fake(i, k)
+                ok = ok and np.array_equal(b, rb) and np.array_equal(s, rs)
+        # ... and the host-record path (variable proposal counts) on the same shards
+        allh = azdist.gather_proposals([_fake(i, k) for i in mine], None)
+        ok = ok and len(allh) == num_images and all(np.array_equal(allh[i][0], _fake(i, k)[0]) for i in range(num_images))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_images", [8, 13, 19, 3])          # 13, 19: ragged; 3: five ranks own nothing
+def test_gather_eight_ranks_in_serial_image_order(num_images):
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, num_images, 40, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]

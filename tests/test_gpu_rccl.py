@@ -35,10 +35,13 @@ def _env():
     return env
 
 
-def _run_world(world, n_images, rows):
+def _run_world(world, n_images, rows, native=False, lanes=1):
     port = _free_port()
+    env = _env()
+    env["AZ_TEST_NATIVE_GATHER"] = "1" if native else "0"
+    env["AZ_TEST_LANES"] = str(lanes)
     procs = [subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "rccl_worker.py"), str(r), str(world),
-                               str(port), str(n_images), str(rows)], env=_env(), stdout=subprocess.PIPE,
+                               str(port), str(n_images), str(rows)], env=env, stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -61,11 +64,21 @@ def test_rccl_gather_world_1(n_images, rows):
     _run_world(1, n_images, rows)
 
 
-def test_rccl_gather_world_2():
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_native_rccl_gather_world_1(lanes):
+    """The same exchange with the library's own ncclAllGather on the ctx stream (az_rccl_init / az_gather_records, RCCL
+    bound at run time to the librccl.so the process already holds) instead of torch.distributed's: a one-rank
+    communicator, padding rows, reruns with restaging, records staged from both lanes; every gathered image equals a
+    plain az_propose."""
+    _run_world(1, 7, 3, native=True, lanes=lanes)
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_rccl_gather_world_2(native):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("one GPU on this box")
-    _run_world(2, 9, 2)
+    _run_world(2, 9, 2, native=native, lanes=2)
 
 
 def test_bench_through_the_launcher_one_rank():
