@@ -176,6 +176,7 @@ struct az_ctx {
     float *nms_dets = nullptr, *nms_sdets = nullptr;
     int *nms_order = nullptr;
     unsigned long long *nms_mask = nullptr;
+    int *nms_rank = nullptr;            // [nms_cap] rank scratch of k_nms_rank_count: zero between calls
     long long *nms_keep = nullptr;
     unsigned char *h_nms = nullptr;     // host-mapped block of az_nms's small case
     unsigned char *h_nmsg = nullptr; size_t h_nmsg_cap = 0;     // ... of az_nms's general case (keep list + count)
@@ -605,7 +606,7 @@ int az_destroy(az_ctx *c)
     for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
                     (void *)c->hisZ, (void *)c->pool, (void *)c->pool_tmp, (void *)c->pool_n, (void *)c->pool_hist})
         if (p) hipFree(p);
-    if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
+    if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); hipFree(c->nms_rank); }
     if (c->h_cnt) hipHostFree(c->h_cnt);
     for (int i = 0; i < 3; ++i) {
         if (c->h_res[i]) hipHostFree(c->h_res[i]);
@@ -2411,7 +2412,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
     }
     if (n > c->nms_cap) {
         HIPCHK(c, hipStreamSynchronize(s));
-        if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); }
+        if (c->nms_dets) { hipFree(c->nms_dets); hipFree(c->nms_sdets); hipFree(c->nms_order); hipFree(c->nms_mask); hipFree(c->nms_keep); hipFree(c->nms_rank); }
         c->nms_dets = nullptr; c->nms_cap = 0;
         int cap = 1024;
         while (cap < n) cap *= 2;
@@ -2421,6 +2422,8 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         HIPCHK(c, hipMalloc((void **)&c->nms_sdets, (size_t)cap * 5 * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_order, (size_t)cap * 4 + 16));
         HIPCHK(c, hipMalloc((void **)&c->nms_mask, (size_t)cap * W * 8));
+        HIPCHK(c, hipMalloc((void **)&c->nms_rank, (size_t)cap * 4));
+        HIPCHK(c, hipMemset(c->nms_rank, 0, (size_t)cap * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_keep, (size_t)cap * 8 + 16));
         c->nms_cap = cap;
     }
@@ -2443,7 +2446,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         long long *hk = (long long *)(c->h_nmsg + 64);                 // (tag << 32) | index
         const unsigned tag = nms_next_tag(c);
         *hn = 0;
-        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, hk, (int *)c->h_nmsg, tag);
+        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, (unsigned long long *)c->nms_rank, hk, (int *)c->h_nmsg, tag);
         bool got = false;
         for (long spin = 0; spin < 4000000 && !got; ++spin) got = (unsigned)((unsigned long long)*hn >> 32) == tag;
         if (got) got = nms_keep_tagged(hk, (int)(*hn & 0xFFFFFFFFll), tag, 200000);
@@ -2458,7 +2461,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         return AZ_OK;
     }
     { Timed t(c, "nms", n);
-      azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, nullptr, c->nms_keep, nk); }
+      azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, (unsigned long long *)c->nms_rank, c->nms_keep, nk); }
     int h_nk = 0;
     HIPCHK(c, hipMemcpyAsync(&h_nk, nk, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

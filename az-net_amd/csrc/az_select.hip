@@ -283,36 +283,47 @@ k_thresh_select(const float *__restrict__ scores, const int *Nptr, int capN, dou
 // 3. greedy scan 64 sorted boxes at a time: the 64x64 diagonal word block resolves the
 //    dependencies inside the chunk, then the kept rows are OR-ed into the removed bitmap.
 // ======================================================================================
-__global__ void k_nms_rank(const float *__restrict__ dets, int n, int *order, float *sdets)
+// rank(i) = #{j: s_j > s_i or (s_j == s_i and j > i)}: the N^2 compares are cut over the whole chip -- workgroup (ib, js)
+// counts, for the 256 boxes of block ib, the boxes of every NMS_RANK_JS-th 256-box block, and adds its share to rank[]
+// (32 workgroups walking all of N each took 320 us of the 1.04 ms at 8129 boxes).
+constexpr int NMS_RANK_JS = 8;
+__global__ void __launch_bounds__(256) k_nms_rank_count(const float *__restrict__ dets, int n, int *rank)
 {
     __shared__ float ss[256];
     const int nblk = (n + 255) / 256;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {
-        const int i = b * 256 + threadIdx.x;
-        const float si = i < n ? dets[5 * (size_t)i + 4] : 0.f;
-        int rank = 0;
-        for (int t = 0; t < nblk; ++t) {
-            const int j = t * 256 + threadIdx.x;
-            __syncthreads();
-            ss[threadIdx.x] = j < n ? dets[5 * (size_t)j + 4] : 0.f;
-            __syncthreads();
-            const int lim = min(256, n - t * 256);
-            for (int jj = 0; jj < lim; ++jj) {
-                const float sj = ss[jj];
-                const int jidx = t * 256 + jj;
-                rank += (sj > si) | ((sj == si) & (jidx > i));
-            }
-        }
-        if (i < n) {
-            order[rank] = i;
-            const float x1 = dets[5 * (size_t)i], y1 = dets[5 * (size_t)i + 1];
-            const float x2 = dets[5 * (size_t)i + 2], y2 = dets[5 * (size_t)i + 3];
-            float w = x2 - x1; w = w + 1.0f;
-            float h = y2 - y1; h = h + 1.0f;
-            float *o = sdets + 5 * (size_t)rank;
-            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = w * h;      // areas, nms.pyx:24
+    const int ib = blockIdx.x, js = blockIdx.y;
+    const int i = ib * 256 + threadIdx.x;
+    const float si = i < n ? dets[5 * (size_t)i + 4] : 0.f;
+    int cnt = 0;
+    for (int t = js; t < nblk; t += NMS_RANK_JS) {
+        const int j = t * 256 + threadIdx.x;
+        __syncthreads();
+        ss[threadIdx.x] = j < n ? dets[5 * (size_t)j + 4] : 0.f;
+        __syncthreads();
+        const int lim = min(256, n - t * 256);
+#pragma unroll 8
+        for (int jj = 0; jj < lim; ++jj) {
+            const float sj = ss[jj];
+            const int jidx = t * 256 + jj;
+            cnt += (sj > si) | ((sj == si) & (jidx > i));
         }
     }
+    if (i < n && cnt) atomicAdd(&rank[i], cnt);
+}
+
+__global__ void __launch_bounds__(256) k_nms_rank_place(const float *__restrict__ dets, int n, int *rank, int *order, float *sdets)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i];
+    rank[i] = 0;                                   // (left clean for the next call)
+    order[r] = i;
+    const float x1 = dets[5 * (size_t)i], y1 = dets[5 * (size_t)i + 1];
+    const float x2 = dets[5 * (size_t)i + 2], y2 = dets[5 * (size_t)i + 3];
+    float w = x2 - x1; w = w + 1.0f;
+    float h = y2 - y1; h = h + 1.0f;
+    float *o = sdets + 5 * (size_t)r;
+    o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = w * h;      // areas, nms.pyx:24
 }
 
 __global__ void __launch_bounds__(256)
@@ -350,7 +361,18 @@ k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long 
     }
 }
 
-__global__ void __launch_bounds__(256)
+// One workgroup of 16 waves walks the 64-box chunks in order; the serial chain runs inside wave 0 alone.  Step c:
+//   wave 0     resolves the 64 x 64 diagonal block of chunk c (its words were requested a step ahead; only boxes still
+//              alive are visited: s_ff1 over the alive word), publishes the kept rows, and at once ORs THEIR words of
+//              chunk c + 1 -- one load per lane, all in flight together, a butterfly -- into removed[c + 1]: all that the
+//              next step's resolve still lacks;
+//   the others OR the kept rows of chunk c - 1 (published a step ago) into the words c + 1 .. W - 1 -- thread = (word,
+//              slot), slot takes every eighth kept row, eight neighbouring lanes meet with three shuffles;
+//   one barrier.
+// The chain per step is a register scan + ONE memory round trip (it was: diagonal round trip, scan, barrier, ~3 dependent
+// batches of row loads on a quarter of the threads, barrier).
+constexpr int NMS_SCAN_NT = 1024;
+__global__ void __launch_bounds__(NMS_SCAN_NT)
 k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ order, int n,
            unsigned long long *removed_g, long long *keep, int *nkeep, unsigned seq)
 {
@@ -358,67 +380,89 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     // order (PCIe posted writes with relaxed ordering: a later word can pass an earlier one -- measured: a count visible
     // before the last keep entries, 5 calls in 27 600), so nothing is inferred from ORDER: every word carries the call's
     // sequence number in its upper half and the host takes a word only once it shows the current number.
-    __shared__ unsigned long long s_kept;
-    __shared__ int s_nk;
+    __shared__ int s_nkept[2];                        // kept rows of the chunk resolved in this / the previous step
+    __shared__ int s_krow[2][64];                     // ... which rows (0..63), ascending
     extern __shared__ unsigned long long removed[];   // W words
     const int W = (n + 63) / 64;
     (void)removed_g;
-    for (int w = threadIdx.x; w < W; w += blockDim.x) removed[w] = 0ull;
-    if (threadIdx.x == 0) s_nk = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int w = tid; w < W; w += NMS_SCAN_NT) removed[w] = 0ull;
+    if (tid < 2) s_nkept[tid] = 0;
+    int nk_total = 0;                                 // (wave 0) boxes kept so far
+    unsigned long long diag_next = (tid < 64 && lane < n) ? mask[(size_t)lane * W] : 0ull;
     __syncthreads();
     for (int c = 0; c < W; ++c) {
-        if (threadIdx.x < 64) {
-            const int lane = threadIdx.x;
+        const int cur = c & 1;
+        if (tid < 64) {
             const int row = c * 64 + lane;
-            const unsigned long long diag = row < n ? mask[(size_t)row * W + c] : 0ull;
+            const unsigned long long diag = diag_next;
+            const int rown = (c + 1) * 64 + lane;
+            diag_next = (c + 1 < W && rown < n) ? mask[(size_t)rown * W + (c + 1)] : 0ull;
             const int nvalid = min(64, n - c * 64);
             unsigned long long alive = ~removed[c];
             if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
             unsigned long long kept = 0ull;
             const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            for (int b = 0; b < nvalid; ++b) {
+            while (alive) {                           // (wave-uniform: alive comes from LDS and readlanes)
+                const int b = __builtin_ctzll(alive);
                 const unsigned long long drow =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
                     (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-                if ((alive >> b) & 1ull) { kept |= (1ull << b); alive &= ~drow; }
+                kept |= (1ull << b);
+                alive &= ~(drow | (1ull << b));
+            }
+            const int nkc = __popcll(kept);
+            const bool mine = (kept >> lane) & 1ull;
+            const int pos = __popcll(kept & ((1ull << lane) - 1ull));
+            if (mine) s_krow[cur][pos] = lane;
+            if (lane == 0) s_nkept[cur] = nkc;
+            // the kept rows' words of the NEXT chunk: lane q takes kept row q (the row lists above are this wave's own
+            // writes: krow of lane q is found with a ballot-free select below)
+            if (c + 1 < W) {
+                // lane `pos` of a kept lane is its index among the kept rows; invert with a permute through LDS written above
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long v = lane < nkc ? mask[(size_t)(c * 64 + s_krow[cur][lane]) * W + (c + 1)] : 0ull;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
+                    v |= ((unsigned long long)hi << 32) | lo;
+                }
+                if (lane == 0 && v) atomicOr(&removed[c + 1], v);      // (the helpers add chunk c - 1's share to the same word)
             }
             // append kept boxes (sorted positions -> original indices, visiting order)
-            const int nk = s_nk;
-            if ((kept >> lane) & 1ull) {
-                const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-                keep[nk + pos] = ((long long)seq << 32) | (unsigned)order[row];
-            }
-            if (lane == 0) { s_kept = kept; s_nk = nk + __popcll(kept); }
-        }
-        __syncthreads();
-        unsigned long long kept = s_kept;
-        for (int w = c + 1 + threadIdx.x; w < W; w += blockDim.x) {
-            unsigned long long acc = removed[w];
-            unsigned long long kk = kept;
-            // the kept rows' words, eight loads in flight at a time (one at a time, ~24 kept rows per block made every
-            // block wait for ~24 dependent memory round trips: 1.2 of the 1.6 ms at 8129 boxes)
-            while (kk) {
-                int b[8];
+            if (mine) keep[nk_total + pos] = ((long long)seq << 32) | (unsigned)order[row];
+            nk_total += nkc;
+        } else if (c > 0) {
+            // helpers: chunk c - 1's kept rows into the words c + 1 ..: thread = (word, slot)
+            const int prev = cur ^ 1, nkp = s_nkept[prev], ht = tid - 64;
+            for (int w0 = c + 1; w0 < W; w0 += (NMS_SCAN_NT - 64) / 8) {
+                const int w = w0 + (ht >> 3), slot = ht & 7;
+                unsigned long long acc = 0ull;
+                if (w < W) {
+                    unsigned long long m[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    b[j] = kk ? __ffsll((long long)kk) - 1 : -1;
-                    kk &= kk - 1;                               // (0 stays 0)
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = slot + 8 * j;
+                        m[j] = q < nkp ? mask[(size_t)((c - 1) * 64 + s_krow[prev][q]) * W + w] : 0ull;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc |= m[j];
                 }
-                unsigned long long m[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) m[j] = b[j] >= 0 ? mask[(size_t)(c * 64 + b[j]) * W + w] : 0ull;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc |= m[j];
+                for (int d = 1; d < 8; d <<= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)acc, d, 64), hi = __shfl_xor((unsigned)(acc >> 32), d, 64);
+                    acc |= ((unsigned long long)hi << 32) | lo;
+                }
+                if (w < W && slot == 0 && acc) atomicOr(&removed[w], acc);
             }
-            removed[w] = acc;
         }
         __syncthreads();
     }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (seq) *reinterpret_cast<long long *>(nkeep) = ((long long)seq << 32) | (unsigned)s_nk;
-        else *nkeep = s_nk;
+        if (seq) *reinterpret_cast<long long *>(nkeep) = ((long long)seq << 32) | (unsigned)nk_total;
+        else *nkeep = nk_total;
     }
 }
 
@@ -637,8 +681,11 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
     if (n <= 0) { hipMemsetAsync(nkeep, 0, sizeof(int), s); return; }
     const int W = (n + 63) / 64;
     const int g = (n + 255) / 256;
-    hipLaunchKernelGGL(k_nms_rank, dim3(g > 1024 ? 1024 : g), dim3(256), 0, s, dets, n, order, sdets);
+    // (`removed`: n ints of rank scratch, zero on entry and left zero)
+    int *rank = reinterpret_cast<int *>(removed);
+    hipLaunchKernelGGL(k_nms_rank_count, dim3(g, NMS_RANK_JS), dim3(256), 0, s, dets, n, rank);
+    hipLaunchKernelGGL(k_nms_rank_place, dim3(g), dim3(256), 0, s, dets, n, rank, order, sdets);
     hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask);
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(256), (size_t)W * sizeof(unsigned long long), s, mask, order,
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(NMS_SCAN_NT), (size_t)W * sizeof(unsigned long long), s, mask, order,
                        n, removed, keep, nkeep, seq);
 }
