@@ -1,7 +1,8 @@
 #!/bin/bash
 # One profiling pass of bench.py for profiles/: kernel stats and the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
 # SQ/GRBM), each summarised with the tools beside this file, for three workloads:
-#   main     the level loop at Tz = 0 (bench.py's `value`: whole-tree pass)     -> <tag>_*
+#   main     the search at Tz = 0 (bench.py's `value`: whole-tree pass, two lanes) -> <tag>_*
+#   onelane  the same on one lane (`one_lane`)                                   -> <tag>_onelane_*
 #   twopass  the same with AZ_FULL_SPEC=0 (48-row pass + 670-row pass)          -> <tag>_twopass_*
 #   onepass  the Tz <= 0 one-pass form (`one_pass`)                             -> <tag>_onepass_*
 #   extras   calibrated Tz, deep tree (config 4), shared detection (config 3), az_nms at 100 / 300 / 2000 / 8129 boxes:
@@ -18,7 +19,10 @@ out=$repo/gpurun_out/$tag
 tools=$repo/az-net_amd/tools
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
-common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast"
+# the context's one-time measurement of head-pass costs (24 head passes at 48 .. 1408 rows, first launch) is kept out of the
+# per-kernel averages: with AZ_PASS_CAL=0 the form choice goes by the built-in figures (same forms at these workloads)
+export AZ_PASS_CAL=0
+common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-sweep --no-box --no-one-lane"
 
 run_set() {
   name=$1; args=$2; pfx=$3; period=$4
@@ -52,6 +56,8 @@ for s in $sets; do
     # kernels whose name contains k_fc_splitk per image: the whole-tree pass's int6 (k_fc_splitk12, 688 rows) and int7 = 2
     # (the search's first, history-less image takes the two-pass form: one stray pair of launches in the averages)
     main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
+    # the same loop on ONE lane (az_set_lanes(1)): strictly one image at a time on the GPU -- rounds 1-3's `value`
+    onelane) run_set onelane "--steps 100 --warmup 10 $common --lanes 1 --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "onelane_" 2 ;;
     # the level loop without the whole-tree pass (AZ_FULL_SPEC=0): 48-row pass (k_fc_splitk int6, int7), 670-row pass
     # (k_fc_splitk12 int6, int7) = 4
     twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "twopass_" 4 ;;
