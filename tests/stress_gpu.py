@@ -16,14 +16,18 @@ sys.path.insert(0, os.path.join(HERE, ".."))
 
 
 FULL = bool(int(os.environ.get("AZ_STRESS_FULL", "0")))     # the full-size head (25088 -> 4096 -> ...): many-row GEMM, big passes
+LANES = int(os.environ.get("AZ_STRESS_LANES", "1"))          # 2: az_set_lanes(2) -- the queued searches of a case overlap on the GPU
 
 
 def make_net():
     from aznet_hip import synth
     from aznet_hip.net import HipAZNet
     if FULL:
-        return HipAZNet(synth.make_head(seed=1234, **synth.FULL_DIMS), name="stress_full", max_regions=4096)
-    return HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="stress")
+        net = HipAZNet(synth.make_head(seed=1234, **synth.FULL_DIMS), name="stress_full", max_regions=4096)
+    else:
+        net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), name="stress")
+    net.ctx.set_lanes(LANES)
+    return net
 
 
 def run_case(net, case):
@@ -102,12 +106,19 @@ def run_case(net, case):
                 f[2].num_eval, b[2].num_eval, list(f[2].pass_rows[:f[2].n_passes]), f[2].search_form, f[2].n_reruns)
         desc += " closure-form %d rows %d" % (f[2].search_form, f[2].pass_rows[0])
     if fixed:
-        net.ctx.propose_launch(ffi.AzContext.make_params(H, W, scale, Tz, **kw))
-        net.ctx.propose_launch(pp)
-        q1 = net.ctx.propose_fetch(want_scores=True)
-        q2 = net.ctx.propose_fetch(want_scores=True)
-        if not (np.array_equal(q1[0], b[0]) and np.array_equal(q1[1], b[1]) and np.array_equal(q2[0], b[0]) and
-                np.array_equal(q2[1], b[1])):
+        # queued searches in all forms -- two deep on one lane, four deep on two lanes (AZ_STRESS_LANES=2: they then overlap
+        # on the GPU, and a rerun inside fetch happens while the other lane works)
+        forms = [ffi.AzContext.make_params(H, W, scale, Tz, **kw), pp, pf, pcl]
+        depth = 2 * LANES
+        got, q = [], 0
+        for j in range(len(forms) + depth - 1):
+            if j < len(forms):
+                net.ctx.propose_launch(forms[j])
+                q += 1
+            if q == depth or j >= len(forms):
+                got.append(net.ctx.propose_fetch(want_scores=True))
+                q -= 1
+        if not all(np.array_equal(g[0], b[0]) and np.array_equal(g[1], b[1]) for g in got) or len(got) != len(forms):
             return False, desc, "queued searches differ from the plain one"
     desc += " levels %d eval %d cand %d" % (a[2].n_levels, a[2].num_eval, Ya.shape[0])
     if case % (16 if FULL else 4):

@@ -21,6 +21,10 @@ def net():
 @pytest.mark.parametrize("block", range(32))
 def test_random_search_configurations(net, block):
     bad = []
+    # (odd blocks on two lanes: the queued searches of a case -- default, pair, whole-tree over tree rows, closure -- then
+    #  run four deep and overlap on the GPU)
+    stress_gpu.LANES = 2 if block % 2 else 1
+    net.ctx.set_lanes(stress_gpu.LANES)
     for case in range(block * BLOCK, (block + 1) * BLOCK):
         ok, desc, why = stress_gpu.run_case(net, case)
         if not ok:
