@@ -348,7 +348,9 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                                         float *__restrict__ slab, float (*sA)[BM * LDT], float (*sB)[BN * LDT])
 {
     static_assert(!HALF || NRT <= 3, "the half strip lives in the tile's fourth strip of LDS rows");
+    static_assert(NRT > 0 || HALF, "a tile has at least a half strip");
     constexpr int NLA = NRT + (HALF ? 1 : 0);    // activation float4s per thread per K-step
+    constexpr int NA = NRT > 0 ? NRT : 1;        // (NRT = 0: the tile IS the half strip; arrays keep one unused slot)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -356,7 +358,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     const int nk = (kend - k0 + BK - 1) / BK;
     floatx4 acch[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-    floatx16 acc[NRT];
+    floatx16 acc[NA];
 #pragma unroll
     for (int r = 0; r < NRT; ++r)
 #pragma unroll
@@ -423,14 +425,16 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     };
     const float *a_base = &sA[0][lrow * LDT + lk];
     const float *b_base = &sB[0][(wave * 32 + lrow) * LDT + lk];
-    auto frag = [&](int buf, int g8, float4 (&af)[NRT], float4 &bf) {
-        bf = *reinterpret_cast<const float4 *>(b_base + buf * (BN * LDT) + g8 * 8);
+    auto frag = [&](int buf, int g8, float4 (&af)[NA], float4 &bf) {
+        if constexpr (NRT > 0) {
+            bf = *reinterpret_cast<const float4 *>(b_base + buf * (BN * LDT) + g8 * 8);
 #pragma unroll
-        for (int r = 0; r < NRT; ++r)
-            af[r] = *reinterpret_cast<const float4 *>(a_base + buf * (BM * LDT) + r * 32 * LDT + g8 * 8);
+            for (int r = 0; r < NRT; ++r)
+                af[r] = *reinterpret_cast<const float4 *>(a_base + buf * (BM * LDT) + r * 32 * LDT + g8 * 8);
+        }
     };
     // 4*NRT MFMAs on one 8-wide k group; k-pairs {j, 4 + j}: accumulation order 0,4,1,5,2,6,3,7
-    auto mfma8 = [&](const float4 (&af)[NRT], const float4 &bf) {
+    auto mfma8 = [&](const float4 (&af)[NA], const float4 &bf) {
 #pragma unroll
         for (int r = 0; r < NRT; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r].x, bf.x, acc[r], 0, 0, 0);
 #pragma unroll
@@ -448,14 +452,14 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     lstore(0, 0, ra0, rb0);
     __syncthreads();
 
-    if constexpr (NRT >= DENSE_MIN_NRT) {
+    if constexpr (NRT >= DENSE_MIN_NRT && NRT > 0) {
         // MFMA-bound shape.  The barrier sits in the MIDDLE of the K-step: when a wave reaches it
         // two of its four k groups (32 MFMAs, ~2000 cycles) are still queued with their operands
         // already in registers, so barrier skew and the first fragment reads of the next tile
         // hide behind them and the matrix pipe never drains.  Inside a group the other
         // instructions are interleaved one per MFMA issue slot (sched_group_barrier).
         //   a0/a1 hold the fragments of k groups 0/1 of tile kt on entry.
-        float4 a0[NRT], a1[NRT], b0, b1;
+        float4 a0[NA], a1[NA], b0, b1;
         HalfFrag h0, h1;
         frag(0, 0, a0, b0);
         frag(0, 1, a1, b1);
@@ -469,7 +473,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
             __builtin_amdgcn_sched_barrier(0);
             // group 0 MFMAs | request tile kt+2 | fragments of group 2
             gload(kt + 2 < nk ? kt + 2 : nk - 1, rl_a, rl_b);   // unconditional: exact vmcnt bookkeeping
-            float4 a2[NRT], b2;
+            float4 a2[NA], b2;
             HalfFrag h2;
             frag(buf, 2, a2, b2);
             hfrag(buf, 2, h2);
@@ -494,7 +498,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
             __builtin_amdgcn_sched_barrier(0);
             // group 1 MFMAs | tile kt+1 -> LDS[buf^1] | fragments of group 3
             lstore(kt + 1, buf ^ 1, rw_a, rw_b);                // (past the last step: a tile nobody reads)
-            float4 a3[NRT], b3;
+            float4 a3[NA], b3;
             HalfFrag h3;
             frag(buf, 3, a3, b3);
             hfrag(buf, 3, h3);
@@ -563,7 +567,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         // density.  MFMAs on LDS[buf] (tile kt); meanwhile request tile kt+2 and write tile kt+1.
         auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
-            float4 a0[NRT], a1[NRT], b0, b1;
+            float4 a0[NA], a1[NA], b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
             HalfFrag h0, h1;
             frag(buf, 0, a0, b0);
             hfrag(buf, 0, h0);
@@ -672,12 +676,27 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         }
         strips = st2; mt = mt2; half_last = true;
     }
+    // spread items (fewer groups than workgroups) with <= 16 rows past the last full strip: those rows are a half strip in
+    // the LAST tile, the tiles counted as if it were a strip -- 48 rows = (1 strip | half strip), 144 = (2 | 2 + half)
+    if ((half_enabled & 1) && !mloop && (M & 31) && (M & 31) <= 16 && (M >> 5) >= 1) {
+        const int st2 = M >> 5;
+        const int mt2 = tiles_for(st2 + 1);
+        int s0, nrt_last;
+        mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
+        if (mt2 >= 2 && nrt_last <= 3) { strips = st2; mt = mt2; half_last = true; }
+    }
     const int nitems = mloop ? G : G * mt;
+    // Two tiles per group on a full grid: workgroups b and b + 8 -- the same XCD, hence the same L2 -- take the two tiles
+    // of ONE group at the same time (the group's weight panel comes from memory once); b and b + 256 tend to share a CU
+    // and take a first and a second tile.  (Adjacent workgroups sit on different XCDs: dealt item by item the panel was
+    // fetched twice.)
+    const bool xcd_pairs = !mloop && mt == 2 && nitems == (int)gridDim.x && (nitems & 15) == 0 && (((int)gridDim.x / 2) & 15) == 0;
     // (256 % mt != 0 in general: the rotation that makes tile(b + 256) = tile(b) + mt / 2)
     const int pair_rot = (half_enabled & 8) ? 0 : (((mt >> 1) - (int)(gridDim.x / 2) % mt) % mt + mt) % mt;
 
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int g = mloop ? item : item / mt;
+        int g = mloop ? item : item / mt;
+        if (xcd_pairs) g = (item >> 4) * 8 + (item & 7);
         const int ntile = g / S, s = g - ntile * S;
         const int n0 = ntile * BN;
         const int k0 = s * Kc;
@@ -686,9 +705,9 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         // (spread items: m-tiles differ by one strip -- front ones larger.  Workgroups b and b + gridDim / 2 tend to
         //  share a CU (two resident per CU): the second half of the grid walks the m-tiles rotated by half a turn, so a
         //  CU gets a larger and a smaller tile rather than two large ones.  AZ_GEMM_PAIR=0: plain order.)
-        int t_sp = item - g * mt;
+        int t_sp = xcd_pairs ? (((item >> 3) + (item >= (int)gridDim.x / 2 ? 1 : 0)) & 1) : item - g * mt;
         // (a whole group rotates or not -- decided by where its first item falls --, so every m-tile is still visited once)
-        if (!mloop && pair_rot && (((g * mt) / ((int)gridDim.x / 2)) & 1)) t_sp = (t_sp + pair_rot) % mt;
+        if (!mloop && !xcd_pairs && pair_rot && (((g * mt) / ((int)gridDim.x / 2)) & 1)) t_sp = (t_sp + pair_rot) % mt;
         const int t_lo = mloop ? 0 : t_sp, t_hi = mloop ? mt : t_lo + 1;
         for (int mtile = t_lo; mtile < t_hi; ++mtile) {
             int strip0, n_rt;                            // live 32-row strips (workgroup-uniform)
@@ -699,6 +718,7 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
 #define FC_TILE(NRT_, HALF_) fc_tile<NRT_, HALF_>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB)
             if (half_last && mtile == mt - 1) {
                 switch (n_rt) {
+                case 0: FC_TILE(0, true); break;
                 case 1: FC_TILE(1, true); break;
                 case 2: FC_TILE(2, true); break;
                 default: FC_TILE(3, true); break;
