@@ -20,11 +20,11 @@ struct AzCounts {
     int nsel;                   // proposals selected at the end
     int err;                    // bit 0: region capacity, bit 1: candidate capacity, bit 2: children
     int scratch[6];
-    // speculative evaluation of levels 1-3 (az_capi.hip): |B1|, children of all of B1, rows forwarded
+    // speculative evaluation of levels 1-3 (az_search.hip): |B1|, children of all of B1, rows forwarded
     int specP1, specCH, specU, specPad;
     // tuner's search (lib/detect/tune.py:256-316): rows of the anchor history written so far
     int nhis, hisPad[3];
-    // head passes of the fused level loop (az_capi.hip): PR[l] = rois the pass launched at level l evaluates (its own
+    // head passes of the fused level loop (az_search.hip): PR[l] = rois the pass launched at level l evaluates (its own
     // unique rois, then -- "pair speculation" -- SPN[l] rows for ALL children of all of its regions, a superset of level
     // l+1's rois, starting at row SPB[l], then the deferred root's row if it rides here); 0 = no pass at that level
     int PR[AZ_MAX_LEVELS], SPB[AZ_MAX_LEVELS], SPN[AZ_MAX_LEVELS];
@@ -233,7 +233,7 @@ struct AzLevelArgs {
     const unsigned char *keep_u;   // MIN_SIDE filter of this level's decoded boxes (tail kernel)
     const int *Uptr;               // unique rois of this level
     int root_row;                  // 1: the LAST row of this level's head pass (cnt->PR[level] - 1) is the deferred root (az_fused.hip)
-    // pair speculation (az_capi.hip): this level's head pass also evaluated rows for all children of its regions
+    // pair speculation (az_search.hip): this level's head pass also evaluated rows for all children of its regions
     // (lookup_next) -> level l+1's outputs are looked up and decoded here into the *_v arrays instead of a head pass;
     // or the NEXT level's pass shall carry such rows (spec_next): they are appended behind its unique rois here
     int lookup_next, spec_next;    // lookup_next = 2: by RoIPool window in the whole-tree pass (stab), not among pair rows

@@ -3,7 +3,7 @@
 // Levels 1-3 hold a few dozen regions (1, then the root's children, then their children), so
 // each of their geometry stages is a handful of elements: as separate launches they cost ~40
 // dependent kernel boundaries of pure latency.  Because the head outputs for these levels come
-// from one speculative pass (az_capi.hip), everything else for them -- roi keys + 1/16 dedup,
+// from one speculative pass (az_search.hip), everything else for them -- roi keys + 1/16 dedup,
 // lookup + box decode, candidate filter + ordered compaction, zoom selection, divide_region,
 // _sift_dup -- runs here inside ONE workgroup with __syncthreads() between stages.
 // Same device helpers (az_geom_dev.h) as the multi-workgroup kernels, so same bits.
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 
     if (a.reset) {
         // first kernel of the search that touches the counters (the pre-pass of this image shape is cached,
-        // az_capi.hip): clear the previous search's, restore what the pre-pass would have left
+        // az_search.hip): clear the previous search's, restore what the pre-pass would have left
         int *w = reinterpret_cast<int *>(cnt);
         for (int i = tid; i < (int)(sizeof(AzCounts) / sizeof(int)); i += NTL) w[i] = 0;
         __syncthreads();

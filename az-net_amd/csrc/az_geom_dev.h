@@ -284,7 +284,7 @@ static __device__ int roi_dedup_sorted(const double *Bn, int Pn, double scale, f
 }
 
 // ----------------------------------------------------------------------------------------
-// Pair speculation (az_capi.hip): rows for ALL children of all P regions `Bn` of a level, appended to that level's
+// Pair speculation (az_search.hip): rows for ALL children of all P regions `Bn` of a level, appended to that level's
 // head pass.  The next level's regions are _sift_dup(divide_region(Z)) with Z a SUBSET of these parents
 // (test.py:386-390), so every region the next level can hold is one of these children, bit for bit (a child is a
 // function of its parent alone).  The head's outputs for a roi (zoom, scores, raw deltas) depend on the roi only
@@ -311,7 +311,7 @@ static __device__ __forceinline__ bool pool_key(const float *roi5, float ss, uns
     return ok;
 }
 
-// Whole-tree speculation (az_capi.hip: SearchPlan::full): ONE head pass evaluates the unique rois of the image shape's full
+// Whole-tree speculation (az_search.hip: SearchPlan::full): ONE head pass evaluates the unique rois of the image shape's full
 // tree (the one-pass plan's rows); a search with any Tz then finds a region's head outputs by its RoIPool window in a
 // table built once per shape: open addressing in global memory, word = (window key << 13) | row, EMPTY = ~0.
 // Row AZ_TAB_ROOT stands for the root's row (the last row of the pass, wherever the extra rows push it).

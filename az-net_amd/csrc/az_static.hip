@@ -4,7 +4,7 @@
 // output (test_fc.prototxt:221-232), so for Tz <= 0 -- the reference's TRAIN-phase setting, config.py:275 -- every
 // region with a finite score zooms and B(level l+1) = divide_region(B(level l)) is a function of the image shape
 // alone.  The regions of ALL levels, their rois, the 1/16 dedup maps and the anchors are then computed once per
-// image shape (the same geometry kernels as the level loop, az_capi.hip: ensure_static_plan) and every image runs
+// image shape (the same geometry kernels as the level loop, az_search.hip: ensure_static_plan) and every image runs
 //   ONE head pass over the unique rois of all levels (RoIPool, int6, int7, tail), then
 //   k_static_select (fixed proposal count) -- candidates of all levels appended in the reference's order, the
 //   per-level counters and the final top-k in one launch -- or k_static_candidates + the selection kernels

@@ -9,7 +9,7 @@ communicator and runs the collective on the GPU --, searches the images it owns 
 az_propose_launch / az_propose_stage_result_dev / az_propose_fetch, exchanges the device-resident records with
 DeviceGather (one all_gather_into_tensor per batch, padding rows for short ranks) and compares EVERY image of the
 gathered list with a plain az_propose of that image on this rank.  The images cover: a healthy search, a search
-whose fused levels overflow on first sight (err bit 8: rerun + restaging of the record, az_capi.hip) and a search
+whose fused levels overflow on first sight (err bit 8: rerun + restaging of the record, az_search.hip) and a search
 whose one-pass premise fails (NaN zoom score, err bit 32: rerun through the level loop + restaging), and forced
 whole-tree passes whose pruned trees miss a window (err bit 256: rerun + restaging).
 Prints "RCCL_WORKER_OK <rank> <images checked>" on success."""

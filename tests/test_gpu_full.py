@@ -1,4 +1,4 @@
-"""Whole-tree speculation in the level loop (az_capi.hip: full_prepare, az_static.hip: window table, az_fused.hip /
+"""Whole-tree speculation in the level loop (az_search.hip: full_prepare, az_static.hip: window table, az_fused.hip /
 az_level.hip: lookup stages) vs the plain level loop -- identical bits.
 
 For a dense tree the search's ONE head pass evaluates the unique rois of the image shape's FULL tree (the one-pass plan's

@@ -1,4 +1,4 @@
-"""Pair speculation in the level loop (az_capi.hip: pair_plan, az_level.hip: lookup stage, az_geom_dev.h:
+"""Pair speculation in the level loop (az_search.hip: pair_plan, az_level.hip: lookup stage, az_geom_dev.h:
 spec_children_rows) vs the plain level loop -- identical bits.
 
 The head pass of level l can also evaluate one row per distinct RoIPool window among ALL children of its regions:
@@ -93,7 +93,7 @@ def test_pair_speculation_equals_plain_level_loop(small, mods, H, W, kw):
 
 def test_history_turns_pair_speculation_on(small, mods):
     """Without history nothing is speculated; after a search of the same shape the context decides by its cost model
-    (az_capi.hip: pair_plan): a dense tree (Tz = 0) speculates; whatever it decides for a sparse one, the bits hold."""
+    (az_search.hip: pair_plan): a dense tree (Tz = 0) speculates; whatever it decides for a sparse one, the bits hold."""
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
     net = HipAZNet(head, name="hist")
