@@ -655,6 +655,19 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
     auto tiles_for = [&](int st) {
         int t = (st + 3) >> 2;
         if (!mloop) t = max(t, min(st, (int)gridDim.x / G));
+        if (!mloop && G * t > (int)gridDim.x) {
+            // more items than resident workgroups: the launch takes ceil(items / workgroups) turns of one tile each.  Finer
+            // tiles (not below 3 strips: 1- and 2-strip tiles keep the matrix pipe waiting for their short accumulation
+            // chains) can make the turns shorter -- 25 strips x 80 groups: 7 tiles of <= 4 strips = 2 turns of 4, 9 tiles
+            // of <= 3 = 2 turns of 3 (int7 at 773 rows: 100 -> 85 us).  Who computes which rows, never a row's bits.
+            const int grid = (int)gridDim.x;
+            int best = t, best_cost = ((G * t + grid - 1) / grid) * ((st + t - 1) / t);
+            for (int u = t + 1; u <= st && (st + u - 1) / u >= 3; ++u) {
+                const int cost = ((G * u + grid - 1) / grid) * ((st + u - 1) / u);
+                if (cost < best_cost) { best = u; best_cost = cost; }
+            }
+            t = best;
+        }
         return t;
     };
     int strips = (M + 31) >> 5;

@@ -16,7 +16,7 @@ for lanes in 2 1; do
   ks=$(find "$d/kt" -name '*kernel_stats.csv' | head -1)
   kt=$(find "$d/kt" -name '*kernel_trace.csv' | head -1)
   python3 "$tools/summarize_prof.py" "$ks" "$out/lanes${lanes}_kernel_stats.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py $args --lanes $lanes"
-  python3 "$tools/trace_gaps.py" "$kt" > "$out/lanes${lanes}_gaps.txt" 2>&1
+  python3 "$tools/lane_timeline.py" "$kt" > "$out/lanes${lanes}_timeline.txt" 2>&1
   rm -rf "$d"
 done
 head -12 "$out"/lanes2_kernel_stats.csv "$out"/lanes1_kernel_stats.csv

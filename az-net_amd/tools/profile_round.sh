@@ -32,7 +32,7 @@ run_set() {
   ks=$(find "$d/kt" -name '*kernel_stats.csv' | head -1)
   kt=$(find "$d/kt" -name '*kernel_trace.csv' | head -1)
   python3 "$tools/summarize_prof.py" "$ks" "$out/${pfx}kernel_stats.csv" "rocprofv3 --kernel-trace --stats -- python3 bench.py $args"
-  python3 "$tools/trace_gaps.py" "$kt" > "$out/${pfx}gaps.txt" 2>&1
+  python3 "$tools/lane_timeline.py" "$kt" > "$out/${pfx}timeline.txt" 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$d/pmc_$ctr" -- python3 bench.py $args > /dev/null 2> "$d/pmc_$ctr.log"
   done

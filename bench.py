@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--no-queue-ahead", action="store_true",
                     help="launch image i+1 only after image i has been fetched (the GPU then idles ~40 us per image while "
                          "the host turns around)")
+    ap.add_argument("--queue-depth", type=int, default=0,
+                    help="searches the host keeps launched and unfetched (0 = lanes + 1: with two lanes the next image of a "
+                         "lane is already queued behind the one it works on, so the lane never waits for the host)")
     ap.add_argument("--event-every", type=int, default=5,
                     help="HIP events around the fc GEMM launches of every n-th timed step (1: every step, ~30 us/step of stream time)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
@@ -305,18 +308,15 @@ def main():
                     collect()
 
         if args.inflight == 1:
-            ahead = not args.no_queue_ahead
-            if nsteps > 0:
-                launch(0)
             trace = step_trace
+            launched = 0
             for i in range(nsteps):
                 t_i = time.perf_counter()
-                if ahead and i + 1 < nsteps:
-                    launch(i + 1)
+                while launched < min(nsteps, i + depth):
+                    launch(launched)
+                    launched += 1
                 reruns[0] += int(net.ctx.propose_fetch(want_scores=True, want_stats=True)[2].n_reruns)
                 done(i)
-                if not ahead and i + 1 < nsteps:
-                    launch(i + 1)
                 if trace is not None:
                     trace.append((time.perf_counter() - t_i) * 1e3)
             return
@@ -331,6 +331,8 @@ def main():
         for m in q:
             m.ctx.propose_fetch(want_scores=True)
 
+    # searches launched and not yet fetched in the loops below
+    depth = 1 if args.no_queue_ahead else (args.queue_depth if args.queue_depth > 0 else args.lanes + 1)
     reruns = [0]                       # searches of the loop that had to be run twice (az_stats.n_reruns)
     ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
     step_trace = []                    # host-side wall time of every step of the loop (diagnostics: median / tail in the line)
@@ -525,7 +527,7 @@ def main():
                        "searches_run_twice_in_timed_region": reruns_timed,
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
                        "parallelism": "image-shard x%d" % world, "images_in_flight_per_gpu": args.inflight,
-                       "host_queue_ahead": (0 if args.no_queue_ahead else 1),
+                       "host_queue_ahead": (0 if args.no_queue_ahead else 1), "searches_launched_and_unfetched": depth,
                        "lanes_per_context": args.lanes,
                        "images_overlapping_on_the_gpu": (2 if (args.lanes == 2 and not args.no_queue_ahead) else 1) * args.inflight,
                        "gather": ("RCCL all_gather every %d images/rank (in the timed loop)" % args.gather_every)
@@ -589,16 +591,14 @@ def main():
         cn = ctxnet or net
 
         def f(k):
-            # (same host pattern as the main loop: image i+1 is enqueued while image i is being waited for)
-            ahead = not args.no_queue_ahead
-            if k > 0:
-                cn.ctx.propose_launch(prm, fmap=convs[0], producer_done=True)
+            # (same host pattern as the main loop: `depth` searches launched and unfetched; a context on one lane queues two)
+            dd = min(depth, 2 * int(getattr(cn.ctx, "lanes", 1)))
+            launched = 0
             for i in range(k):
-                if ahead and i + 1 < k:
-                    cn.ctx.propose_launch(prm, fmap=convs[(i + 1) % len(convs)], producer_done=True)
+                while launched < min(k, i + dd):
+                    cn.ctx.propose_launch(prm, fmap=convs[launched % len(convs)], producer_done=True)
+                    launched += 1
                 cn.ctx.propose_fetch(want_scores=True)
-                if not ahead and i + 1 < k:
-                    cn.ctx.propose_launch(prm, fmap=convs[(i + 1) % len(convs)], producer_done=True)
         return f
 
     # ---- the same loop on ONE lane: strictly one image at a time on the GPU (the host still queues one ahead) -----------
@@ -852,11 +852,11 @@ def main():
             cnt_r = [0]
 
             def fq(k, pq=pq):
-                if k > 0:
-                    net.ctx.propose_launch(pq, fmap=convs[0], producer_done=True)
+                launched = 0
                 for i in range(k):
-                    if i + 1 < k:
+                    while launched < min(k, i + depth):
                         net.ctx.propose_launch(pq, fmap=convs[0], producer_done=True)
+                        launched += 1
                     cnt_r[0] += int(net.ctx.propose_fetch(want_stats=True)[1].n_reruns)
             gc.collect(); gc.disable()
             fq(5)
