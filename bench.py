@@ -1003,7 +1003,8 @@ def main():
     if rank == 0 and box is not None:
         out["box"] = box
         out["roofline"]["frac_of_sustained"] = out["roofline"]["achieved"] / box["sustained_fp32_mfma_tflops"]
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (N = 1 only: at N > 1 the other ranks would sit in the closing barrier while rank 0 holds the host's cores)
         fm = conv.detach().cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(head, fm, args.tz)
         out["gpu_over_cpu"] = out["value"] / world / out["cpu_baseline"]["value"]
