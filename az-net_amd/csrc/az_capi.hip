@@ -564,7 +564,17 @@ int az_set_graphs(az_ctx *c, int on)
 int az_set_profiling(az_ctx *c, int on)
 {
     if (!c) return AZ_ERR_INVALID;
-    if (on & 8) {
+    const int asked = on;
+    if ((on & 8) && (on & 16) && c->span_ring) {
+        // bit 4 with bit 3: forget the spans recorded so far WITHOUT touching the GPU -- the ring keeps handing out slots it
+        // has not used yet (each is used once), so nothing has to be cleared: no stream synchronisation, no copy, no idle
+        // gap in front of the region the caller is about to time
+        std::vector<AzEventRec> keep;
+        for (auto &e : c->events) if (e.slot < 0) keep.push_back(e);
+        c->events.swap(keep);
+        on &= ~16;
+    } else if (on & 8) {
+        on &= ~16;
         // every slot starts as (first-in = ~0, last-out = 0); a slot is used once between two calls of this function
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -580,7 +590,7 @@ int az_set_profiling(az_ctx *c, int on)
     }
     c->profiling = on;
     if (!on) clear_events(c);
-    if (c->twin) az_set_profiling(c->twin, on);
+    if (c->twin) az_set_profiling(c->twin, asked);
     return AZ_OK;
 }
 

@@ -337,7 +337,8 @@ int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const flo
  * 8 = the fp32 fc GEMM launches time THEMSELVES instead (first workgroup in to last workgroup out on the GPU's constant
  * 100 MHz clock, written by the kernels: no event pair on the stream -- an event pair costs ~7 us of stream time and, with
  * two lanes, also spans the time a launch waits for the other lane's GEMM to release the CUs); 32768 launches per call of
- * az_set_profiling, which resets them;
+ * az_set_profiling, which resets them; 16 (with 8, after a call with 8) = forget the spans recorded so far without
+ * touching the GPU -- no stream synchronisation, no copy: what to call right in front of a region to be timed;
  * 0 = off.  names_out: `cap` slots of 32 chars. */
 int az_set_profiling(az_ctx *ctx, int mode);
 int az_last_kernel_times(az_ctx *ctx, char *names_out, float *ms_out, int32_t *level_out,
