@@ -212,6 +212,7 @@ struct az_ctx {
     struct PendingSearch {
         az_params p{};
         int nlev = 0, is_static = 0, defer = 0, pair_mask = 0, npass = 0, full = 0, reruns = 0;
+        int cut = 0;                        // > 0: the search was enqueued up to (not including) this level
         int pass_src[AZ_MAX_LEVELS + 2] = {0};
         void *stage_dst = nullptr;          // az_propose_stage_result_dev target
         size_t stage_cap = 0;
@@ -240,6 +241,11 @@ struct az_ctx {
     std::map<std::string, GraphEntry> graphs;        // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_defer = 0;
+    // Early end: a tree whose previous search of the shape had no regions from some level on is enqueued only up to that
+    // level (the passes and geometry kernels of an empty level cost ~35 us each, a fifth of a sparse search); the last
+    // geometry kernel checks -- regions after all set err bit 1024 and az_propose_fetch runs the search again in full
+    // (params.reserved bit 12 / AZ_EARLY_END=0: never).  cut_block: searches left before the next attempt after a miss.
+    int last_cut = 0, cut_block = 0, cut_env = -1;
     // head passes of the search being enqueued / last launched: where each one's row count lives
     // (>= 0: int index into AzCounts; < 0: -(rows + 1), a count the host knows)
     int npass = 0;

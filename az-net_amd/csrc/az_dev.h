@@ -191,6 +191,10 @@ struct AzFusedArgs {
     int *index, *inv, *zr, *choff, *csrc;
     float *rois, *urois;          // (next_dedup) roi projection + dedup of the first level after the fused ones
     int next_dedup, defer_root;
+    int cut_next;                 // the host enqueued nothing for the level after the fused ones (it expects the tree to
+                                  // end here): regions for it set err bit 1024 and the search is run again without the cut
+    int cut_short;                // ... and expects it to end before the third level: the speculative pass evaluated the root
+                                  // and its children only; a third level sets err bit 1024
     int spec_next;                // (next_dedup) that level's head pass also carries rows for all children of its regions
     int *choff_next, *crow;       // (spec_next) first child of every region in the all-children list; child -> spec row
     float spatial_scale;
@@ -221,6 +225,7 @@ void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
 struct AzLevelArgs {
     AzCounts *cnt;
     int level, nlev;
+    int cut_next;                  // as AzFusedArgs::cut_next, for the level after this one
     const double *B;               // regions of this level
     double *Bnext;                 // regions of the next level
     const double *pred_u;          // head outputs of this level's unique rois

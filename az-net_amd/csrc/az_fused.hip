@@ -248,6 +248,10 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
         const int cur = l & 1;
         const double *B = sB[cur];
         if (tid == 0) { cnt->P[l] = P; cnt->ytot[l] = ybase; }
+        if (a.cut_short && l == 2 && P > 0) {        // the pass holds no rows for this level: the host runs the search again
+            if (tid == 0) atomicOr(&cnt->err, 1024);
+            return;
+        }
         if (P == 0) {                                // Z was empty: the reference's loop breaks
             if (tid == 0)
                 for (int ll = l; ll < a.n_fused; ++ll) { cnt->P[ll] = 0; cnt->ytot[ll + 1] = ybase; }
@@ -391,6 +395,10 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
 #endif
     for (int i = tid; i < P * 4; i += NTL) a.B[nxt][i] = sB[nxt][i];
     if (tid == 0) cnt->P[a.n_fused] = P;
+    if (a.cut_next) {                // the host stopped the search here: right if the tree did, too
+        if (tid == 0 && P > 0) atomicOr(&cnt->err, 1024);
+        return;
+    }
     if (a.next_dedup && a.n_fused < a.nlev) {
         // the next level runs on the fused level kernel (az_level.hip), which expects its rois deduplicated
         if (P > a.batch) { if (tid == 0) atomicOr(&cnt->err, 8); return; }      // chunked dedup: multi-launch path

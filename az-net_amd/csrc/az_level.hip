@@ -281,6 +281,10 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     }
     if (Pn > LV_R || Pn > a.capR) { if (tid == 0) { atomicOr(&cnt->err, Pn > a.capR ? 1 : 8); cnt->scratch[5] = l + 1; } return; }
     if (tid == 0) { cnt->CH[l] = CH; cnt->P[l + 1] = Pn; }
+    if (a.cut_next) {                // the host stopped the search after this level: right if the tree did, too
+        if (tid == 0 && Pn > 0) atomicOr(&cnt->err, 1024);
+        return;
+    }
     __syncthreads();
     TSTAMP();
     // ---- level l+1: roi projection + feature-space dedup (test.py:61-97, 210-218) ---------------------

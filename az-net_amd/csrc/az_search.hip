@@ -4,7 +4,8 @@
 #include "az_ctx.h"
 
 // Which form of the search a call takes.
-struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; int full; /* 0 / 1 tree rows / 2 closure */ };
+struct SearchPlan { int n_spec; bool fused, fused_lv, defer_root; int pair_mask; int lv_limit; int full; /* 0 / 1 tree rows / 2 closure */
+                    int cut; /* > 0: nothing is enqueued from this level on (the tree is expected to end before it) */ };
 
 // Cost of one head pass (RoIPool, int6, reduce, int7, heads) at `rows` rois, in us: measured on this device at a few row
 // counts the first time the context launches a search (calibrate_passes) and interpolated; until then (or with
@@ -164,6 +165,18 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     q.full = (c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit >= q.n_spec && c->plan &&
               c->plan->fs[c->full_now - 1].full_state == 1 && plan_is_for(*c->plan, p, nlev)) ? c->full_now : 0;
     if (q.full) { q.defer_root = false; q.pair_mask = 0; }
+    // early end: the previous search of the shape had no regions from level `cut` on (a level the fused kernels hand over
+    // to: the one before it carries the check)
+    q.cut = 0;
+    if (c->cut_env < 0) { const char *e = getenv("AZ_EARLY_END"); c->cut_env = (e && !atoi(e)) ? 0 : 1; }
+    if (c->cut_env && !(p->reserved & 4096) && !q.full && !tune && q.fused && q.fused_lv && c->cut_block == 0 &&
+        c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev) {
+        // (a tree that ended before its third level: the speculative pass then evaluates the root and its children only)
+        for (int l = (q.n_spec == 3 ? 2 : q.n_spec); l < nlev; ++l)
+            if (c->hint_P[l] == 0) { q.cut = l; break; }
+        if (q.cut > q.n_spec && q.cut - 1 >= q.lv_limit) q.cut = 0;      // (the level before it runs on the multi-launch kernels)
+        if (q.cut && q.cut < q.n_spec && q.defer_root) q.cut = 0;         // (cannot be: a deferred root needs level 4 to exist)
+    }
     return q;
 }
 
@@ -211,6 +224,8 @@ static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
     HIPCHK(c, hipMemcpyAsync(e.B1, c->spec_scr_B1[defer], (size_t)e.P1 * 4 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(e.choff, c->spec_scr_choff[defer], (size_t)e.P1 * sizeof(int), hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipMemcpyAsync(e.Udev, &c->cnt->specU, sizeof(int), hipMemcpyDeviceToDevice, s));
+    const int rows_short = (defer ? 0 : 1) + e.P1;        // the pass without the third level's rows (early end: plan.cut == 2)
+    HIPCHK(c, hipMemcpyAsync(e.Udev + 1, &rows_short, sizeof(int), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     if (c->spec_store.size() >= 128) {
         // drop the least recently used entry; captured launch sequences may hold its pointers: drop those too
@@ -654,6 +669,10 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         // lacks), the root last; outputs by row in zoom_s / score_s / delta_s
         launch_head(c, fp->full_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 1,
                     fp->full_urois, fp->full_ubox, fp->Ufull);
+    else if (fused && plan.cut == 2 && !defer_root)
+        // early end before the third level: the first 1 + P1 rows of S = [root ; B1 ; children of all of B1]
+        launch_head(c, c->spec_U[0] + 1, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
+                    0, c->spec_urois[0], nullptr, 1 + c->spc[0].P1);
     else if (fused)
         launch_head(c, c->spec_U[defer_root ? 1 : 0], -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
                     0, c->spec_urois[defer_root ? 1 : 0], nullptr, c->spc[defer_root ? 1 : 0].U);
@@ -675,6 +694,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
         a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
         a.rois = c->rois; a.urois = c->urois; a.next_dedup = fused_lv ? 1 : 0; a.defer_root = defer_root ? 1 : 0;
+        a.cut_next = (plan.cut && plan.cut <= n_spec) ? 1 : 0;
+        a.cut_short = (plan.cut == 2 && !defer_root) ? 1 : 0;
         a.spec_next = (plan.pair_mask >> n_spec) & 1; a.choff_next = c->choff_pair; a.crow = c->crow;
         a.spatial_scale = c->spatial_scale;
         a.row_map = full ? fp->spec_map : nullptr; a.root_row = full ? fp->Ufull - 1 : 0;
@@ -683,7 +704,8 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         azk_spec_levels(s, a);
     }
     bool have_v = full;               // this level's head outputs were looked up among the previous pass's rows (*_v arrays)
-    for (int l = fused ? n_spec : 0; l < nlev; ++l) {
+    const int nlev_run = plan.cut ? plan.cut : nlev;     // (early end: the levels from plan.cut on are not enqueued)
+    for (int l = fused ? n_spec : 0; l < nlev_run; ++l) {
         const int cur = l & 1;
         const int *Pptr = &c->cnt->P[l];
         int *Uptr = &c->cnt->U[l];
@@ -700,6 +722,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             Timed t(c, "level_geom", l);
             AzLevelArgs a;
             a.cnt = c->cnt; a.level = l; a.nlev = nlev;
+            a.cut_next = (plan.cut == l + 1) ? 1 : 0;
             a.B = c->B[cur]; a.Bnext = c->B[cur ^ 1];
             a.pred_u = have_v ? Vp(l) : c->pred_u; a.score_u = have_v ? Vs(l) : c->score_u;
             a.zoom_u = have_v ? Vz(l) : c->zoom_u; a.keep_u = have_v ? Vk(l) : c->keep_u; a.Uptr = Uptr;
@@ -780,7 +803,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         }
         have_v = false;           // (a level on the multi-launch kernels never looks the next one's outputs up)
     }
-    enqueue_select(c, p, nlev, k);
+    enqueue_select(c, p, nlev_run, k);
     if (tune && c->pool) {
         Timed t(c, "pool_append", nlev);
         azk_pool_append(s, c->hisZ, &c->cnt->nhis, c->capHis, c->pool, c->pool_n, c->pool_cap);
@@ -832,6 +855,7 @@ int launch_impl(az_ctx *c, const az_params *p)
     if (!stat && (rc = ensure_spec_cache(c, p, plan_search(c, p, nlev, tune))) != AZ_OK) return rc;
     c->last_defer = (!stat && plan_search(c, p, nlev, tune).defer_root) ? 1 : 0;
     c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
+    c->last_cut = stat ? 0 : plan_search(c, p, nlev, tune).cut;
     hipStream_t s = c->stream;
     auto enqueue = [&]() { c->npass = 0; prep_scale(c); return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
@@ -858,6 +882,7 @@ int launch_impl(az_ctx *c, const az_params *p)
         key.append((const char *)&c->last_pair_mask, sizeof(int));
         key.append((const char *)&c->last_defer, sizeof(int));
         key.append((const char *)&c->last_full, sizeof(int));
+        key.append((const char *)&c->last_cut, sizeof(int));
         for (int l = 0; l < nlev; ++l) { const int mr = many_rows_expected(c, l); key.append((const char *)&mr, sizeof(int)); }
         const void *pp = (stat || c->last_full) ? (const void *)c->plan : nullptr;
         key.append((const char *)&pp, sizeof(pp));
@@ -895,6 +920,8 @@ int launch_impl(az_ctx *c, const az_params *p)
     az_ctx::PendingSearch q;
     q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
     q.full = c->last_full;
+    q.cut = c->last_cut;
+    if (c->cut_block > 0) --c->cut_block;
     q.npass = c->npass;
     q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
     q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
@@ -955,7 +982,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
     if (st) {
         std::memset(st, 0, sizeof(*st));
         st->n_levels = nlev;
-        st->n_candidates = h.ytot[nlev];
+        st->n_candidates = h.ytot[q.cut ? q.cut : nlev];
         st->spec_rows = h.specU;
         st->root_deferred = q.defer;
         st->static_plan = q.is_static;
@@ -1011,6 +1038,14 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         p2.reserved = (p2.reserved | 64) & ~128;
         return rerun(p2);
     }
+    if ((h.err & 1024) && q.cut) {
+        // the search was enqueued up to level q.cut only (the previous search of the shape ended there) and this tree goes
+        // on: run it in full, and leave the next searches alone for a while
+        c->cut_block = 16;
+        az_params p2 = q.p;
+        p2.reserved |= 4096;
+        return rerun(p2);
+    }
     if ((h.err & 256) && !(q.p.reserved & 256)) {
         // the whole-tree pass did not hold a window this search needed (a _sift_dup survivor other than the full tree's):
         // repeat it level by level; its history then says "pruned tree" and the next search of the shape goes that way at once
@@ -1064,7 +1099,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
     }
     const int n = h.nsel;
     // (the candidate list stays readable only while no later search has been queued: it would be overwriting it)
-    c->cand_n = c->pend.empty() ? h.ytot[nlev] : -1;
+    c->cand_n = c->pend.empty() ? h.ytot[q.cut ? q.cut : nlev] : -1;
     c->his_n = h.nhis;
     if (st) st->n_proposals = n;
     *n_out = n;

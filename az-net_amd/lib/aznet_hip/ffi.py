@@ -289,7 +289,8 @@ class AzContext(object):
     @staticmethod
     def make_params(im_h, im_w, scale, Tz, num_proposals=300, fixed_num=True, Tc=0.05,
                     dedup=1. / 16., eps=1e-14, min_side=10, batch_size=10000, speculate=True, fused=True,
-                    tune=False, radix_select=False, fused_levels=True, static_tree=True, pair_spec=None, full_spec=None):
+                    tune=False, radix_select=False, fused_levels=True, static_tree=True, pair_spec=None, full_spec=None,
+                    early_end=True):
         """speculate=False evaluates levels 1-3 one by one instead of in one pass (same bits,
         slower); fused=False keeps the geometry of those levels as separate launches;
         fused_levels=False does the same for the levels after them (az_level.hip).  All
@@ -305,14 +306,18 @@ class AzContext(object):
         head pass evaluates the rows of the shape's full tree, every level finding its outputs by RoIPool window (pays
         for dense trees: after a full tree the full tree's rows, otherwise the closure rows); False = never; True = the
         full tree's rows whenever the shape allows; "closure" = the closure rows whenever the shape allows -- every region
-        any pruning of the tree can produce, so no Tz can miss a window (same bits in all four)."""
+        any pruning of the tree can produce, so no Tz can miss a window (same bits in all four).
+        early_end=False: enqueue every level even when the context's previous search of the shape ended early (by default
+        such a search is enqueued only up to the level where that one ended, and run again in full if this tree goes on;
+        same bits)."""
         return AzParams(int(im_h), int(im_w), float(scale), float(Tz), float(Tc), float(dedup),
                         float(eps), float(min_side), int(batch_size), int(num_proposals),
                         1 if fixed_num else 0,
                         (0 if speculate else 1) | (0 if fused else 2) | (4 if tune else 0) |
                         (8 if radix_select else 0) | (0 if fused_levels else 16) | (0 if static_tree else 32) |
                         (0 if pair_spec is None else (128 if pair_spec else 64)) |
-                        (0 if full_spec is None else ((512 | 1024) if full_spec == "closure" else (512 if full_spec else 256))))
+                        (0 if full_spec is None else ((512 | 1024) if full_spec == "closure" else (512 if full_spec else 256))) |
+                        (0 if early_end else 4096))
 
     def propose(self, params, want_scores=False, want_stats=False):
         cap = params.num_proposals if params.fixed_num else self.max_candidates

@@ -1,0 +1,70 @@
+"""Early end of a sparse search: a search whose context's previous search of the image shape had no regions from some level
+on is enqueued only up to that level; regions there after all -> the search is run again in full.  Same bits as the plain
+level loop either way (lib/detect/test.py:373-391: the reference's loop simply finds Z empty)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    return ffi, synth, HipAZNet
+
+
+def _plain(ffi, H, W, scale, Tz, **kw):
+    return ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, fused_levels=False, static_tree=False,
+                                     pair_spec=False, full_spec=False, early_end=False, **kw)
+
+
+@pytest.mark.parametrize("H,W,scale", [(600, 1000, 1.0), (375, 500, 1.6), (480, 640, 1.25)])
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, scale, lanes):
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="early_end")
+    ref = HipAZNet(head, name="early_end_ref")
+    net.ctx.set_lanes(lanes)
+    C = synth.SMALL_DIMS["C"]
+    fh, fw = int(np.ceil(H * scale / 16.0)), int(np.ceil(W * scale / 16.0))
+    maps = [synth.make_feature_map(40 + i, C, fh, fw) for i in range(3)]
+    # thresholds from the zoom scores of the first map: one that prunes everything below level 2, one that keeps most
+    ref.set_conv(maps[0])
+    _, _, st0 = ref.propose(_plain(ffi, H, W, scale, 0.0), want_scores=True, want_stats=True)
+    assert st0.n_levels >= 4
+    # hi: above every level-2 zoom score of the three maps and below the root's forced 1.0 (test.py:383-384): trees [1, 8]
+    B1 = ref.ctx.divide_region(np.array([[0.0, 0.0, W - 1.0, H - 1.0]]), 10.0)
+    zmax = 0.0
+    for m in maps:
+        ref.set_conv(m)
+        z, _, _ = ref.ctx.head_forward(np.hstack([np.zeros((len(B1), 1)), B1 * scale]).astype(np.float32))
+        zmax = max(zmax, float(z.max()))
+    assert zmax < 1.0
+    hi, lo = 0.5 * (zmax + 1.0), 0.0
+
+    def run(Tz, fmap):
+        net.set_conv(fmap)
+        ref.set_conv(fmap)
+        Y, S, st = net.propose(ffi.AzContext.make_params(H, W, scale, Tz, static_tree=False, full_spec=False),
+                               want_scores=True, want_stats=True)
+        Yr, Sr, sr = ref.propose(_plain(ffi, H, W, scale, Tz), want_scores=True, want_stats=True)
+        assert np.array_equal(Y, Yr) and np.array_equal(S, Sr)
+        assert list(st.level_regions) == list(sr.level_regions) and st.n_candidates == sr.n_candidates
+        assert st.num_eval == sr.num_eval and st.depth == sr.depth
+        Ya, Sa = net.ctx.last_candidates()
+        Yb, Sb = ref.ctx.last_candidates()
+        assert np.array_equal(Ya, Yb) and np.array_equal(Sa, Sb)
+        return st
+
+    s1 = run(hi, maps[0])                                # no history of this shape yet: every level enqueued
+    assert list(s1.level_regions[:2]) == [1, len(B1)] and sum(s1.level_regions[2:s1.n_levels]) == 0 and s1.n_reruns == 0
+    s2 = run(hi, maps[1])                                # the previous search ended at level 2: this one is cut there
+    assert s2.n_reruns == 0 and s2.n_passes <= s1.n_passes
+    s3 = run(lo, maps[2])                                # a full tree behind a sparse one: cut, missed, run again
+    assert s3.n_reruns == 1 and sum(s3.level_regions[2:s3.n_levels]) > 0
+    s4 = run(hi, maps[0])                                # (blocked for a while after a miss: no cut, no rerun)
+    assert s4.n_reruns == 0
+    s5 = run(lo, maps[1])
+    assert s5.n_reruns == 0
