@@ -62,6 +62,12 @@ def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, sc
     assert list(s1.level_regions[:2]) == [1, len(B1)] and sum(s1.level_regions[2:s1.n_levels]) == 0 and s1.n_reruns == 0
     s2 = run(hi, maps[1])                                # the previous search ended at level 2: this one is cut there
     assert s2.n_reruns == 0 and s2.n_passes <= s1.n_passes
+    # the same with a data-dependent proposal count (cfg.SEAR.FIXED_PROPOSAL_NUM = False: everything with score >= Tc)
+    net.set_conv(maps[0]); ref.set_conv(maps[0])
+    Yt, St = net.propose(ffi.AzContext.make_params(H, W, scale, hi, static_tree=False, full_spec=False, fixed_num=False, Tc=0.3),
+                         want_scores=True)
+    Yq, Sq = ref.propose(_plain(ffi, H, W, scale, hi, fixed_num=False, Tc=0.3), want_scores=True)
+    assert np.array_equal(Yt, Yq) and np.array_equal(St, Sq)
     s3 = run(lo, maps[2])                                # a full tree behind a sparse one: cut, missed, run again
     assert s3.n_reruns == 1 and sum(s3.level_regions[2:s3.n_levels]) > 0
     s4 = run(hi, maps[0])                                # (blocked for a while after a miss: no cut, no rerun)
