@@ -1,0 +1,99 @@
+// az_epilogue.hip -- what follows a backbone convolution, in ONE pass over its output: bias + ReLU, and for the layers in
+// front of a pooling layer bias + ReLU + 2x2/2 max-pool (ceil mode), on channel-last activations.
+// The VGG16 convolutions themselves stay PyTorch-ROCm's (MIOpen), as north_star says; PyTorch then runs the bias add and the
+// ReLU as two more element-wise launches over the layer's whole output (and the pool as a third): at 600x1000 that is
+// 154 MB read and written twice behind conv1_x -- 0.46 ms per image, 9 % of the CLI's loop (az-net_amd/tools/cli_trace.sh).
+// Layer definitions: models/Pascal/VGG16/az-net/test.prototxt:16-384 (Convolution with bias_term, ReLU in place, Pooling MAX
+// kernel 2 stride 2; Caffe pools in ceil mode: a last window may be clipped by the map's edge).
+// Arithmetic is PyTorch's: fp32 add, max(., 0), max over the window -- and max(relu(y_i + b)) == relu(max(y_i) + b) bit for
+// bit (rounding is monotonic), which is the order used here.
+#include <hip/hip_runtime.h>
+
+#include "../../include/aznet_hip.h"
+
+namespace {
+
+// y: [HW][C] (channel-last), C % 4 == 0.  One float4 per thread and turn.
+__global__ void __launch_bounds__(256) k_bias_relu_cl(float4 *__restrict__ y, const float4 *__restrict__ bias, long long n4, int C4)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = y[i];
+        const float4 b = bias[i % C4];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        y[i] = v;
+    }
+}
+
+// y: [C][HW] (NCHW): the slower layout of the backbone, kept correct rather than fast
+__global__ void __launch_bounds__(256) k_bias_relu_nchw(float *__restrict__ y, const float *__restrict__ bias, long long n, long long hw, int C)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = y[i] + bias[(i / hw) % C];
+        y[i] = v > 0.f ? v : 0.f;
+    }
+}
+
+// y: [H][W][C] -> out: [OH][OW][C], OH = ceil(H / 2), OW = ceil(W / 2); window rows / columns past the map are left out
+__global__ void __launch_bounds__(256) k_bias_relu_pool_cl(const float4 *__restrict__ y, const float4 *__restrict__ bias,
+                                                           float4 *__restrict__ out, int C4, int H, int W, int OH, int OW)
+{
+    const long long n4 = (long long)OH * OW * C4, stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int c = (int)(i % C4);
+        const long long p = i / C4;
+        const int ow = (int)(p % OW), oh = (int)(p / OW);
+        const int h0 = 2 * oh, w0 = 2 * ow;
+        const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
+        const float4 *r0 = y + ((long long)h0 * W + w0) * C4 + c;
+        float4 m = r0[0];
+        auto mx = [&](const float4 &v) {
+            m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y; m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+        };
+        if (w1) mx(r0[C4]);
+        if (h1) { mx(r0[(long long)W * C4]); if (w1) mx(r0[(long long)W * C4 + C4]); }
+        const float4 b = bias[c];
+        m.x += b.x; m.y += b.y; m.z += b.z; m.w += b.w;
+        m.x = m.x > 0.f ? m.x : 0.f; m.y = m.y > 0.f ? m.y : 0.f; m.z = m.z > 0.f ? m.z : 0.f; m.w = m.w > 0.f ? m.w : 0.f;
+        out[i] = m;
+    }
+}
+
+int grid_for(long long n)
+{
+    const long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_bias_relu(void *stream, float *y, const float *bias, int C, long long hw, int channels_last)
+{
+    if (!y || !bias || C <= 0 || hw < 0) return AZ_ERR_INVALID;
+    const long long n = (long long)C * hw;
+    if (n == 0) return AZ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (channels_last && (C & 3) == 0 && (((size_t)y | (size_t)bias) & 15) == 0)
+        hipLaunchKernelGGL(k_bias_relu_cl, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4 *)y, (const float4 *)bias, n / 4, C / 4);
+    else if (channels_last)
+        return AZ_ERR_INVALID;         // (a channel count that is no multiple of 4, or unaligned storage: the caller keeps PyTorch's ops)
+    else
+        hipLaunchKernelGGL(k_bias_relu_nchw, dim3(grid_for(n)), dim3(256), 0, s, y, bias, n, hw, C);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
+int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W)
+{
+    if (!y || !bias || !out || C <= 0 || H <= 0 || W <= 0) return AZ_ERR_INVALID;
+    if ((C & 3) != 0 || (((size_t)y | (size_t)bias | (size_t)out) & 15) != 0) return AZ_ERR_INVALID;
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    hipLaunchKernelGGL(k_bias_relu_pool_cl, dim3(grid_for((long long)OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)y, (const float4 *)bias, (float4 *)out, C / 4, H, W, OH, OW);
+    return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
+}
+
+}  // extern "C"

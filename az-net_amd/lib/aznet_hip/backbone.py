@@ -31,6 +31,7 @@ class VGG16Conv5(object):
         self.device = torch.device(device)
         self.channels_last_out = bool(channels_last_out)
         self.cl_compute = bool(channels_last_compute) and self.device.type == "cuda"
+        self.fused_epilogue = True          # (False: PyTorch's own bias / ReLU / pool launches -- tests compare the two)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.layers = []
         cin = 3
@@ -60,11 +61,30 @@ class VGG16Conv5(object):
         x = torch.as_tensor(blob, dtype=torch.float32, device=self.device)
         if self.cl_compute:
             x = x.contiguous(memory_format=torch.channels_last)
-        for layer in self.layers:
+        # On the GPU, channels_last: what follows a convolution -- bias, ReLU, and the pooling layer where there is one --
+        # is ONE pass over its output (az_bias_relu / az_bias_relu_pool, az_epilogue.hip) instead of PyTorch's two or three
+        # element-wise launches; same fp32 operations, same bits.  The convolutions are PyTorch-ROCm's either way.
+        fused = self.cl_compute and self.fused_epilogue and x.is_cuda and x.shape[0] == 1
+        skip_pool = False
+        for li, layer in enumerate(self.layers):
             if layer is None:
-                x = F.max_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
-            else:
-                x = F.relu_(F.conv2d(x, layer[1], layer[2], padding=1))
+                if not skip_pool:
+                    x = F.max_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
+                skip_pool = False
+                continue
+            if fused and layer[1].shape[0] % 4 == 0:
+                y = F.conv2d(x, layer[1], None, padding=1)
+                if y.is_contiguous(memory_format=torch.channels_last) and y.data_ptr() % 16 == 0:
+                    from . import ffi
+                    if li + 1 < len(self.layers) and self.layers[li + 1] is None:
+                        x = ffi.bias_relu_pool(y, layer[2])
+                        skip_pool = True
+                    else:
+                        x = ffi.bias_relu_(y, layer[2])
+                    continue
+                x = F.relu_(y + layer[2].view(1, -1, 1, 1))
+                continue
+            x = F.relu_(F.conv2d(x, layer[1], layer[2], padding=1))
         if self.channels_last_out:
             return x.contiguous(memory_format=torch.channels_last)
         return x.contiguous()

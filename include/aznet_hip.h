@@ -334,6 +334,18 @@ int az_image_blob_dev(az_ctx *ctx, const uint8_t *im, int h, int w, const float 
 int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means, double scale,
                          float *blob_dev, int oh, int ow, void *stream);
 
+/* ---- backbone epilogues (context-free; `stream`: a hipStream_t, NULL = the default stream) -------------------- */
+/* What follows a VGG16 convolution (models/Pascal/VGG16/az-net/test.prototxt:16-384: Convolution with bias, ReLU in
+ * place; Pooling MAX 2x2 / 2, Caffe's ceil mode) in ONE pass over the convolution's output, which PyTorch-ROCm produces
+ * without the bias (F.conv2d(x, w, None)): y = max(y + bias[c], 0) in place -- channels_last != 0: y is [hw][C] (C % 4 == 0,
+ * 16-byte aligned), else [C][hw].  PyTorch's own bias add and ReLU are two element-wise launches over the same bytes;
+ * same fp32 operations, same bits. */
+int az_bias_relu(void *stream, float *y, const float *bias, int C, long long hw, int channels_last);
+/* The same followed by the 2x2 / 2 max-pool: y [H][W][C] (channel-last, C % 4 == 0) -> out [ceil(H/2)][ceil(W/2)][C]; the
+ * last window row / column is clipped by the map's edge (ceil mode).  out = max over the window of max(y + bias, 0),
+ * computed as max(max(y) + bias, 0): the same bits (rounding is monotonic). */
+int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W);
+
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /
  * az_head_forward.  mode bits: 1 = time only the fc GEMM launches, 2 = time every launch

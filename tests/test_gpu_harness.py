@@ -332,3 +332,39 @@ def test_vgg16_conv5_plumbing(mods):
     net2 = HipAZNet(synth.make_head(seed=1, **synth.SMALL_DIMS), name="plumb2")
     net2.set_conv(conv.cpu().numpy())
     assert np.array_equal(Y, net2.propose(ffi.AzContext.make_params(600, 1000, 1.0, 0.0)))
+
+
+def test_backbone_epilogues_equal_pytorchs_ops_bit_for_bit(mods):
+    """az_bias_relu / az_bias_relu_pool (az_epilogue.hip; test.prototxt:16-384: bias, in-place ReLU, MAX pool 2x2/2 in ceil
+    mode) against PyTorch's own element-wise launches: same fp32 operations, so the same bits -- on even and odd map sizes, with
+    non-zero biases and negative inputs -- and a channels_last VGG16Conv5 with the fused epilogues gives the map it gives
+    without them (at fp32 tolerance: see below)."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for C, H, W in [(64, 600, 1000), (128, 75, 125), (512, 38, 63), (8, 1, 1), (4, 3, 2), (256, 151, 7)]:
+        y = (torch.randn(1, C, H, W, generator=g) * 3.0).cuda()
+        b = torch.randn(C, generator=g).cuda()
+        ref = F.relu(y + b.view(1, -1, 1, 1))
+        refp = F.max_pool2d(ref, 2, 2, ceil_mode=True)
+        ycl = y.clone().contiguous(memory_format=torch.channels_last)
+        got = ffi.bias_relu_(ycl.clone(memory_format=torch.preserve_format), b)
+        assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, ref)
+        gotn = ffi.bias_relu_(y.clone(), b)                      # the NCHW form
+        assert torch.equal(gotn, ref)
+        gp = ffi.bias_relu_pool(ycl, b)
+        assert tuple(gp.shape) == tuple(refp.shape) and torch.equal(gp, refp)
+    from aznet_hip.backbone import VGG16Conv5
+    x = torch.from_numpy(np.random.RandomState(3).uniform(-120, 130, (1, 3, 375, 500)).astype(np.float32))
+    bb = VGG16Conv5(device="cuda:0", seed=13, width_div=8, channels_last_compute=True, channels_last_out=True)
+    for layer_i, layer in enumerate(bb.layers):                  # non-zero biases
+        if layer is not None:
+            bb.layers[layer_i] = (layer[0], layer[1], torch.randn(layer[2].shape, generator=g).cuda() * 0.1)
+    # The whole stack, fused epilogues against PyTorch's own launches: MIOpen's convolutions do not repeat their bits from
+    # call to call at every shape (two runs of the SAME PyTorch-only stack differ by an ulp from conv5_1 on: measured), so
+    # the stack is compared at fp32 tolerance; the bit-for-bit statement is the per-launch one above.
+    fused = bb(x)
+    assert tuple(fused.shape) == (1, 64, 24, 32) and fused.is_contiguous(memory_format=torch.channels_last)
+    bb.fused_epilogue = False
+    plain = bb(x)
+    assert torch.allclose(fused, plain, rtol=1e-5, atol=1e-5 * float(plain.abs().max()))
