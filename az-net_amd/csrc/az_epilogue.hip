@@ -26,13 +26,72 @@ __global__ void __launch_bounds__(256) k_bias_relu_cl(float4 *__restrict__ y, co
     }
 }
 
-// y: [C][HW] (NCHW): the slower layout of the backbone, kept correct rather than fast
+// y: [C][HW] (NCHW, PyTorch's default layout -- what tools/prop_az.py runs unless told otherwise)
 __global__ void __launch_bounds__(256) k_bias_relu_nchw(float *__restrict__ y, const float *__restrict__ bias, long long n, long long hw, int C)
 {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float v = y[i] + bias[(i / hw) % C];
         y[i] = v > 0.f ? v : 0.f;
+    }
+}
+
+// the same with hw % 4 == 0: a float4 never straddles two channels
+__global__ void __launch_bounds__(256) k_bias_relu_nchw4(float4 *__restrict__ y, const float *__restrict__ bias, long long n4, long long hw4, int C)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float b = bias[(i / hw4) % C];
+        float4 v = y[i];
+        v.x += b; v.y += b; v.z += b; v.w += b;
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        y[i] = v;
+    }
+}
+
+// y: [C][H][W] -> out: [C][OH][OW]; a thread makes two neighbouring outputs of a row from two float4s (W % 4 == 0) or one
+// output from scalars
+template <bool VEC>
+__global__ void __launch_bounds__(256) k_bias_relu_pool_nchw(const float *__restrict__ y, const float *__restrict__ bias,
+                                                             float *__restrict__ out, int C, int H, int W, int OH, int OW)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    if (VEC) {
+        const int OW2 = OW >> 1;                               // W % 4 == 0: OW even, pairs of outputs
+        const long long n = (long long)C * OH * OW2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const int p = (int)(i % OW2);
+            const long long r = i / OW2;
+            const int oh = (int)(r % OH), c = (int)(r / OH);
+            const float *r0 = y + ((long long)c * H + 2 * oh) * W + 4 * p;
+            const float4 a = *reinterpret_cast<const float4 *>(r0);
+            float m0 = a.x > a.y ? a.x : a.y, m1 = a.z > a.w ? a.z : a.w;
+            if (2 * oh + 1 < H) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(r0 + W);
+                const float n0 = b4.x > b4.y ? b4.x : b4.y, n1 = b4.z > b4.w ? b4.z : b4.w;
+                m0 = n0 > m0 ? n0 : m0; m1 = n1 > m1 ? n1 : m1;
+            }
+            const float b = bias[c];
+            m0 += b; m1 += b;
+            float2 o;
+            o.x = m0 > 0.f ? m0 : 0.f; o.y = m1 > 0.f ? m1 : 0.f;
+            *reinterpret_cast<float2 *>(out + ((long long)c * OH + oh) * OW + 2 * p) = o;
+        }
+    } else {
+        const long long n = (long long)C * OH * OW;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const int ow = (int)(i % OW);
+            const long long r = i / OW;
+            const int oh = (int)(r % OH), c = (int)(r / OH);
+            const int h0 = 2 * oh, w0 = 2 * ow;
+            const float *r0 = y + ((long long)c * H + h0) * W + w0;
+            float m = r0[0];
+            const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
+            if (w1) m = r0[1] > m ? r0[1] : m;
+            if (h1) { m = r0[W] > m ? r0[W] : m; if (w1) m = r0[W + 1] > m ? r0[W + 1] : m; }
+            m += bias[c];
+            out[i] = m > 0.f ? m : 0.f;
+        }
     }
 }
 
@@ -81,18 +140,29 @@ int az_bias_relu(void *stream, float *y, const float *bias, int C, long long hw,
         hipLaunchKernelGGL(k_bias_relu_cl, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4 *)y, (const float4 *)bias, n / 4, C / 4);
     else if (channels_last)
         return AZ_ERR_INVALID;         // (a channel count that is no multiple of 4, or unaligned storage: the caller keeps PyTorch's ops)
+    else if ((hw & 3) == 0 && ((size_t)y & 15) == 0)
+        hipLaunchKernelGGL(k_bias_relu_nchw4, dim3(grid_for(n / 4)), dim3(256), 0, s, (float4 *)y, bias, n / 4, hw / 4, C);
     else
         hipLaunchKernelGGL(k_bias_relu_nchw, dim3(grid_for(n)), dim3(256), 0, s, y, bias, n, hw, C);
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 
-int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W)
+int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W, int channels_last)
 {
     if (!y || !bias || !out || C <= 0 || H <= 0 || W <= 0) return AZ_ERR_INVALID;
-    if ((C & 3) != 0 || (((size_t)y | (size_t)bias | (size_t)out) & 15) != 0) return AZ_ERR_INVALID;
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-    hipLaunchKernelGGL(k_bias_relu_pool_cl, dim3(grid_for((long long)OH * OW * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       (const float4 *)y, (const float4 *)bias, (float4 *)out, C / 4, H, W, OH, OW);
+    hipStream_t s = (hipStream_t)stream;
+    if (channels_last) {
+        if ((C & 3) != 0 || (((size_t)y | (size_t)bias | (size_t)out) & 15) != 0) return AZ_ERR_INVALID;
+        hipLaunchKernelGGL(k_bias_relu_pool_cl, dim3(grid_for((long long)OH * OW * (C / 4))), dim3(256), 0, s,
+                           (const float4 *)y, (const float4 *)bias, (float4 *)out, C / 4, H, W, OH, OW);
+    } else if ((W & 3) == 0 && ((size_t)y & 15) == 0 && ((size_t)out & 7) == 0) {
+        hipLaunchKernelGGL((k_bias_relu_pool_nchw<true>), dim3(grid_for((long long)C * OH * (OW / 2))), dim3(256), 0, s, y, bias, out,
+                           C, H, W, OH, OW);
+    } else {
+        hipLaunchKernelGGL((k_bias_relu_pool_nchw<false>), dim3(grid_for((long long)C * OH * OW)), dim3(256), 0, s, y, bias, out,
+                           C, H, W, OH, OW);
+    }
     return hipGetLastError() == hipSuccess ? AZ_OK : AZ_ERR_HIP;
 }
 

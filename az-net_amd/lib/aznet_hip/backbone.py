@@ -61,10 +61,10 @@ class VGG16Conv5(object):
         x = torch.as_tensor(blob, dtype=torch.float32, device=self.device)
         if self.cl_compute:
             x = x.contiguous(memory_format=torch.channels_last)
-        # On the GPU, channels_last: what follows a convolution -- bias, ReLU, and the pooling layer where there is one --
+        # On the GPU: what follows a convolution -- bias, ReLU, and the pooling layer where there is one --
         # is ONE pass over its output (az_bias_relu / az_bias_relu_pool, az_epilogue.hip) instead of PyTorch's two or three
         # element-wise launches; same fp32 operations, same bits.  The convolutions are PyTorch-ROCm's either way.
-        fused = self.cl_compute and self.fused_epilogue and x.is_cuda and x.shape[0] == 1
+        fused = self.fused_epilogue and x.is_cuda and x.shape[0] == 1
         skip_pool = False
         for li, layer in enumerate(self.layers):
             if layer is None:
@@ -72,9 +72,10 @@ class VGG16Conv5(object):
                     x = F.max_pool2d(x, kernel_size=2, stride=2, ceil_mode=True)
                 skip_pool = False
                 continue
-            if fused and layer[1].shape[0] % 4 == 0:
+            if fused and (layer[1].shape[0] % 4 == 0 or not self.cl_compute):
                 y = F.conv2d(x, layer[1], None, padding=1)
-                if y.is_contiguous(memory_format=torch.channels_last) and y.data_ptr() % 16 == 0:
+                if (y.is_contiguous(memory_format=torch.channels_last) if self.cl_compute else y.is_contiguous()) \
+                        and y.data_ptr() % 16 == 0:
                     from . import ffi
                     if li + 1 < len(self.layers) and self.layers[li + 1] is None:
                         x = ffi.bias_relu_pool(y, layer[2])

@@ -163,7 +163,7 @@ def load_library(path=None):
     L.az_image_blob_dev.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci]
     L.az_image_blob_dev_on.argtypes = [vp, u8p, ci, ci, fp, cd, vp, ci, ci, vp]
     L.az_bias_relu.argtypes = [vp, vp, vp, ci, ctypes.c_longlong, ci]
-    L.az_bias_relu_pool.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.az_bias_relu_pool.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci]
     for name in SYMBOLS:
         if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream", "az_comm_stream"):
             getattr(L, name).restype = ci
@@ -782,15 +782,18 @@ def bias_relu_(y, bias):
 
 
 def bias_relu_pool(y, bias):
-    """y [1,C,H,W] channels_last CUDA fp32 -> max_pool2d(relu(y + bias), 2, 2, ceil_mode=True) as a new channels_last tensor,
-    one launch on torch's current stream (az_bias_relu_pool)."""
+    """y [1,C,H,W] CUDA fp32 (contiguous or channels_last) -> max_pool2d(relu(y + bias), 2, 2, ceil_mode=True) as a new tensor
+    of the same memory format, one launch on torch's current stream (az_bias_relu_pool)."""
     import torch
     L = load_library()
     C, H, W = int(y.shape[1]), int(y.shape[2]), int(y.shape[3])
+    cl = y.is_contiguous(memory_format=torch.channels_last) and not (y.is_contiguous() and C > 1 and H * W > 1)
+    if not cl and not y.is_contiguous():
+        raise ValueError("bias_relu_pool: the tensor must be contiguous or channels_last")
     out = torch.empty((1, C, (H + 1) // 2, (W + 1) // 2), dtype=torch.float32, device=y.device,
-                      memory_format=torch.channels_last)
+                      memory_format=torch.channels_last if cl else torch.contiguous_format)
     rc = L.az_bias_relu_pool(ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream), ctypes.c_void_p(y.data_ptr()),
-                             ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(out.data_ptr()), C, H, W)
+                             ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(out.data_ptr()), C, H, W, 1 if cl else 0)
     if rc != AZ_OK:
         raise AzError(rc, "az_bias_relu_pool")
     return out

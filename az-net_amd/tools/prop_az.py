@@ -10,6 +10,8 @@ output).  Differences forced by what exists offline:
   --imdb  `voc_<year>_<split>` (needs data/VOCdevkit<year>), `synthetic_<H>x<W>_<N>` or `npy:<dir>`.
   --recall  (extension) also evaluate recall against the imdb's ground truth
           (imdb.evaluate_recall, lib/datasets/imdb.py:120-159) and store it in proposals.pkl.
+  --tune-backbone  (extension) channels_last VGG16 + MIOpen's benchmark search: ~12 % faster convolutions for a shape once it
+          has been searched (seconds, the first time it is seen): for datasets of few image shapes; what bench.py runs.
 With several GPUs: python -m torch.distributed.run --nproc-per-node N tools/prop_az.py ...
 shards the images one rank per GPU and gathers the proposals on every rank (RCCL)."""
 import _init_paths  # noqa: F401
@@ -29,10 +31,16 @@ FLAGS = [
 ]
 
 
-def load_net(spec, device):
+def load_net(spec, device, tuned=False):
     from aznet_hip import synth
     from aznet_hip.net import HipAZNet
-    from aznet_hip.backbone import VGG16Conv5
+    from aznet_hip.backbone import VGG16Conv5 as _VGG
+    if tuned:
+        import torch
+        torch.backends.cudnn.benchmark = True          # (before the first forward: MIOpen's search per convolution shape)
+
+    def VGG16Conv5(**kw):
+        return _VGG(channels_last_compute=bool(tuned), channels_last_out=bool(tuned), **kw)
     if spec.startswith('synthetic'):
         seed = int(spec.split(':')[1]) if ':' in spec else 1234
         head = synth.make_head(seed=seed, **synth.FULL_DIMS)
@@ -66,7 +74,7 @@ def main():
     from datasets.factory import get_imdb
     from detect.config import get_output_dir
     from detect.test import test_proposals, im_propose, _propose_start, _propose_finish, _prefetched, _can_queue
-    net = load_net(args.caffemodel, device)
+    net = load_net(args.caffemodel, device, tuned=bool(getattr(args, "tune_backbone", False)))
     nets = {"full": net, "fc": net}
     imdb = get_imdb(args.imdb_name)
 

@@ -29,7 +29,7 @@ def main():
     from prop_az import load_net
     from datasets.factory import get_imdb
     from detect.tune import tune_thresh
-    net = load_net(args.caffemodel, device)
+    net = load_net(args.caffemodel, device, tuned=bool(getattr(args, "tune_backbone", False)))
     nets = {"full": net, "fc": net}
     imdb = get_imdb(args.imdb_name)
     if world == 1:

@@ -49,7 +49,7 @@ def main():
     from aznet_hip.net import HipDetNet
     from datasets.factory import get_imdb
     from detect.test import test_net_shared
-    az_net = load_net(args.caffemodel_az, args.gpu_id)
+    az_net = load_net(args.caffemodel_az, args.gpu_id, tuned=bool(getattr(args, "tune_backbone", False)))
     det_head, det_name = load_det_head(args.caffemodel_frcnn)
     imdb = get_imdb(args.imdb_name)
     if hasattr(imdb, "competition_mode"):

@@ -993,7 +993,9 @@ def main():
                               "synthetic_600x1000_64: image from the imdb (read ahead by a worker thread), PCIe upload + "
                               "front-end kernel + VGG16 + search enqueued one image ahead of the GPU, boxes to the host, the "
                               "reference's per-image print lines.  vs_end_to_end = end_to_end.from_host_image_ms over this "
-                              "(> 1: the harness loop is faster than the one-image-at-a-time sequence timed there)"}
+                              "(> 1: the harness loop is faster than the one-image-at-a-time sequence timed there).  The backbone "
+                              "is this run's (channels_last + MIOpen's benchmark search: tools/prop_az.py --tune-backbone; the "
+                              "tool's default backbone layout is ~0.45 ms per image slower)"}
         net.set_conv(conv)
     # what this box holds under the matrix pipe and through HBM (register-only MFMA loop, float4 copy);
     # measured LAST: 40 ms of a saturated matrix pipe and HBM leave the chip ~8 % slower for the next tens of ms

@@ -341,10 +341,11 @@ int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const flo
  * 16-byte aligned), else [C][hw].  PyTorch's own bias add and ReLU are two element-wise launches over the same bytes;
  * same fp32 operations, same bits. */
 int az_bias_relu(void *stream, float *y, const float *bias, int C, long long hw, int channels_last);
-/* The same followed by the 2x2 / 2 max-pool: y [H][W][C] (channel-last, C % 4 == 0) -> out [ceil(H/2)][ceil(W/2)][C]; the
- * last window row / column is clipped by the map's edge (ceil mode).  out = max over the window of max(y + bias, 0),
- * computed as max(max(y) + bias, 0): the same bits (rounding is monotonic). */
-int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W);
+/* The same followed by the 2x2 / 2 max-pool: y [H][W][C] (channels_last != 0: C % 4 == 0, 16-byte aligned) or [C][H][W]
+ * -> out [ceil(H/2)][ceil(W/2)][C] / [C][ceil(H/2)][ceil(W/2)]; the last window row / column is clipped by the map's edge
+ * (ceil mode).  out = max over the window of max(y + bias, 0), computed as max(max(y) + bias, 0): the same bits (rounding
+ * is monotonic). */
+int az_bias_relu_pool(void *stream, const float *y, const float *bias, float *out, int C, int H, int W, int channels_last);
 
 /* ---- measurement ------------------------------------------------------------------ */
 /* HIP-event timing (events on the ctx stream) of the launches made by az_propose /
