@@ -340,10 +340,27 @@ def test_net_shared(sc_net, frcnn_net, imdb):
     if not os.path.exists(output_dir):
         os.makedirs(output_dir)
     _t = {'im_detect': Timer(), 'misc': Timer()}
+    # Images are read ahead by a worker thread, and (fixed proposal count, a backbone on the GPU) image i+1's upload +
+    # front-end + backbone + search are enqueued as soon as image i's detections are on the host: the GPU works on image
+    # i+1 while Python does image i's per-class bookkeeping below.  Same calls per image, same printed lines in the same
+    # order; the reference's loop (test.py:690-737) waits for each image before it reads the next.
+    images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
+    queued = _can_queue(hnet) and num_images > 0
+    pend, im = None, None
+    if queued:
+        im = next(images)
+        pend = _propose_start(sc_net, im)
     for i in range(num_images):
-        im = imdb.image_at(i) if hasattr(imdb, "image_at") else np.load(imdb.image_path_at(i))
         _t['im_detect'].tic()
-        scores, boxes = im_detect_shared(sc_net, frcnn_net, im, num_classes)
+        if queued:
+            prop, conv = _propose_finish(sc_net, pend, return_conv=True)
+            scores, boxes, _ = _frcnn_forward(frcnn_net, im, prop, num_classes, conv)
+            if i + 1 < num_images:
+                im = next(images)
+                pend = _propose_start(sc_net, im)
+        else:
+            im = next(images)
+            scores, boxes = im_detect_shared(sc_net, frcnn_net, im, num_classes)
         num_boxes += scores.shape[0]
         _t['im_detect'].toc()
         _t['misc'].tic()

@@ -144,20 +144,22 @@ def test_test_net_shared_matches_the_reference_run(rig, mods):
     from detect import test as T
     n = int(g["n_img"])
     # per-image results of the path itself, recorded while the harness runs
+    # (at the Fast R-CNN head's forward: the dataset loop enqueues image i+1 before image i's bookkeeping and does not go
+    #  through im_detect_shared)
     rec = []
-    inner = T.im_detect_shared
+    inner = T._frcnn_forward
 
-    def recording(a, f, im, k):
-        s, b = inner(a, f, im, k)
+    def recording(*a, **kw):
+        s, b, c = inner(*a, **kw)
         rec.append((s.copy(), b.copy()))
-        return s, b
-    T.im_detect_shared = recording
+        return s, b, c
+    T._frcnn_forward = recording
     try:
         buf = io.StringIO()
         with redirect_stdout(buf):
             nms_dets = T.test_net_shared({"full": net, "fc": net}, {"fc": dnet}, imdb)
     finally:
-        T.im_detect_shared = inner
+        T._frcnn_forward = inner
     assert scrub(buf.getvalue()) == str(g["det_stdout"])
     det_file = os.path.join(C.get_output_dir(imdb, net), "detections.pkl")
     assert os.path.relpath(det_file, C.cfg.ROOT_DIR) == str(g["det_relpath"]).replace("/harness/", "/harness_test/")
