@@ -64,8 +64,12 @@ def tune_thresh(net, imdb, gather=None):
     mine = getattr(imdb, "shard", None) or range(num_images)
     ctx = hnet.ctx
     ctx.tune_begin(max(1, len(mine)) * 2 * ctx.max_regions)
+    # (images read ahead by a worker thread, as in detect.test.test_proposals: reading / decoding an image takes about as long
+    #  as the GPU needs for one)
+    from detect.test import _prefetched
+    images = _prefetched(imdb, list(mine), depth=int(cfg.TEST.get("PREFETCH", 2)))
     for n, i in enumerate(mine):
-        im = imdb.image_at(i)
+        im = next(images)
         _t['im_prop'].tic()
         _search(hnet, im)
         _t['im_prop'].toc()
