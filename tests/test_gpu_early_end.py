@@ -74,3 +74,44 @@ def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, sc
     assert s4.n_reruns == 0
     s5 = run(lo, maps[1])
     assert s5.n_reruns == 0
+
+
+@pytest.mark.parametrize("lanes,depth", [(1, 2), (2, 3), (2, 4)])
+def test_an_early_end_that_misses_is_run_again_inside_a_full_queue(mods, lanes, depth):
+    """The same with searches queued ahead (az_propose_launch x depth before the first fetch): the rerun of a search whose tree
+    went deeper than the cut happens inside az_propose_fetch with other searches queued behind it, on one lane and on two."""
+    ffi, synth, HipAZNet = mods
+    H, W, scale = 600, 1000, 1.0
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="early_end_q")
+    ref = HipAZNet(head, name="early_end_q_ref")
+    net.ctx.set_lanes(lanes)
+    C = synth.SMALL_DIMS["C"]
+    maps = [synth.make_feature_map(60 + i, C, 38, 63) for i in range(4)]
+    import torch
+    tmaps = [torch.from_numpy(m).cuda().contiguous(memory_format=torch.channels_last) for m in maps]
+    B1 = ref.ctx.divide_region(np.array([[0.0, 0.0, W - 1.0, H - 1.0]]), 10.0)
+    zmax = 0.0
+    for m in maps:
+        ref.set_conv(m)
+        z, _, _ = ref.ctx.head_forward(np.hstack([np.zeros((len(B1), 1)), B1 * scale]).astype(np.float32))
+        zmax = max(zmax, float(z.max()))
+    hi = 0.5 * (zmax + 1.0)
+    # sparse x 3 (history: the tree ends after its second level), then dense, sparse, dense, dense, sparse ...
+    seq = [hi, hi, hi, 0.0, hi, 0.0, 0.0, hi, hi, 0.0, hi, hi]
+    prm = [ffi.AzContext.make_params(H, W, scale, t, static_tree=False, full_spec=False) for t in seq]
+    want = []
+    for i, t in enumerate(seq):
+        ref.set_conv(maps[i % 4])
+        want.append(ref.propose(_plain(ffi, H, W, scale, t), want_scores=True))
+    got, reruns, launched = [], 0, 0
+    for i in range(len(seq)):
+        while launched < min(len(seq), i + depth):
+            net.ctx.propose_launch(prm[launched], fmap=tmaps[launched % 4], producer_done=True)
+            launched += 1
+        Y, S, st = net.ctx.propose_fetch(want_scores=True, want_stats=True)
+        got.append((Y, S))
+        reruns += int(st.n_reruns)
+    for i, ((Y, S), (Yr, Sr)) in enumerate(zip(got, want)):
+        assert np.array_equal(Y, Yr) and np.array_equal(S, Sr), i
+    assert reruns >= 1                                    # (the first dense search behind the sparse ones)
