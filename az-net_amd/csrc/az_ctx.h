@@ -244,8 +244,11 @@ struct az_ctx {
     // Early end: a tree whose previous search of the shape had no regions from some level on is enqueued only up to that
     // level (the passes and geometry kernels of an empty level cost ~35 us each, a fifth of a sparse search); the last
     // geometry kernel checks -- regions after all set err bit 1024 and az_propose_fetch runs the search again in full
-    // (params.reserved bit 12 / AZ_EARLY_END=0: never).  cut_block: searches left before the next attempt after a miss.
-    int last_cut = 0, cut_block = 0, cut_env = -1;
+    // (params.reserved bit 12 / AZ_EARLY_END=0: never).  A miss costs more than a hit saves (a second search against two
+    // empty levels), so the cut is taken only when the context's last FOUR level-loop searches all ended at or before the
+    // level in question: early_hist holds the first empty level of the last eight (4 bits each, 15 = none).
+    int last_cut = 0, cut_env = -1;
+    unsigned early_hist = 0xFFFFFFFFu;
     // head passes of the search being enqueued / last launched: where each one's row count lives
     // (>= 0: int index into AzCounts; < 0: -(rows + 1), a count the host knows)
     int npass = 0;

@@ -169,13 +169,16 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     // to: the one before it carries the check)
     q.cut = 0;
     if (c->cut_env < 0) { const char *e = getenv("AZ_EARLY_END"); c->cut_env = (e && !atoi(e)) ? 0 : 1; }
-    if (c->cut_env && !(p->reserved & 4096) && !q.full && !tune && q.fused && q.fused_lv && c->cut_block == 0 &&
+    if (c->cut_env && !(p->reserved & 4096) && !q.full && !tune && q.fused && q.fused_lv &&
         c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev) {
         // (a tree that ended before its third level: the speculative pass then evaluates the root and its children only)
         for (int l = (q.n_spec == 3 ? 2 : q.n_spec); l < nlev; ++l)
             if (c->hint_P[l] == 0) { q.cut = l; break; }
         if (q.cut > q.n_spec && q.cut - 1 >= q.lv_limit) q.cut = 0;      // (the level before it runs on the multi-launch kernels)
         if (q.cut && q.cut < q.n_spec && q.defer_root) q.cut = 0;         // (cannot be: a deferred root needs level 4 to exist)
+        // ... and the last four searches of the context all ended there or earlier (az_ctx.h: early_hist)
+        for (int i = 0; i < 4 && q.cut; ++i)
+            if ((int)((c->early_hist >> (4 * i)) & 15u) > q.cut) q.cut = 0;
     }
     return q;
 }
@@ -921,7 +924,6 @@ int launch_impl(az_ctx *c, const az_params *p)
     q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
     q.full = c->last_full;
     q.cut = c->last_cut;
-    if (c->cut_block > 0) --c->cut_block;
     q.npass = c->npass;
     q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
     q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
@@ -1040,8 +1042,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
     }
     if ((h.err & 1024) && q.cut) {
         // the search was enqueued up to level q.cut only (the previous search of the shape ended there) and this tree goes
-        // on: run it in full, and leave the next searches alone for a while
-        c->cut_block = 16;
+        // on: run it in full (its result enters the history below as a search that did not end early)
         az_params p2 = q.p;
         p2.reserved |= 4096;
         return rerun(p2);
@@ -1096,6 +1097,10 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         }
         c->hint_h = q.p.im_h; c->hint_w = q.p.im_w; c->hint_nlev = nlev;
         hint_store(c);
+        int first_empty = 15;
+        for (int l = 1; l < nlev && l < 15; ++l)
+            if (h.P[l] == 0) { first_empty = l; break; }
+        c->early_hist = (c->early_hist << 4) | (unsigned)first_empty;
     }
     const int n = h.nsel;
     // (the candidate list stays readable only while no later search has been queued: it would be overwriting it)

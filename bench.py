@@ -465,6 +465,8 @@ def main():
                 rows = spec_rows if l < 0 else uniq[l] + (1 if (st.root_deferred and l == 3) else 0)
                 label = "speculative 1-3" if l < 0 else l + 1
             t_us = float(np.mean(v)) * 1e3
+            if not t_us > 0:                 # (a launch that found no rows -- an empty level -- records no span)
+                continue
             fl = rows * 2.0 * 25088 * 4096
             tmin = max(25088 * 4096 * 4 / HBM_PEAK, fl / (PEAK_F32_MFMA_TFLOPS * 1e12)) * 1e6
             fc6_shapes.append({"level": label, "rows": int(rows), "avg_us": t_us,
@@ -481,6 +483,8 @@ def main():
         kernel_table = []
         for (n, l), v in sorted(ktab.items(), key=lambda kv: (kv[0][1], kv[0][0])):
             us = float(np.mean(v)) * 1e3
+            if not us > 0:                   # (as above: launches of an empty level)
+                continue
             rows = pass_rows_now[pass_levels.index(l)] if (l in pass_levels and pass_levels.index(l) < len(pass_rows_now)) else None
             ent = {"kernel": n, "first_level": ("2" if l < 0 else str(l + 1)), "avg_us": us}
             if rows is not None and not st.static_plan:
@@ -863,7 +867,7 @@ def main():
                         launched += 1
                     cnt_r[0] += int(net.ctx.propose_fetch(want_stats=True)[1].n_reruns)
             gc.collect(); gc.disable()
-            fq(5)
+            fq(12)                                       # (both lanes' histories: a form may need several searches of a kind)
             cnt_r[0] = 0
             barrier()
             t = time.perf_counter()
@@ -891,7 +895,7 @@ def main():
             out["tz_sweep"] = {"points": pts,
                                "note": "convs[0]'s image, Tz at quantiles of the zoom scores of ALL regions of its full tree (untrained "
                                        "weights: the scores drift with region size, so a quantile can empty the deep levels). Each "
-                                       "point: 3 untimed searches (the context's history of the shape becomes this tree), then "
+                                       "point: 3 + 12 untimed searches (the context's history -- both lanes' -- becomes this tree), then "
                                        "timed_images searches, queue-ahead, one image at a time.  path_floor = BASELINE.md section "
                                        "3's per-level floor for THIS tree (every level one weight stream at 8 TB/s or its flops at "
                                        "157.3 TF): a tree of a few dozen rois per level is five 54.6 us weight streams there, "

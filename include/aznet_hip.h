@@ -82,10 +82,10 @@ typedef struct {
                                  repeated level by level; otherwise the closure rows, which hold every region any
                                  pruning can produce; same bits in all three);
                                  bit 10: with bit 9, the closure rows instead of the full tree's;
-                                 bit 12: no early end (by default a search whose context's previous search of the image
-                                 shape had no regions from some level on is enqueued only up to that level -- an empty
-                                 level still costs its launches, ~35 us -- and is run again in full if this tree goes on;
-                                 same bits)                                                                         */
+                                 bit 12: no early end (by default, when the context's previous search of the image shape
+                                 had no regions from some level on AND its last four searches all ended there or earlier,
+                                 a search is enqueued only up to that level -- an empty level still costs its launches,
+                                 ~35 us -- and is run again in full if this tree goes on; same bits)                 */
 } az_params;
 
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */

@@ -58,10 +58,12 @@ def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, sc
         assert np.array_equal(Ya, Yb) and np.array_equal(Sa, Sb)
         return st
 
-    s1 = run(hi, maps[0])                                # no history of this shape yet: every level enqueued
+    s1 = run(hi, maps[0])                                # no history yet: every level enqueued
     assert list(s1.level_regions[:2]) == [1, len(B1)] and sum(s1.level_regions[2:s1.n_levels]) == 0 and s1.n_reruns == 0
-    s2 = run(hi, maps[1])                                # the previous search ended at level 2: this one is cut there
-    assert s2.n_reruns == 0 and s2.n_passes <= s1.n_passes
+    for k in range(3):                                   # four searches in a row that ended after their second level ...
+        assert run(hi, maps[(k + 1) % 3]).n_reruns == 0
+    s2 = run(hi, maps[1])                                # ... so this one is enqueued only that far
+    assert s2.n_reruns == 0 and s2.n_passes == 1 and list(s2.pass_rows[:1]) == [1 + len(B1)]
     # the same with a data-dependent proposal count (cfg.SEAR.FIXED_PROPOSAL_NUM = False: everything with score >= Tc)
     net.set_conv(maps[0]); ref.set_conv(maps[0])
     Yt, St = net.propose(ffi.AzContext.make_params(H, W, scale, hi, static_tree=False, full_spec=False, fixed_num=False, Tc=0.3),
@@ -70,10 +72,12 @@ def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, sc
     assert np.array_equal(Yt, Yq) and np.array_equal(St, Sq)
     s3 = run(lo, maps[2])                                # a full tree behind a sparse one: cut, missed, run again
     assert s3.n_reruns == 1 and sum(s3.level_regions[2:s3.n_levels]) > 0
-    s4 = run(hi, maps[0])                                # (blocked for a while after a miss: no cut, no rerun)
+    s4 = run(hi, maps[0])                                # (a search that went on is in the history now: no cut, no rerun)
     assert s4.n_reruns == 0
     s5 = run(lo, maps[1])
     assert s5.n_reruns == 0
+    for k in range(4):                                   # alternating sparse / dense images are never cut: nothing is run twice
+        assert run(hi if k % 2 == 0 else lo, maps[k % 3]).n_reruns == 0
 
 
 @pytest.mark.parametrize("lanes,depth", [(1, 2), (2, 3), (2, 4)])
@@ -97,8 +101,8 @@ def test_an_early_end_that_misses_is_run_again_inside_a_full_queue(mods, lanes, 
         z, _, _ = ref.ctx.head_forward(np.hstack([np.zeros((len(B1), 1)), B1 * scale]).astype(np.float32))
         zmax = max(zmax, float(z.max()))
     hi = 0.5 * (zmax + 1.0)
-    # sparse x 3 (history: the tree ends after its second level), then dense, sparse, dense, dense, sparse ...
-    seq = [hi, hi, hi, 0.0, hi, 0.0, 0.0, hi, hi, 0.0, hi, hi]
+    # a run of sparse trees (each lane's last four end after their second level: cut), a dense one (missed, run again), a mix
+    seq = [hi] * 10 + [0.0, hi, 0.0, 0.0] + [hi] * 10 + [0.0, hi]
     prm = [ffi.AzContext.make_params(H, W, scale, t, static_tree=False, full_spec=False) for t in seq]
     want = []
     for i, t in enumerate(seq):
