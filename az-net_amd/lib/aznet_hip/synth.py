@@ -46,6 +46,53 @@ def make_image(seed, height=600, width=1000):
     return np.random.RandomState(seed).randint(0, 256, size=(height, width, 3)).astype(np.uint8)
 
 
+def make_scene_image(seed, height=600, width=1000):
+    """uint8 BGR image with STRUCTURE that differs from seed to seed: a flat or softly shaded background carrying 0..7
+    textured rectangles ("objects") of random size, contrast and position.  make_image's uniform noise gives every image the
+    same statistics everywhere, hence trees of the same density at a given Tz; a dataset does not -- some images are nearly
+    empty, some are crowded, and the zoom tree follows the content.  Used where a STREAM of distinct images is the point
+    (bench.py: stream_tz, tests/test_gpu_stream.py)."""
+    rng = np.random.RandomState(50_000 + seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float32)
+    base = rng.uniform(40, 200, 3).astype(np.float32)
+    gx, gy = rng.uniform(-0.08, 0.08, 2)
+    im = base[None, None, :] + (gx * (xx - width / 2) + gy * (yy - height / 2))[:, :, None]
+    im += rng.normal(0, rng.uniform(1, 12), (height, width, 1)).astype(np.float32)
+    n_obj = int(rng.choice([0, 0, 1, 1, 2, 3, 4, 5, 7]))
+    for _ in range(n_obj):
+        w = int(rng.uniform(0.04, 0.6) * width)
+        h = int(rng.uniform(0.04, 0.6) * height)
+        x0 = int(rng.uniform(0, width - w))
+        y0 = int(rng.uniform(0, height - h))
+        col = rng.uniform(0, 255, 3).astype(np.float32)
+        period = rng.uniform(3, 40)
+        ang = rng.uniform(0, np.pi)
+        tex = np.sin((np.cos(ang) * xx[y0:y0 + h, x0:x0 + w] + np.sin(ang) * yy[y0:y0 + h, x0:x0 + w]) * (2 * np.pi / period))
+        amp = rng.uniform(10, 110)
+        im[y0:y0 + h, x0:x0 + w, :] = col[None, None, :] + amp * tex[:, :, None] + \
+            rng.normal(0, rng.uniform(0, 25), (h, w, 3)).astype(np.float32)
+    return np.clip(np.rint(im), 0, 255).astype(np.uint8)
+
+
+def make_scene_map(seed, C, H, W):
+    """A conv5_3 stand-in whose content differs from seed to seed the way make_scene_image's does (tests without a backbone):
+    post-ReLU noise whose gain varies over 0..6 rectangular patches on a weak background, so that some maps drive deep trees
+    and others end after a level or two at the same Tz."""
+    rng = np.random.Generator(np.random.PCG64(70_000 + seed))
+    a = rng.standard_normal((1, C, H, W), dtype=np.float32)
+    gain = np.full((H, W), rng.uniform(0.15, 1.0), dtype=np.float32)
+    for _ in range(int(rng.integers(0, 7))):
+        h = int(rng.integers(2, max(3, H // 2)))
+        w = int(rng.integers(2, max(3, W // 2)))
+        y0 = int(rng.integers(0, H - h + 1))
+        x0 = int(rng.integers(0, W - w + 1))
+        gain[y0:y0 + h, x0:x0 + w] = rng.uniform(0.3, 2.5)
+    a *= gain[None, None, :, :]
+    a += rng.uniform(-0.6, 0.3)
+    np.maximum(a, 0, out=a)
+    return a
+
+
 def conv_out_size(n):
     """Spatial size after VGG16's four ceil-mode 2x2/2 max-pools
     (models/Pascal/VGG16/az-net/test.prototxt:16-384)."""

@@ -146,6 +146,57 @@ def test_topk_vs_numpy(small):
         assert np.array_equal(idx, ref), (n, k)
 
 
+def test_roi_dedup_golden_g3(small):
+    """az_roi_dedup against index / inv_index recorded from the reference's own np.unique inside _az_forward
+    (test.py:212-218; tests/golden/g3_roi_dedup.npz: scales 1.0 / 1.6 / 0.9375, chunked levels)."""
+    ctx = small[0].ctx
+    g = load("g3_roi_dedup.npz")
+    by_level = {}
+    for i in range(int(g["ncases"])):
+        boxes, scale = g["c%d_boxes" % i], float(g["c%d_scale" % i])
+        rois, index, inv = ctx.roi_dedup(boxes, scale, 1. / 16., 10000)
+        assert np.array_equal(index, g["c%d_index" % i]) and np.array_equal(inv, g["c%d_inv_index" % i]), i
+        v = np.array([1, 1e3, 1e6, 1e9, 1e12])
+        assert np.array_equal(np.round(rois * np.float32(1. / 16.)).dot(v), g["c%d_hashes" % i])
+        by_level.setdefault((int(g["c%d_H" % i]), int(g["c%d_W" % i]), int(g["c%d_batch" % i])), []).append(i)
+    # the chunked cases once more as ONE call with BATCH_SIZE 100: the library chunks as test.py:195-205 does
+    for (H, W, batch), ids in by_level.items():
+        if batch != 100:
+            continue
+        big = [i for i in ids if g["c%d_boxes" % i].shape[0] == 100 or i == ids[-1]][-4:]
+        boxes = np.vstack([g["c%d_boxes" % i] for i in big])
+        rois, index, inv = ctx.roi_dedup(boxes, float(g["c%d_scale" % big[0]]), 1. / 16., 100)
+        ref_index, ref_inv, off, s = [], [], 0, 0
+        for i in big:
+            ref_index.append(g["c%d_index" % i] + s)
+            ref_inv.append(g["c%d_inv_index" % i] + off)
+            off += g["c%d_index" % i].shape[0]
+            s += g["c%d_boxes" % i].shape[0]
+        assert np.array_equal(index, np.concatenate(ref_index)) and np.array_equal(inv, np.concatenate(ref_inv))
+
+
+def test_topk_golden_g8(small):
+    """az_topk against the reference's own `np.argsort(-aScores)` of whole im_propose runs (test.py:397-401;
+    tests/golden/g8_topk.npz).  NumPy's order inside a tie is unspecified: the score sequence must agree, the index set
+    above the last selected score must agree, and where ties are duplicates of one RoI (identical boxes) the selected BOXES
+    must agree."""
+    ctx = small[0].ctx
+    g = load("g8_topk.npz")
+    for tag in [str(t) for t in g["runs"]]:
+        neg, indA, Yall, Y = g[tag + "_neg_scores"], g[tag + "_indA"], g[tag + "_Y_all"], g[tag + "_Y"]
+        k = int(g[tag + "_num_proposals"])
+        sc = (-neg).astype(np.float32)
+        assert np.array_equal(sc.astype(np.float64), -neg)               # (aScores hold f32 values, test.py:381)
+        idx = ctx.topk(sc, k)
+        n = min(k, sc.shape[0])
+        assert idx.shape == (n,)
+        assert np.array_equal(neg[idx], neg[indA[:n]]), tag
+        cut = neg[indA[n - 1]]
+        assert set(idx[neg[idx] < cut].tolist()) == set(indA[:n][neg[indA[:n]] < cut].tolist()), tag
+        if tag in ("distinct", "short"):
+            assert np.array_equal(Yall[idx], Y), tag
+
+
 # ---------------------------------------------------------------- head
 def _rand_rois(rng, n, W, H):
     x1 = rng.uniform(0, W - 20, n)

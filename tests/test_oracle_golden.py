@@ -229,3 +229,38 @@ def test_net_shared_bookkeeping_and_apply_nms_golden():
     assert sorted(str(k) for k in g["prop_keys"]) == ["boxes", "recall", "time"] and int(g["prop_recall"]) == 0
     assert str(g["prop_relpath"]) == "output/harness/stub_2img/az_small/proposals.pkl"
     assert str(g["det_relpath"]) == "output/harness/stub_2img/az_small/detections.pkl"
+
+
+# ---- G3 / G8: the two inline computations of lib/detect/test.py, recorded from the reference itself -------------
+def test_roi_dedup_reproduces_the_reference_np_unique():
+    """g3: index / inv_index as the reference's own `np.unique(hashes, return_index, return_inverse)` (test.py:212-218)
+    produced them inside _az_forward, for every level of three trees (scales 1.0, 1.6, 0.9375) and BATCH_SIZE chunks."""
+    g = load("g3_roi_dedup.npz")
+    scales = set()
+    for i in range(int(g["ncases"])):
+        boxes, scale = g["c%d_boxes" % i], float(g["c%d_scale" % i])
+        scales.add(scale)
+        rois = orc.get_rois_blob(boxes, scale)
+        index, inv = orc.roi_dedup(rois)
+        assert np.array_equal(index, g["c%d_index" % i]) and np.array_equal(inv, g["c%d_inv_index" % i]), i
+        # the hash itself (f32 round-half-even of rois / 16, exact integers in f64)
+        v = np.array([1, 1e3, 1e6, 1e9, 1e12])
+        assert np.array_equal(np.round(rois * (1. / 16.)).dot(v), g["c%d_hashes" % i])
+    assert scales == {1.0, 1.6, 0.9375}
+
+
+def test_top_k_reproduces_the_reference_argsort():
+    """g8: `np.argsort(-aScores)` of whole im_propose runs (test.py:397-401), distinct and heavily tied scores.  The oracle's
+    selection is the same call on the same array; with ties the ORDER inside a tie is NumPy's (unstable sort), so what must
+    agree is the score sequence and, above the last selected score, the index set."""
+    g = load("g8_topk.npz")
+    for tag in [str(t) for t in g["runs"]]:
+        neg, indA, Yall, Y = g[tag + "_neg_scores"], g[tag + "_indA"], g[tag + "_Y_all"], g[tag + "_Y"]
+        k = int(g[tag + "_num_proposals"])
+        Yo, ind = orc.top_k(Yall, -neg, k)
+        n = min(k, Yall.shape[0])
+        assert Yo.shape == Y.shape == (n, 4)
+        assert np.array_equal(neg[ind], neg[indA[:n]])                      # same scores in the same order
+        cut = neg[indA[n - 1]]
+        assert set(ind[neg[ind] < cut]) == set(indA[:n][neg[indA[:n]] < cut])
+        assert np.array_equal(Yall[indA[:n]], Y)
