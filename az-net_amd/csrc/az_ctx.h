@@ -123,7 +123,18 @@ struct az_ctx {
     int hint_h = -1, hint_w = -1, hint_nlev = 0;
     // ... kept per image shape (a dataset mixes a few dozen shapes: each keeps the history of ITS last search; the fields
     // above are the entry of the shape being launched / last fetched)
+    // (round 5) A dataset is a stream of DIFFERENT images: the tree of the previous image is one sample of what the next one
+    // looks like, not a prediction of it.  Each shape keeps its last HINT_K level-loop searches (newest = the hint_* fields
+    // above, then hint_old[0..]); the choices that cost little when wrong and gain little when right are made on the
+    // EXPECTED cost over those (pair_plan, full_prepare), the ones that cost a second search when wrong need a streak
+    // (tree rows of the whole-tree pass: the last two searches of the shape both walked the full tree).
+    static constexpr int HINT_K = 4;
+    struct HintRec { int rows[AZ_MAX_LEVELS], P[AZ_MAX_LEVELS], PZ[AZ_MAX_LEVELS], U[AZ_MAX_LEVELS], SPN[AZ_MAX_LEVELS]; };
+    HintRec hint_old[HINT_K - 1];
+    int hint_n = 0;                           // records held for the shape in the working fields (0: none, 1: hint_* only, ...)
+    int hint_full_streak = 0;                 // consecutive searches of the shape, up to the last, that walked the FULL tree
     struct ShapeHint { int h, w, nlev; int rows[AZ_MAX_LEVELS], P[AZ_MAX_LEVELS], PZ[AZ_MAX_LEVELS], U[AZ_MAX_LEVELS], SPN[AZ_MAX_LEVELS];
+                       HintRec old[HINT_K - 1]; int n, full_streak;
                        unsigned long long use; };
     std::vector<ShapeHint> hints;
     unsigned long long hint_clock = 0;
@@ -214,6 +225,7 @@ struct az_ctx {
         int nlev = 0, is_static = 0, defer = 0, pair_mask = 0, npass = 0, full = 0, reruns = 0;
         int cut = 0;                        // > 0: the search was enqueued up to (not including) this level
         int pass_src[AZ_MAX_LEVELS + 2] = {0};
+        int pass_lv[AZ_MAX_LEVELS + 2] = {0};   // the `level` each head pass was launched for (-1: speculative / whole-tree / one-pass)
         void *stage_dst = nullptr;          // az_propose_stage_result_dev target
         size_t stage_cap = 0;
         int slot = 0;
@@ -237,7 +249,7 @@ struct az_ctx {
     std::vector<LvLimit> lv_limits;
     int defer_root_env = -1;            // AZ_DEFER_ROOT=0: keep the root's row in the speculative pass (measurements)
     int level_fused_env = -1;           // AZ_LEVEL_FUSED=0: keep levels >= 4 as separate launches (measurements)
-    struct GraphEntry { hipGraphExec_t exec; int npass; int pass_src[AZ_MAX_LEVELS + 2]; };
+    struct GraphEntry { hipGraphExec_t exec; int npass; int pass_src[AZ_MAX_LEVELS + 2]; int pass_lv[AZ_MAX_LEVELS + 2]; };
     std::map<std::string, GraphEntry> graphs;        // captured launch sequences (az_set_graphs)
     int use_graphs = -1;                             // -1: take the AZ_GRAPH environment variable
     int last_defer = 0;
@@ -249,10 +261,12 @@ struct az_ctx {
     // level in question: early_hist holds the first empty level of the last eight (4 bits each, 15 = none).
     int last_cut = 0, cut_env = -1;
     unsigned early_hist = 0xFFFFFFFFu;
+    int n_hist = 0;                     // level-loop searches this context has recorded in early_hist (saturating)
     // head passes of the search being enqueued / last launched: where each one's row count lives
     // (>= 0: int index into AzCounts; < 0: -(rows + 1), a count the host knows)
     int npass = 0;
     int pass_src[AZ_MAX_LEVELS + 2] = {0};
+    int pass_lv[AZ_MAX_LEVELS + 2] = {0};
     int his_n = 0;                      // rows of the anchor history of the last fetched tuner search
     int cand_n = -1;                    // candidates of the last fetched search still in Yall/Sall (-1: overwritten)
     // profiling
@@ -445,6 +459,7 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     if (c->npass < AZ_MAX_LEVELS + 2) {
         const int *c0 = reinterpret_cast<const int *>(c->cnt);
         const bool in_cnt = Uptr >= c0 && Uptr < c0 + sizeof(AzCounts) / sizeof(int);
+        c->pass_lv[c->npass] = level;
         c->pass_src[c->npass++] = in_cnt ? (int)(Uptr - c0) : -(rows_hint > 0 ? rows_hint : 0) - 1;
     }
     if (c->gemm12_env < 0) {            // AZ_GEMM12_MIN=<rows> (0: never): measurements

@@ -108,6 +108,25 @@ static int calibrate_passes(az_ctx *c)
 // the previous search of this context on the same image shape (what a dataset run looks like); without history
 // nothing is speculated.  params.reserved bit 6 / AZ_PAIR_SPEC=0: never; bit 7 / AZ_PAIR_SPEC=2: at every eligible
 // level (tests).  Results are bit-identical either way.
+// The records of the shape's history: r = 0 the last search (the hint_* fields), r = 1.. the ones before it.
+struct HintView { const int *rows, *P, *PZ, *U, *SPN; };
+static HintView hint_rec(const az_ctx *c, int r)
+{
+    if (r == 0) return {c->hint_rows, c->hint_P, c->hint_PZ, c->hint_U, c->hint_SPN};
+    const auto &o = c->hint_old[r - 1];
+    return {o.rows, o.P, o.PZ, o.U, o.SPN};
+}
+constexpr double EMPTY_LEVEL_US = 35.0;    // an enqueued level whose row count turns out to be zero: five launches + a geometry kernel that leave at once
+
+// rows a pair-speculating pass of level l carries for level l+1, for one recorded tree: what it carried then, else level l+1's
+// unique rois scaled by parents / zoomed parents, else (the tree ended at level l) ~4.5 windows per region
+static double pair_rows(const HintView &v, int l)
+{
+    if (v.SPN[l] >= 0) return (double)v.SPN[l];
+    if (v.U[l + 1] > 0) return (double)v.U[l + 1] * v.P[l] / (v.PZ[l] > 0 ? v.PZ[l] : 1);
+    return 4.5 * v.P[l];
+}
+
 static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool fused_lv, int lv_limit)
 {
     if (c->pair_env < 0) { const char *e = getenv("AZ_PAIR_SPEC"); c->pair_env = e ? atoi(e) : 1; }
@@ -115,17 +134,26 @@ static int pair_plan(az_ctx *c, const az_params *p, int nlev, int n_spec, bool f
     for (const auto &hw : c->nopair)
         if (hw.first == p->im_h && hw.second == p->im_w) return 0;
     const bool force = (p->reserved & 128) || c->pair_env == 2;
-    const bool hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
+    const bool hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev && c->hint_n > 0;
     int mask = 0;
     for (int l = n_spec; l + 1 < nlev && l < lv_limit; ++l) {      // (the lookup runs in level l's fused geometry kernel)
         bool want = force;
-        if (!want && hist && c->hint_P[l] > 0 && c->hint_U[l + 1] > 0) {
-            // rows the speculation adds: what it added last time, else level l+1's unique rois scaled by parents / zoomed parents
-            const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
-                                                 : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
-            const double with = pass_us(c, c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
-            const double without = pass_us(c, c->hint_U[l]) + pass_us(c, c->hint_U[l + 1]) + 2 * PASS_OVERHEAD_US;
-            want = with < without && c->hint_U[l] + S + 2 < c->maxR;
+        if (!want && hist) {
+            // expected cost over the shape's recorded trees that reached level l (the others pay nothing here either way)
+            double with = 0.0, without = 0.0;
+            int n = 0;
+            bool fits = true;
+            for (int r = 0; r < c->hint_n; ++r) {
+                const HintView v = hint_rec(c, r);
+                if (v.P[l] <= 0) continue;
+                const double S = pair_rows(v, l);
+                with += pass_us(c, v.U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
+                without += pass_us(c, v.U[l]) + PASS_OVERHEAD_US +
+                           (v.U[l + 1] > 0 ? pass_us(c, v.U[l + 1]) + PASS_OVERHEAD_US : EMPTY_LEVEL_US);
+                fits = fits && v.U[l] + S + 2 < c->maxR;
+                ++n;
+            }
+            want = n > 0 && with < without && fits;
         }
         if (want) { mask |= 1 << l; ++l; }          // level l+1 is looked up: it has no pass to carry rows
     }
@@ -156,6 +184,11 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     // [1, 8, 0, 0, 0] tree 0.43 ms deferred against 0.32).  The previous search of this image shape tells.
     if (q.defer_root && c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev && c->hint_P[q.n_spec] == 0)
         q.defer_root = false;
+    // (round 5: a stream of different images -- deferring gains 16 us when the tree reaches that level and costs a whole
+    //  one-row head pass, ~110 us, when it does not: only when every one of the context's last four searches got there)
+    if (q.defer_root && c->n_hist < 4) q.defer_root = false;
+    for (int i = 0; i < 4 && q.defer_root; ++i)
+        if ((int)((c->early_hist >> (4 * i)) & 15u) <= q.n_spec) q.defer_root = false;
     q.lv_limit = AZ_MAX_LEVELS + 1;
     for (const auto &e : c->lv_limits)
         if (e.h == p->im_h && e.w == p->im_w) q.lv_limit = e.limit;
@@ -165,20 +198,29 @@ static SearchPlan plan_search(az_ctx *c, const az_params *p, int nlev, bool tune
     q.full = (c->full_now && q.fused && q.fused_lv && q.n_spec == 3 && q.lv_limit >= q.n_spec && c->plan &&
               c->plan->fs[c->full_now - 1].full_state == 1 && plan_is_for(*c->plan, p, nlev)) ? c->full_now : 0;
     if (q.full) { q.defer_root = false; q.pair_mask = 0; }
-    // early end: the previous search of the shape had no regions from level `cut` on (a level the fused kernels hand over
-    // to: the one before it carries the check)
+    // early end: recent searches of this context had no regions from level `cut` on (a level the fused kernels hand over
+    // to: the one before it carries the check).  Two rules, by what a miss costs (round 5; az_ctx.h: early_hist):
+    //   cut == 2 (the tree is the root and its children): a hit saves the third level's 40 rows and two empty levels
+    //            (~70 us of ~170), a miss wastes the 9-row pass (~100 us) -- taken when at least 7 of the context's last 8
+    //            searches ended there, whatever the very last one did;
+    //   cut >= 3: a miss repeats a search that has already run most of its passes -- taken only when the last four all
+    //            ended at or before that level.
     q.cut = 0;
     if (c->cut_env < 0) { const char *e = getenv("AZ_EARLY_END"); c->cut_env = (e && !atoi(e)) ? 0 : 1; }
-    if (c->cut_env && !(p->reserved & 4096) && !q.full && !tune && q.fused && q.fused_lv &&
-        c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev) {
-        // (a tree that ended before its third level: the speculative pass then evaluates the root and its children only)
-        for (int l = (q.n_spec == 3 ? 2 : q.n_spec); l < nlev; ++l)
-            if (c->hint_P[l] == 0) { q.cut = l; break; }
+    if (c->cut_env && !(p->reserved & 4096) && !q.full && !tune && q.fused && q.fused_lv) {
+        auto ended_by = [&](int i, int l) { return (int)((c->early_hist >> (4 * i)) & 15u) <= l; };
+        if (q.n_spec == 3 && nlev > 2) {
+            int n2 = 0;
+            for (int i = 0; i < 8; ++i) n2 += ended_by(i, 2) ? 1 : 0;
+            if (n2 >= 7) q.cut = 2;
+        }
+        for (int l = q.n_spec; !q.cut && l < nlev; ++l) {
+            bool all = true;
+            for (int i = 0; i < 4 && all; ++i) all = ended_by(i, l);
+            if (all) q.cut = l;
+        }
         if (q.cut > q.n_spec && q.cut - 1 >= q.lv_limit) q.cut = 0;      // (the level before it runs on the multi-launch kernels)
-        if (q.cut && q.cut < q.n_spec && q.defer_root) q.cut = 0;         // (cannot be: a deferred root needs level 4 to exist)
-        // ... and the last four searches of the context all ended there or earlier (az_ctx.h: early_hist)
-        for (int i = 0; i < 4 && q.cut; ++i)
-            if ((int)((c->early_hist >> (4 * i)) & 15u) > q.cut) q.cut = 0;
+        if (q.cut && q.cut < q.n_spec && q.defer_root) q.defer_root = false;   // (a deferred root needs level 4 to exist)
     }
     return q;
 }
@@ -389,11 +431,13 @@ static void hint_load(az_ctx *c, int h, int w, int nlev)
             std::memcpy(c->hint_rows, e.rows, sizeof(e.rows)); std::memcpy(c->hint_P, e.P, sizeof(e.P));
             std::memcpy(c->hint_PZ, e.PZ, sizeof(e.PZ)); std::memcpy(c->hint_U, e.U, sizeof(e.U));
             std::memcpy(c->hint_SPN, e.SPN, sizeof(e.SPN));
+            std::memcpy(c->hint_old, e.old, sizeof(e.old)); c->hint_n = e.n; c->hint_full_streak = e.full_streak;
             c->hint_h = h; c->hint_w = w; c->hint_nlev = nlev;
             e.use = ++c->hint_clock;
             return;
         }
     c->hint_h = -1; c->hint_w = -1; c->hint_nlev = 0;          // no search of this shape seen (yet)
+    c->hint_n = 0; c->hint_full_streak = 0;
     std::memset(c->hint_rows, 0, sizeof(c->hint_rows));
 }
 
@@ -415,6 +459,7 @@ static void hint_store(az_ctx *c)
     std::memcpy(slot->rows, c->hint_rows, sizeof(slot->rows)); std::memcpy(slot->P, c->hint_P, sizeof(slot->P));
     std::memcpy(slot->PZ, c->hint_PZ, sizeof(slot->PZ)); std::memcpy(slot->U, c->hint_U, sizeof(slot->U));
     std::memcpy(slot->SPN, c->hint_SPN, sizeof(slot->SPN));
+    std::memcpy(slot->old, c->hint_old, sizeof(slot->old)); slot->n = c->hint_n; slot->full_streak = c->hint_full_streak;
     slot->use = ++c->hint_clock;
 }
 
@@ -524,19 +569,22 @@ static int build_full_set(az_ctx *c, const az_params *p, int nlev, int variant)
     return AZ_OK;
 }
 
-// What the level-by-level form the context would pick for this shape (pair_plan on the same history) costs, in us.
-static double level_forms_cost(az_ctx *c, int nlev, int n_spec, int specU, int pair_mask)
+// What the level-by-level form the context would pick for this shape (pair_plan on the same history) costs for ONE of the
+// shape's recorded trees, in us.
+static double level_forms_cost(az_ctx *c, const HintView &v, int nlev, int n_spec, int specU, int pair_mask)
 {
     double t = pass_us(c, specU) + PASS_OVERHEAD_US;
     for (int l = n_spec; l < nlev; ++l) {
-        if (c->hint_U[l] <= 0) break;
+        if (v.U[l] <= 0) {              // the tree had ended: the level's pass is enqueued all the same and finds no rows
+            t += EMPTY_LEVEL_US;
+            if ((pair_mask >> l) & 1) ++l;
+            continue;
+        }
         if ((pair_mask >> l) & 1) {
-            const double S = c->hint_SPN[l] >= 0 ? (double)c->hint_SPN[l]
-                                                 : (double)c->hint_U[l + 1] * c->hint_P[l] / (c->hint_PZ[l] > 0 ? c->hint_PZ[l] : 1);
-            t += pass_us(c, c->hint_U[l] + S) + PASS_OVERHEAD_US + LOOKUP_US;
+            t += pass_us(c, v.U[l] + pair_rows(v, l)) + PASS_OVERHEAD_US + LOOKUP_US;
             ++l;
         } else
-            t += pass_us(c, c->hint_U[l]) + PASS_OVERHEAD_US;
+            t += pass_us(c, v.U[l]) + PASS_OVERHEAD_US;
     }
     return t;
 }
@@ -550,10 +598,12 @@ static int full_prepare(az_ctx *c, const az_params *p, int nlev, bool tune)
     if (!forced && c->full_env == 0) return AZ_OK;
     const SearchPlan q0 = plan_search(c, p, nlev, tune);        // (full_now is 0: the other form's plan)
     if (!(q0.fused && q0.fused_lv && q0.n_spec == 3 && q0.lv_limit >= q0.n_spec && nlev > q0.n_spec)) return AZ_OK;
-    const bool have_hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev;
-    // the previous search of this shape walked the FULL tree (every region zoomed at every level but the last)?
-    bool full_hist = have_hist;
-    for (int l = 0; full_hist && l + 1 < nlev; ++l) full_hist = c->hint_P[l] > 0 && c->hint_PZ[l] == c->hint_P[l];
+    const bool have_hist = c->hint_h == p->im_h && c->hint_w == p->im_w && c->hint_nlev == nlev && c->hint_n > 0;
+    // the last TWO searches of this shape walked the FULL tree (every region zoomed at every level but the last)?  One full
+    // tree in a stream of different images says little about the next, and a tree-rows pass that misses a window costs a
+    // second search; a context that keeps seeing full trees (Tz <= 0, or a threshold every region passes) gets there at its
+    // third search.
+    const bool full_hist = have_hist && c->hint_full_streak >= 2;
     if (!forced && !have_hist) return AZ_OK;
     int variant = forced ? (((p->reserved & 1024) || c->full_env == 3) ? 1 : 0) : (full_hist ? 0 : 1);
     int rc;
@@ -564,8 +614,12 @@ static int full_prepare(az_ctx *c, const az_params *p, int nlev, bool tune)
     double now = 0.0;
     if (!forced) {
         // cheapest the superset can be: the full tree's rows.  Not worth building anything if even that loses.
-        now = level_forms_cost(c, nlev, q0.n_spec, c->spc[q0.defer_root ? 1 : 0].h == p->im_h ? c->spc[q0.defer_root ? 1 : 0].U : 48,
-                               q0.pair_mask);
+        // (expected over the shape's recorded trees)
+        const int specU = c->spc[q0.defer_root ? 1 : 0].h == p->im_h ? c->spc[q0.defer_root ? 1 : 0].U : 48;
+        // (the tree-rows pass presumes the tree is full again: priced against the full trees of the streak)
+        const int nrec = variant == 0 ? (c->hint_full_streak < c->hint_n ? c->hint_full_streak : c->hint_n) : c->hint_n;
+        for (int r = 0; r < nrec; ++r) now += level_forms_cost(c, hint_rec(c, r), nlev, q0.n_spec, specU, q0.pair_mask);
+        now /= nrec;
         const double best = pass_us(c, k.Utot) + PASS_OVERHEAD_US + LOOKUP_US * (nlev - q0.n_spec);
         if (!(best + 10.0 < now)) return AZ_OK;
     }
@@ -614,8 +668,11 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
 // launch_head).  A wrong guess costs an idle launch, never a result.
 static int many_rows_expected(const az_ctx *c, int l)
 {
-    return (l >= 0 && l < AZ_MAX_LEVELS && c->hint_rows[l] >= c->gemm12_dual_rows &&
-            c->gemm12_min_rows < 0x7fffffff) ? -1 : 0;        // (hint_rows: rows of the PASS at that level, speculative rows included)
+    // (hint rows: rows of the PASS at that level, speculative rows included; the mean over the shape's recorded searches)
+    if (l < 0 || l >= AZ_MAX_LEVELS || c->gemm12_min_rows == 0x7fffffff || c->hint_n <= 0) return 0;
+    long sum = 0;
+    for (int r = 0; r < c->hint_n; ++r) sum += hint_rec(c, r).rows[l];
+    return sum >= (long)c->gemm12_dual_rows * c->hint_n ? -1 : 0;
 }
 
 // --------------------------------------------------------------------------------------
@@ -911,10 +968,12 @@ int launch_impl(az_ctx *c, const az_params *p)
             az_ctx::GraphEntry ent;
             ent.exec = ge; ent.npass = c->npass;
             std::memcpy(ent.pass_src, c->pass_src, sizeof(ent.pass_src));
+            std::memcpy(ent.pass_lv, c->pass_lv, sizeof(ent.pass_lv));
             it = c->graphs.emplace(key, ent).first;
         }
         c->npass = it->second.npass;
         std::memcpy(c->pass_src, it->second.pass_src, sizeof(c->pass_src));
+        std::memcpy(c->pass_lv, it->second.pass_lv, sizeof(c->pass_lv));
         HIPCHK(c, hipGraphLaunch(it->second.exec, s));
     } else {
         if ((rc = enqueue()) != AZ_OK) return rc;
@@ -928,6 +987,7 @@ int launch_impl(az_ctx *c, const az_params *p)
     q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
     q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
     std::memcpy(q.pass_src, c->pass_src, sizeof(q.pass_src));
+    std::memcpy(q.pass_lv, c->pass_lv, sizeof(q.pass_lv));
     for (q.slot = 0; q.slot < 2 && c->slot_busy[q.slot]; ++q.slot) { }
     if (p->fixed_num) {
         // the result block follows the search's kernels in stream order: whatever is enqueued next (the next image's
@@ -993,7 +1053,21 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         const int *hc = reinterpret_cast<const int *>(&h);
         for (int i = 0; i < q.npass && i < AZ_MAX_LEVELS; ++i) {
             const int r = q.pass_src[i] >= 0 ? hc[q.pass_src[i]] : -q.pass_src[i] - 1;
-            if (r > 0) st->pass_rows[st->n_passes++] = r;
+            if (r <= 0) continue;
+            // the tree levels whose rois the pass evaluated
+            const int lv = q.pass_lv[i];
+            const bool spec3 = nlev >= 3 && !(q.p.reserved & (1 | 4));         // (plan_search: n_spec == 3)
+            int mask;
+            if (lv < 0) {
+                if (q.is_static || q.full) mask = (1 << nlev) - 1;
+                else mask = (q.cut == 2 ? 3 : 7) & ~(q.defer ? 1 : 0);
+            } else {
+                mask = 1 << lv;
+                if ((q.pair_mask >> lv) & 1) mask |= 1 << (lv + 1);
+                if (q.defer && spec3 && lv == 3) mask |= 1;
+            }
+            st->pass_levels[st->n_passes] = mask;
+            st->pass_rows[st->n_passes++] = r;
         }
         for (int l = 0; l < nlev; ++l) {
             st->level_regions[l] = h.P[l];
@@ -1086,6 +1160,17 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
                     std::string("az_propose: ctx capacity exceeded (flags ") + std::to_string(h.err) +
                         "): raise az_set_limits");
     if (!q.is_static && !(q.p.reserved & 4)) {
+        hint_load(c, q.p.im_h, q.p.im_w, nlev);           // (the shape's records: a search of another shape may have been launched since)
+        if (c->hint_n > 0) {                              // the records move down by one, the oldest drops out
+            for (int r = az_ctx::HINT_K - 2; r > 0; --r) c->hint_old[r] = c->hint_old[r - 1];
+            std::memcpy(c->hint_old[0].rows, c->hint_rows, sizeof(c->hint_rows)); std::memcpy(c->hint_old[0].P, c->hint_P, sizeof(c->hint_P));
+            std::memcpy(c->hint_old[0].PZ, c->hint_PZ, sizeof(c->hint_PZ)); std::memcpy(c->hint_old[0].U, c->hint_U, sizeof(c->hint_U));
+            std::memcpy(c->hint_old[0].SPN, c->hint_SPN, sizeof(c->hint_SPN));
+        }
+        c->hint_n = c->hint_n < az_ctx::HINT_K ? c->hint_n + 1 : az_ctx::HINT_K;
+        bool walked_full = true;
+        for (int l = 0; walked_full && l + 1 < nlev; ++l) walked_full = h.P[l] > 0 && h.PZ[l] == h.P[l];
+        c->hint_full_streak = walked_full ? c->hint_full_streak + 1 : 0;
         for (int l = 0; l < AZ_MAX_LEVELS; ++l) {
             const bool in = l < nlev;
             // rows of the pass at that level (fused level loop: PR; multi-launch forms: the level's unique rois)
@@ -1101,6 +1186,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         for (int l = 1; l < nlev && l < 15; ++l)
             if (h.P[l] == 0) { first_empty = l; break; }
         c->early_hist = (c->early_hist << 4) | (unsigned)first_empty;
+        if (c->n_hist < 1000000) ++c->n_hist;
     }
     const int n = h.nsel;
     // (the candidate list stays readable only while no later search has been queued: it would be overwriting it)

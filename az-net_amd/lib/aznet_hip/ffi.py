@@ -57,7 +57,8 @@ class AzStats(ctypes.Structure):
                 ("spec_rows", ctypes.c_int32), ("root_deferred", ctypes.c_int32),
                 ("static_plan", ctypes.c_int32), ("n_passes", ctypes.c_int32),
                 ("pass_rows", ctypes.c_int32 * AZ_MAX_LEVELS),
-                ("search_form", ctypes.c_int32), ("n_reruns", ctypes.c_int32)]
+                ("search_form", ctypes.c_int32), ("n_reruns", ctypes.c_int32),
+                ("pass_levels", ctypes.c_int32 * AZ_MAX_LEVELS)]
 
 
 SEARCH_FORMS = {0: "level_loop", 1: "pair_speculation", 2: "whole_tree_pass", 3: "closure_pass", 4: "one_pass_plan"}

@@ -93,6 +93,53 @@ def make_scene_map(seed, C, H, W):
     return a
 
 
+def make_object_head(seed=1234, zoom_channel=0, gamma=10.0, beta=0.12, delta=3.0, noise=0.1, clip=0.5, **dims):
+    """make_head with a planted path through the zoom branch, so that the zoom indicator behaves the way a TRAINED AZ-Net's
+    does -- high for a region that contains an object small against the region, falling as the region shrinks onto the
+    object, low where there is none; hence consistent along an object's path down the tree -- instead of drifting with region
+    size as random weights make it:
+        s               = sum over the 49 bins of roi_pool5[zoom_channel]      (how much of the window the object fills)
+        int6 units 0, 1 = relu(s), relu(s - clip)                              (W6 rows 0 and 1, b6[1] = -clip)
+        int7_2 unit 0   = int6[0] - int6[1] = min(s, clip)                     ("there is an object in the window")
+        int7_2 unit 1   = int6[0] = s
+        zoom_score      = gamma * int7_2[0] - beta * int7_2[1] - delta + noise * (the random rest)       (Wz, bz)
+    With maps from make_object_map (zoom_channel is zero except on a few planted blobs, each >= clip) the zoom tree at a
+    tuned Tz follows the planted objects down the levels until a region is about the object's size: deep and sparse, a
+    handful of regions per level, different from image to image.  Everything else (adjacency scores and boxes, the other
+    units) is make_head's.  Caffe layout: W6 column c * 49 + p."""
+    head = make_head(seed=seed, **dims)
+    n6, K6 = head["W6"].shape
+    C = K6 // 49
+    assert 0 <= zoom_channel < C and n6 >= 2 and head["W72"].shape[0] >= 2
+    for j, b in ((0, 0.0), (1, -clip)):
+        head["W6"][j, :] = 0.0
+        head["W6"][j, zoom_channel * 49:(zoom_channel + 1) * 49] = 1.0
+        head["b6"][j] = b
+    head["W71"][:, 0:2] = 0.0                    # (the planted units feed the zoom branch only)
+    head["W72"][:, 0:2] = 0.0
+    head["W72"][0:2, :] = 0.0
+    head["W72"][0, 0], head["W72"][0, 1] = 1.0, -1.0
+    head["W72"][1, 0] = 1.0
+    head["b72"][0:2] = 0.0
+    head["Wz"] *= np.float32(noise)
+    head["Wz"][0, 0], head["Wz"][0, 1] = gamma, -beta
+    head["bz"][0] = -delta
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in head.items()}
+
+
+def make_object_map(seed, C, H, W, zoom_channel=0, max_objects=4):
+    """A conv5_3 stand-in for make_object_head: make_feature_map's noise in every channel but `zoom_channel`, which is zero
+    except on 0..max_objects planted blobs of 1x1..3x3 cells (16..48 px objects) with amplitudes in [0.6, 2]."""
+    a = make_feature_map(20_000 + seed, C, H, W)
+    rng = np.random.Generator(np.random.PCG64(90_000 + seed))
+    a[0, zoom_channel] = 0.0
+    for _ in range(int(rng.integers(0, max_objects + 1))):
+        h, w = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        y0, x0 = int(rng.integers(0, max(1, H - h + 1))), int(rng.integers(0, max(1, W - w + 1)))
+        a[0, zoom_channel, y0:y0 + h, x0:x0 + w] = np.float32(rng.uniform(0.6, 2.0))
+    return a
+
+
 def conv_out_size(n):
     """Spatial size after VGG16's four ceil-mode 2x2/2 max-pools
     (models/Pascal/VGG16/az-net/test.prototxt:16-384)."""

@@ -62,6 +62,38 @@ def t_min_us(unique_per_level, fmap_elems):
     return tot * 1e6
 
 
+def merged_floor_us(unique_per_level, pass_levels, fmap_elems):
+    """The floor of the passes that RAN: every head pass that evaluated rois of the tree streams the weights once and does
+    the flops of the tree levels it covered (az_stats.pass_levels) -- max(bytes / 8 TB/s, flops / 157.3 TF) per pass.  A
+    search that merges levels into one pass is bounded by THIS, not by t_min_us (one weight stream per level), so a
+    fraction of it never exceeds 1."""
+    tot = 0.0
+    for m in pass_levels:
+        U = sum(u for l, u in enumerate(unique_per_level) if (int(m) >> l) & 1)
+        if U <= 0:
+            continue
+        b = 432239616 + 21728 + 4 * fmap_elems + U * 244
+        tot += max(b / HBM_PEAK, U * HEAD_FLOP_PER_ROI / (PEAK_F32_MFMA_TFLOPS * 1e12))
+    return tot * 1e6
+
+
+def floors(st, fmap_elems, measured_us):
+    """path_floor entry of one search from its az_stats: BASELINE.md section 3's per-level floor and the merged-pass floor
+    of the form that ran, with `frac` = merged-pass floor / measured (<= 1 by construction)."""
+    uq = [int(st.level_unique[l]) for l in range(st.n_levels)]
+    pl = [int(x) for x in list(st.pass_levels)[:int(st.n_passes)]]
+    per_level = t_min_us(uq, fmap_elems)
+    merged = merged_floor_us(uq, pl, fmap_elems)
+    return {"t_min_us_per_image": per_level, "merged_pass_t_min_us": merged, "frac": merged / measured_us,
+            "per_level_floor_over_measured": per_level / measured_us, "head_passes": len(pl)}
+
+
+FLOOR_NOTE = ("t_min_us_per_image = BASELINE.md section 3: sum over the LEVELS of max(bytes / 8 TB/s, flops / 157.3 TF), one weight "
+              "stream per level; merged_pass_t_min_us = the same sum over the head PASSES that ran (a pass that covers several "
+              "levels streams the weights once: az_stats.pass_levels); frac = merged_pass_t_min_us / measured, which no search can "
+              "exceed; per_level_floor_over_measured may exceed 1 for a search that merges levels")
+
+
 def cpu_baseline(head, fmap, Tz, budget_s=20.0):
     """The oracle (kind "port") on the host: NumPy geometry exactly as lib/detect/test.py,
     C divide_region/RoIPool, BLAS sgemm for the fc head."""
@@ -151,6 +183,8 @@ def main():
                          "consecutive images overlap on the GPU (one context, queue-ahead); 1 = one stream, strictly one "
                          "image at a time on the GPU (reported as `one_lane` either way)")
     ap.add_argument("--no-one-lane", action="store_true", help="skip the extra one-lane measurement of the same loop")
+    ap.add_argument("--no-stream", action="store_true", help="skip stream_tz (distinct images in dataset order at a threshold tuned over the set)")
+    ap.add_argument("--stream-images", type=int, default=32, help="images per set of stream_tz")
     ap.add_argument("--no-sweep", action="store_true", help="skip tz_sweep (the same image at four quantiles of its zoom scores)")
     ap.add_argument("--e2e-pipelined", action="store_true",
                     help="also time backbone(i+1) overlapped with search(i) (measured slower than the serial order on most boxes)")
@@ -559,9 +593,7 @@ def main():
                          "traffic_source": traffic_source, "int6_launch_shapes": fc6_shapes,
                          "note": "achieved = ALGORITHMIC flops (unique RoIs of the tree x 216 006 656) / time inside the "
                                  "fc GEMM launches; speculative rows that the tree did not need are work done but not counted"},
-            "path_floor": {"t_min_us_per_image": floor_us, "measured_us_per_image": ms_step * 1e3,
-                           "frac": floor_us / (ms_step * 1e3),
-                           "note": "t_min = BASELINE.md section 3: sum over the levels of max(bytes / 8 TB/s, flops / 157.3 TF)"},
+            "path_floor": dict(floors(st, fmap_elems, ms_step * 1e3), measured_us_per_image=ms_step * 1e3, note=FLOOR_NOTE),
             "timed_region_ms": {"total": dt * 1e3, "loop_of_this_rank": t_loop * 1e3, "closing_barrier": (dt - t_loop) * 1e3},
             "value_200_steps": long_run,
             "box": box,
@@ -622,7 +654,8 @@ def main():
             net.propose(params)
         if rank == 0:
             out["one_lane"] = {"value": world * NUM_PROPOSALS * n_1 / d_1, "unit": "proposals/s", "ms_per_image": d_1 / n_1 * 1e3,
-                               "path_floor_frac": floor_us / (d_1 / n_1 * 1e6),
+                               "path_floor": floors(st, fmap_elems, d_1 / n_1 * 1e6),
+                               "path_floor_frac": floors(st, fmap_elems, d_1 / n_1 * 1e6)["frac"],
                                "note": "az_set_lanes(1): the context's searches run one after the other on one stream -- nothing of "
                                        "image i+1 starts on the GPU before image i's last kernel (rounds 1-3's `value`).  With two "
                                        "lanes (`value`) image i+1's RoIPool + int6 run beside image i's single-workgroup geometry "
@@ -642,12 +675,14 @@ def main():
             if one_pass_main:
                 out["level_loop"] = {"value": world * NUM_PROPOSALS * n_o / d_o, "unit": "proposals/s",
                                      "ms_per_image": d_o / n_o * 1e3, "rows_per_pass": rows_per_pass(sto),
-                                     "path_floor_frac": t_min_us(uo, fmap_elems) / (d_o / n_o * 1e6),
+                                     "path_floor": floors(sto, fmap_elems, d_o / n_o * 1e6),
+                                     "path_floor_frac": floors(sto, fmap_elems, d_o / n_o * 1e6)["frac"],
                                      "note": "same image, same Tz, walked level by level; bit-identical to `value`'s"}
             else:
                 out["one_pass"] = {"value": world * NUM_PROPOSALS * n_o / d_o, "unit": "proposals/s",
                                    "ms_per_image": d_o / n_o * 1e3, "rows": int(sto.spec_rows),
-                                   "path_floor_frac": t_min_us(uo, fmap_elems) / (d_o / n_o * 1e6),
+                                   "path_floor": floors(sto, fmap_elems, d_o / n_o * 1e6),
+                                   "path_floor_frac": floors(sto, fmap_elems, d_o / n_o * 1e6)["frac"],
                                    "one_pass_t_min_us": t_min_us([sum(uo)], fmap_elems),
                                    "note": "Tz <= 0 ONLY (the reference's TRAIN-phase setting, config.py:275): every zoom test "
                                            "passes, the tree is a function of the image shape, all levels' rois go through "
@@ -668,7 +703,8 @@ def main():
             out["level_loop_without_whole_tree_pass"] = {
                 "value": world * NUM_PROPOSALS * n_w / d_w, "unit": "proposals/s", "ms_per_image": d_w / n_w * 1e3,
                 "rows_per_pass": rows_per_pass(stw),
-                "path_floor_frac": t_min_us([int(stw.level_unique[l]) for l in range(stw.n_levels)], fmap_elems) / (d_w / n_w * 1e6),
+                "path_floor": floors(stw, fmap_elems, d_w / n_w * 1e6),
+                "path_floor_frac": floors(stw, fmap_elems, d_w / n_w * 1e6)["frac"],
                 "search_form": ffi.SEARCH_FORMS.get(int(stw.search_form), "?"),
                 "note": "Tz = 0 without the whole-tree pass: speculative rows, then level 4 + all children of level 4 -- the "
                         "form a dense pruned tree takes; bit-identical results"}
@@ -832,16 +868,16 @@ def main():
         convs[:] = convs_keep
         if rank == 0:
             uc = [int(stc.level_unique[l]) for l in range(stc.n_levels)]
-            fl_c = t_min_us(uc, fmap_elems)
             out["calibrated_tz"] = {
                 "Tz": tz_c, "value": world * Yc.shape[0] * n_c / dc, "unit": "proposals/s",
                 "ms_per_image": dc / n_c * 1e3,
                 "regions_per_level": [int(stc.level_regions[l]) for l in range(stc.n_levels)],
                 "unique_per_level": uc, "rows_per_pass": rows_per_pass(stc),
                 "search_form": ffi.SEARCH_FORMS.get(int(stc.search_form), "?"),
-                "path_floor": {"t_min_us_per_image": fl_c, "frac": fl_c / (dc / n_c * 1e6)},
-                "note": "same image and weights, zoom threshold at the median zoom score of the regions of levels "
-                        "2-3: a partially expanded, data-dependent tree"}
+                "path_floor": floors(stc, fmap_elems, dc / n_c * 1e6),
+                "note": "HISTORY-PRIMED (one image replayed; a stream of different images is `stream_tz`): same image and "
+                        "weights, zoom threshold at the median zoom score of the regions of levels 2-3: a partially expanded, "
+                        "data-dependent tree"}
     # ---- the searches a tuned Tz > 0 produces: the same image at four quantiles of its own zoom scores ----------------
     if not args.no_sweep:
         net.set_conv(conv)
@@ -878,14 +914,13 @@ def main():
             net.set_conv(conv)
             Yq, stq = net.propose(pq, want_stats=True)
             uq = [int(stq.level_unique[l]) for l in range(stq.n_levels)]
-            flq = t_min_us(uq, fmap_elems)
             pts.append({"quantile": q, "Tz": tz_q, "ms_per_image": dq / n_s * 1e3,
                         "value": world * Yq.shape[0] * n_s / dq, "unit": "proposals/s",
                         "regions_per_level": [int(stq.level_regions[l]) for l in range(stq.n_levels)],
                         "zoomed_per_level": [int(stq.level_zoomed[l]) for l in range(stq.n_levels)],
                         "unique_per_level": uq, "rows_per_pass": rows_per_pass(stq),
                         "search_form": ffi.SEARCH_FORMS.get(int(stq.search_form), "?"),
-                        "path_floor": {"t_min_us_per_image": flq, "frac": flq / (dq / n_s * 1e6)},
+                        "path_floor": floors(stq, fmap_elems, dq / n_s * 1e6),
                         "searches_run_twice": cnt_r[0], "timed_images": n_s})
         convs[:] = convs_keep
         net.set_conv(conv)
@@ -893,13 +928,21 @@ def main():
             net.propose(params)                          # (back to `value`'s tree as the shape's history)
         if rank == 0:
             out["tz_sweep"] = {"points": pts,
-                               "note": "convs[0]'s image, Tz at quantiles of the zoom scores of ALL regions of its full tree (untrained "
+                               "note": "HISTORY-PRIMED (each point replays ONE image; a stream of different images is `stream_tz`): "
+                                       "convs[0]'s image, Tz at quantiles of the zoom scores of ALL regions of its full tree (untrained "
                                        "weights: the scores drift with region size, so a quantile can empty the deep levels). Each "
                                        "point: 3 + 12 untimed searches (the context's history -- both lanes' -- becomes this tree), then "
                                        "timed_images searches, queue-ahead, one image at a time.  path_floor = BASELINE.md section "
                                        "3's per-level floor for THIS tree (every level one weight stream at 8 TB/s or its flops at "
                                        "157.3 TF): a tree of a few dozen rois per level is five 54.6 us weight streams there, "
                                        "which two head passes replace"}
+    # ---- the reference's operating point: ONE threshold tuned over a set, a stream of DIFFERENT images in dataset order ------
+    if not args.no_stream and rank == 0 and args.inflight == 1:
+        out["stream_tz"] = stream_tz(net, head, backbone, convs, ffi, synth, HipAZNet, torch, _get_image_blob, args, depth,
+                                     local_rank)
+        net.set_conv(conv)
+        for _ in range(3):
+            net.propose(params)                          # (back to `value`'s tree as the shape's history)
     # ---- BASELINE configs 3 and 4 and the NMS kernel under this run's clock (kernel time from HIP events) -----------
     if not args.no_extras and rank == 0:
         out.update(extras(net, head, ffi, synth, HipDetNet, torch, args))
@@ -1026,6 +1069,122 @@ def main():
         real_stdout.flush()
 
 
+def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_image_blob, args, depth, device):
+    """What tools/prop_az.py runs (prop_az.py:74-79 -> test.py:508-513): cfg_set_mode('Test', Tz) with ONE threshold tuned
+    over an image set (detect.tune.tune_thresh: the score that ANCHORS_PER_IMG anchors per image exceed on average --
+    az_tune_begin / az_tune_kth_largest), then image after image, every one a different tree.  No per-image priming: the
+    context's history when image i is launched is what the images before it left.  Two sets of 600x1000 maps:
+      objects    conv5_3 stand-ins with a few planted objects each + a head whose zoom unit reads them (synth.make_object_*):
+                 the zoom indicator is high where an object is and consistent from a region to its sub-regions, as a TRAINED
+                 AZ-Net's is -- deep, sparse trees that differ from image to image; tuned at cfg.TRAIN.ANCHORS_PER_IMG = 20
+                 (config.py:104), the reference's own setting;
+      untrained  scene images (synth.make_scene_image) through the random-weight backbone and head of `value`: the zoom
+                 score drifts with region size, so one threshold gives a MIXTURE of trees that end at their second level and
+                 dense ones -- the hardest case for choices made from history; at 20 and at 1500 anchors per image.
+    Per point: the set once untimed (the dataset's first images: plans, histories), then `passes` x the set timed in order,
+    queue-ahead as `value`; searches run twice; the forms taken; every image's own same-tree replay (history primed with
+    its own tree, the round-4 measurement) for the ratio; the mean fraction of the images' merged-pass floors."""
+    import gc
+    H, W = H_IM, W_IM
+    n_img = max(8, int(args.stream_images))
+    passes = 3
+    res = {"images_per_set": n_img, "timed_images_per_point": passes * n_img, "lanes": int(getattr(net.ctx, "lanes", 1)),
+           "searches_launched_and_unfetched": depth, "points": []}
+
+    def run_set(cnet, maps, prm, seq, stats=None):
+        launched = 0
+        for i in range(len(seq)):
+            while launched < min(len(seq), i + depth):
+                cnet.ctx.propose_launch(prm, fmap=maps[seq[launched]], producer_done=True)
+                launched += 1
+            Y, st = cnet.ctx.propose_fetch(want_stats=True)
+            if stats is not None:
+                stats.append((seq[i], st))
+
+    def tune(cnet, maps, anchors_per_img):
+        cnet.ctx.tune_begin(len(maps) * 2 * cnet.ctx.max_regions)
+        for m in maps:
+            cnet.set_conv(m)
+            cnet.propose(ffi.AzContext.make_params(H, W, 1.0, 0.0, num_proposals=NUM_PROPOSALS, tune=True))
+        tz = [cnet.ctx.tune_kth_largest(len(maps) * a)[0] for a in anchors_per_img]
+        cnet.ctx.tune_end()
+        return tz
+
+    def point(label, cnet, maps, tz, anchors):
+        prm = ffi.AzContext.make_params(H, W, 1.0, tz, num_proposals=NUM_PROPOSALS)
+        fm = int(maps[0].numel())
+        order = list(range(len(maps)))
+        gc.collect()
+        gc.disable()
+        run_set(cnet, maps, prm, order)                       # the dataset's first pass: untimed
+        stats = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            run_set(cnet, maps, prm, order, stats)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = len(stats)
+        ms = dt / n * 1e3
+        forms, reruns, fracs, trees = {}, 0, [], []
+        for i, st in stats:
+            f = ffi.SEARCH_FORMS.get(int(st.search_form), "?")
+            forms[f] = forms.get(f, 0) + 1
+            reruns += int(st.n_reruns)
+        for i, st in stats[:len(maps)]:
+            trees.append([int(st.level_regions[l]) for l in range(st.n_levels)])
+        # every image's same-tree replay: 12 untimed searches of that image alone, then 30 timed
+        rep = []
+        for i in order:
+            run_set(cnet, maps, prm, [i] * 12)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st_i = []
+            run_set(cnet, maps, prm, [i] * 30, st_i)
+            torch.cuda.synchronize()
+            r_ms = (time.perf_counter() - t0) / 30 * 1e3
+            rep.append(r_ms)
+            fracs.append(floors(st_i[-1][1], fm, 1.0)["merged_pass_t_min_us"])
+        gc.enable()
+        merged_mean = float(np.mean(fracs))
+        reg = np.array([t + [0] * (8 - len(t)) for t in trees])[:, :len(trees[0])]
+        return {"set": label, "anchors_per_img": anchors, "Tz": tz, "ms_per_image": ms, "value": NUM_PROPOSALS * 1e3 / ms,
+                "unit": "proposals/s", "timed_images": n, "searches_run_twice": reruns, "rerun_rate": reruns / float(n),
+                "search_forms": forms,
+                "same_tree_replay_ms_per_image": float(np.mean(rep)), "stream_over_replay": ms / float(np.mean(rep)),
+                "merged_pass_floor": {"mean_t_min_us_per_image": merged_mean, "frac": merged_mean / (ms * 1e3),
+                                      "frac_of_replay": merged_mean / (float(np.mean(rep)) * 1e3)},
+                "regions_per_level": {"mean": [float(x) for x in reg.mean(0)], "min": [int(x) for x in reg.min(0)],
+                                      "max": [int(x) for x in reg.max(0)]},
+                "trees_of_the_first_images": trees[:8],
+                "levels_reached_histogram": {str(k): int(v) for k, v in
+                                             zip(*np.unique([sum(1 for x in t if x > 0) for t in trees], return_counts=True))}}
+
+    # ---- objects: planted-object maps + a head whose zoom unit reads them ---------------------------------------------
+    ohead = synth.make_object_head(seed=1234, **synth.FULL_DIMS)
+    onet = HipAZNet(ohead, backbone=None, device=device, name="stream_objects", max_regions=4096)
+    onet.ctx.set_lanes(int(getattr(net.ctx, "lanes", 1)))
+    omaps = [torch.from_numpy(synth.make_object_map(j, 512, 38, 63)).to("cuda:%d" % device).contiguous(memory_format=torch.channels_last)
+             for j in range(n_img)]
+    tz_o = tune(onet, omaps, [20])
+    res["points"].append(point("objects", onet, omaps, tz_o[0], 20))
+    del onet, omaps, ohead
+    # ---- untrained: scene images through `value`'s backbone and head --------------------------------------------------------
+    smaps = []
+    for j in range(n_img):
+        b = get_image_blob(synth.make_scene_image(j, H, W), net)[0]
+        smaps.append(net.compute_conv(b).clone().contiguous(memory_format=torch.channels_last))
+    tz_s = tune(net, smaps, [20, 1500])
+    for a, tz in zip([20, 1500], tz_s):
+        res["points"].append(point("untrained", net, smaps, tz, a))
+    res["note"] = ("one threshold per point, tuned over its set with az_tune_*; images launched in dataset order, no per-image "
+                   "priming; rerun_rate = searches that had to be run twice (an early end that missed, a whole-tree pass that "
+                   "lacked a window) / timed images; stream_over_replay = ms_per_image over the mean of every image's own "
+                   "history-primed replay (what calibrated_tz / tz_sweep measure for ONE image); merged_pass_floor.frac = mean "
+                   "of the images' merged-pass floors (of their replay's passes) over ms_per_image")
+    return res
+
+
 def extras(net, head, ffi, synth, HipDetNet, torch, args):
     """deep_tree (BASELINE config 4), shared_detection (config 3) and az_nms at SURVEY 8(d)'s sizes, each with the
     kernel time of its launches from HIP events on the ctx stream (az_set_profiling) next to the wall clock through
@@ -1068,7 +1227,8 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
         ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
         fl = t_min_us(ud, int(fmap.size))
         kms, by = kernel_ms(lambda: net.propose(p), 5)
-        d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor_frac": fl / (ms * 1e3),
+        d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor": floors(std, int(fmap.size), ms * 1e3),
+             "path_floor_frac": floors(std, int(fmap.size), ms * 1e3)["frac"],
              "kernel_ms_per_image": kms, "rows_per_pass": [int(x) for x in list(std.pass_rows)[:int(std.n_passes)]]}
         if form == "level_loop":
             res["deep_tree"] = dict(d, workload="BASELINE config 4: 800x1200 image (scale 0.75), K = 7, Tz = 0",

@@ -116,6 +116,10 @@ typedef struct {
     int32_t n_reruns;                     /* times this search had to be run again in another form before it gave this
                                              result (0 normally; e.g. a whole-tree pass over the full tree's rows that lacked
                                              a window the pruned tree needed)                                               */
+    int32_t pass_levels[AZ_MAX_LEVELS];   /* per head pass (as pass_rows): bit l set = the pass evaluated the rois of tree level
+                                             l + 1 (its own level, the next one's when it carried pair-speculation rows, levels
+                                             1-3 for the speculative pass, every level for a whole-tree / one-pass form) --
+                                             what a floor that charges ONE weight stream per pass needs (bench.py)           */
 } az_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */

@@ -139,7 +139,7 @@ def main():
         head = synth.make_head(seed=77, **synth.SMALL_DIMS)
         runs = []
         for tag, H, W, steps, nprop in (("distinct", 375, 500, 0, 300), ("ties", 375, 500, 64, 300),
-                                        ("ties_coarse", 480, 640, 8, 300), ("short", 600, 1000, 0, 5000)):
+                                        ("ties_coarse", 480, 640, 8, 300), ("short", 600, 1000, 0, 4000)):
             C.cfg_set_mode("Test", 0.0)
             C.cfg.SEAR.NUM_PROPOSALS = nprop
             im = synth.make_image(6, H, W)

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--noise", action="store_true", help="uniform-noise images (synth.make_image) instead of scenes")
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--replay", type=int, default=4, help="images whose same-tree replay is timed for comparison")
     args = ap.parse_args()
     import torch
@@ -52,7 +54,7 @@ def main():
         print("anchors/img %d -> Tz %.6f (pool %d)" % (a, tz, npool))
         per_level.append((a, tz))
     net.ctx.tune_end()
-    depth = args.lanes + 1
+    depth = args.depth or args.lanes + 1
 
     def stream(prm, seq, stats=None):
         launched = 0
@@ -64,6 +66,9 @@ def main():
             if stats is not None:
                 stats.append((seq[i], st))
 
+    import gc
+    gc.collect()
+    gc.disable()
     for a, tz in per_level:
         prm = ffi.AzContext.make_params(H, W, 1.0, tz)
         order = list(range(args.images))
@@ -82,21 +87,32 @@ def main():
             forms[ffi.SEARCH_FORMS[int(st.search_form)]] = forms.get(ffi.SEARCH_FORMS[int(st.search_form)], 0) + 1
             reruns += int(st.n_reruns)
         print("== anchors/img %d Tz %.5f: %.4f ms/image over %d images, reruns %d, forms %s" % (a, tz, dt / n * 1e3, n, reruns, forms))
-        for i, st in stats[:args.images]:
+        for i, st in stats[:args.images] if args.verbose else []:
             print("   img %2d regions %s passes %s form %d reruns %d" % (
                 i, [int(st.level_regions[l]) for l in range(st.n_levels)], [int(x) for x in list(st.pass_rows)[:int(st.n_passes)]],
                 int(st.search_form), int(st.n_reruns)))
         # same-tree replay of a few images (history primed with the image's own tree)
         rep = []
         for i in range(min(args.replay, args.images)):
-            for _ in range(8):
+            for _ in range(4):
                 stream(prm, [i] * 4)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            stream(prm, [i] * 100)
+            stream(prm, [i] * 40)
             torch.cuda.synchronize()
-            rep.append((time.perf_counter() - t0) / 100 * 1e3)
-        print("   same-tree replay of images 0..%d: %s ms/image (mean %.4f)" % (len(rep) - 1, ["%.3f" % x for x in rep], float(np.mean(rep))))
+            rep.append((time.perf_counter() - t0) / 40 * 1e3)
+        print("   same-tree replay of images 0..%d: %s ms/image (mean %.4f); stream / replay = %.3f" % (
+            len(rep) - 1, ["%.3f" % x for x in rep], float(np.mean(rep)), (dt / n * 1e3) / float(np.mean(rep))))
+        trees = {}
+        for i, st in stats[:args.images]:
+            k = tuple(int(st.level_regions[l]) for l in range(st.n_levels))
+            trees[k] = trees.get(k, 0) + 1
+        print("   trees:", sorted(trees.items(), key=lambda kv: -kv[1])[:12])
+        pk = {}
+        for i, st in stats:
+            k = (tuple(int(st.level_regions[l]) > 0 for l in range(st.n_levels)).count(True), tuple(int(x) > 0 for x in list(st.pass_rows)[:int(st.n_passes)]).count(True), int(st.n_reruns))
+            pk[k] = pk.get(k, 0) + 1
+        print("   (levels reached, passes, reruns): count", sorted(pk.items()))
         # the stream restricted to those images, for a like-for-like ratio
         sub = list(range(min(args.replay, args.images)))
         stream(prm, sub * 4)

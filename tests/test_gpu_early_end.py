@@ -60,24 +60,28 @@ def test_sparse_searches_end_early_and_a_deeper_tree_is_run_again(mods, H, W, sc
 
     s1 = run(hi, maps[0])                                # no history yet: every level enqueued
     assert list(s1.level_regions[:2]) == [1, len(B1)] and sum(s1.level_regions[2:s1.n_levels]) == 0 and s1.n_reruns == 0
-    for k in range(3):                                   # four searches in a row that ended after their second level ...
-        assert run(hi, maps[(k + 1) % 3]).n_reruns == 0
-    s2 = run(hi, maps[1])                                # ... so this one is enqueued only that far
+    assert s1.n_passes == 1 and s1.pass_rows[0] > 1 + len(B1)
+    for k in range(6):                                   # seven searches that ended after their second level ...
+        sk = run(hi, maps[(k + 1) % 3])
+        assert sk.n_reruns == 0 and sk.pass_rows[0] > 1 + len(B1)      # (fewer than 7 of the last 8: not cut yet)
+    s2 = run(hi, maps[1])                                # ... 7 of the last 8: this one is enqueued only that far
     assert s2.n_reruns == 0 and s2.n_passes == 1 and list(s2.pass_rows[:1]) == [1 + len(B1)]
+    assert int(s2.pass_levels[0]) == 3                   # (the pass evaluated levels 1 and 2)
     # the same with a data-dependent proposal count (cfg.SEAR.FIXED_PROPOSAL_NUM = False: everything with score >= Tc)
     net.set_conv(maps[0]); ref.set_conv(maps[0])
     Yt, St = net.propose(ffi.AzContext.make_params(H, W, scale, hi, static_tree=False, full_spec=False, fixed_num=False, Tc=0.3),
                          want_scores=True)
     Yq, Sq = ref.propose(_plain(ffi, H, W, scale, hi, fixed_num=False, Tc=0.3), want_scores=True)
     assert np.array_equal(Yt, Yq) and np.array_equal(St, Sq)
-    s3 = run(lo, maps[2])                                # a full tree behind a sparse one: cut, missed, run again
+    s3 = run(lo, maps[2])                                # a full tree behind sparse ones: cut, missed, run again
     assert s3.n_reruns == 1 and sum(s3.level_regions[2:s3.n_levels]) > 0
-    s4 = run(hi, maps[0])                                # (a search that went on is in the history now: no cut, no rerun)
-    assert s4.n_reruns == 0
-    s5 = run(lo, maps[1])
-    assert s5.n_reruns == 0
-    for k in range(4):                                   # alternating sparse / dense images are never cut: nothing is run twice
-        assert run(hi if k % 2 == 0 else lo, maps[k % 3]).n_reruns == 0
+    s4 = run(hi, maps[0])                                # (still 7 sparse searches among the last 8: cut, and right)
+    assert s4.n_reruns == 0 and list(s4.pass_rows[:s4.n_passes]) == [1 + len(B1)]
+    s5 = run(lo, maps[1])                                # ... cut, and wrong once more
+    assert s5.n_reruns == 1
+    for k in range(6):                                   # from here on 6 or fewer of the last 8 are sparse: alternating sparse /
+        sk = run(hi if k % 2 == 0 else lo, maps[k % 3])  # dense images are never cut, nothing is run twice
+        assert sk.n_reruns == 0 and sk.pass_rows[0] > 1 + len(B1)
 
 
 @pytest.mark.parametrize("lanes,depth", [(1, 2), (2, 3), (2, 4)])
@@ -102,7 +106,8 @@ def test_an_early_end_that_misses_is_run_again_inside_a_full_queue(mods, lanes, 
         zmax = max(zmax, float(z.max()))
     hi = 0.5 * (zmax + 1.0)
     # a run of sparse trees (each lane's last four end after their second level: cut), a dense one (missed, run again), a mix
-    seq = [hi] * 10 + [0.0, hi, 0.0, 0.0] + [hi] * 10 + [0.0, hi]
+    # (a lane cuts when 7 of ITS last 8 searches ended early: with two lanes every other search of the sequence)
+    seq = [hi] * 18 + [0.0, hi, 0.0, 0.0] + [hi] * 18 + [0.0, hi]
     prm = [ffi.AzContext.make_params(H, W, scale, t, static_tree=False, full_spec=False) for t in seq]
     want = []
     for i, t in enumerate(seq):

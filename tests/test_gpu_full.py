@@ -175,24 +175,35 @@ def test_history_takes_the_closure_for_dense_pruned_trees_when_it_is_cheaper(mod
     assert c[2].search_form in (0, 1) and np.array_equal(c[0], plain[0])
 
 
-def test_history_turns_it_on_for_dense_trees_only(small, mods):
+def test_history_turns_it_on_for_dense_trees_only(mods):
+    """The tree-rows pass costs a second search when it lacks a window, so one full tree is not enough to take it: the
+    shape's last TWO searches must both have walked the full tree (a stream of different images at a tuned Tz rarely does
+    that; a context at Tz <= 0 always does).  A pruned history goes back to the level-by-level forms."""
     ffi, synth, HipAZNet, orc = mods
-    net, head = small
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="hist_dense")
+    net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)
     H, W = 600, 1000
     net.set_conv(synth.make_feature_map(9, synth.SMALL_DIMS["C"], 38, 63))
     p0 = ffi.AzContext.make_params(H, W, 1.0, 0.0, static_tree=False)
     a = net.propose(p0, want_scores=True, want_stats=True)          # first search of the shape: no history
-    b = net.propose(p0, want_scores=True, want_stats=True)          # dense tree seen: one pass
-    assert a[2].n_passes >= 2 and b[2].n_passes == 1
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    b = net.propose(p0, want_scores=True, want_stats=True)          # one full tree seen: not yet
+    c3 = net.propose(p0, want_scores=True, want_stats=True)         # two in a row: one pass over the full tree's rows
+    assert a[2].n_passes >= 2 and b[2].search_form != 2 and c3[2].n_passes == 1 and c3[2].search_form == 2
+    for r in (b, c3):
+        assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
     z = _zooms(net, ffi, H, W, 1.0)
     psparse = ffi.AzContext.make_params(H, W, 1.0, float(np.quantile(z, 0.6)), static_tree=False)
-    net.propose(psparse)
-    c = net.propose(psparse, want_stats=True)                        # pruned tree seen: level by level again
-    assert c[1].num_eval < b[2].num_eval and c[1].pass_rows[0] < b[2].pass_rows[0]
+    for _ in range(4):
+        net.propose(psparse)
+    c = net.propose(psparse, want_stats=True)                        # pruned trees seen: level by level again
+    assert c[1].num_eval < c3[2].num_eval and c[1].pass_rows[0] < c3[2].pass_rows[0] and c[1].search_form in (0, 1)
     d = net.propose(p0, want_scores=True, want_stats=True)          # (history says pruned: the full tree is found out first)
     e = net.propose(p0, want_scores=True, want_stats=True)
-    assert e[2].n_passes == 1 and np.array_equal(e[0], a[0]) and np.array_equal(d[0], a[0])
+    f = net.propose(p0, want_scores=True, want_stats=True)
+    assert d[2].search_form != 2 and f[2].n_passes == 1 and f[2].search_form == 2
+    for r in (d, e, f):
+        assert np.array_equal(r[0], a[0]) and np.array_equal(r[1], a[1])
 
 
 def test_full_head_whole_tree_pass_vs_pure_cpu_oracle(mods, gemm_mode):
@@ -256,8 +267,8 @@ def test_deep_tree_takes_the_whole_tree_pass_too(small, mods):
 
 
 def test_history_is_kept_per_image_shape(small, mods):
-    """A dataset mixes image shapes: each shape keeps the history of its own last search, so alternating shapes still
-    reach the speculative forms from their second search on."""
+    """A dataset mixes image shapes: each shape keeps the history of its own last searches, so alternating shapes still
+    reach the speculative forms from their third search on."""
     ffi, synth, HipAZNet, orc = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
     net = HipAZNet(head, name="mixed")
@@ -266,7 +277,7 @@ def test_history_is_kept_per_image_shape(small, mods):
     maps = [synth.make_feature_map(50 + i, synth.SMALL_DIMS["C"], synth.conv_out_size(int(round(H * sc))),
                                    synth.conv_out_size(int(round(W * sc)))) for i, (H, W, sc) in enumerate(shapes)]
     first, passes = {}, {}
-    for rnd in range(3):
+    for rnd in range(4):
         for i, (H, W, sc) in enumerate(shapes):
             net.set_conv(maps[i])
             Y, S, st = net.propose(ffi.AzContext.make_params(H, W, sc, 0.0, static_tree=False), want_scores=True,
@@ -277,4 +288,5 @@ def test_history_is_kept_per_image_shape(small, mods):
             else:
                 assert np.array_equal(Y, first[i][0]) and np.array_equal(S, first[i][1])
     for i in range(len(shapes)):
-        assert passes[i][0] >= 2 and passes[i][1] == 1 and passes[i][2] == 1, passes
+        # (the whole-tree pass over the full tree's rows from the third search of a shape on: two full trees in a row)
+        assert passes[i][0] >= 2 and passes[i][2] == 1 and passes[i][3] == 1, passes

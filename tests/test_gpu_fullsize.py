@@ -110,7 +110,8 @@ def test_config_a_full_head_vs_pure_cpu_oracle(full, mods, mode):
     Y, S, st = net.propose(ffi.AzContext.make_params(H, W, 1.0, Tz, static_tree=(mode != "tz0_level_loop")),
                            want_scores=True, want_stats=True)
     assert st.static_plan == (1 if mode == "tz0" else 0)
-    assert st.spec_rows == (688 if mode == "tz0" else 48)
+    # (48: the root's row deferred to level 4's pass -- taken when the context's last searches all reached that level; 49 otherwise)
+    assert st.spec_rows == 688 if mode == "tz0" else st.spec_rows in (48, 49)
     # tree: same regions per level, same unique counts, same zoom sets (integer work: exact)
     assert st.depth == tr["depth"] and st.num_eval == tr["num_eval"]
     for l, lev in enumerate(tr["levels"]):

@@ -100,7 +100,8 @@ def test_history_turns_pair_speculation_on(small, mods):
     net.ctx.set_pass_costs(ffi.AzContext.REFERENCE_PASS_COSTS)      # (the decision below: not by this box's clock)
     net.set_conv(synth.make_feature_map(41, synth.SMALL_DIMS["C"], 38, 63))
     first = _run(net, ffi, 600, 1000, 1.0, 0.0, None)
-    assert first["st"].n_passes == 3 and list(first["st"].pass_rows[:3])[0] == 48
+    # (49: the root's row rides in the speculative pass -- a context without history does not defer it)
+    assert first["st"].n_passes == 3 and list(first["st"].pass_rows[:3])[0] == 49
     second = _run(net, ffi, 600, 1000, 1.0, 0.0, None)
     _same(first, second)
     assert second["st"].n_passes == 2                       # (48 rows) + (level 4 + all children of level 4)

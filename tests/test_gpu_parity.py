@@ -193,8 +193,14 @@ def test_topk_golden_g8(small):
         assert np.array_equal(neg[idx], neg[indA[:n]]), tag
         cut = neg[indA[n - 1]]
         assert set(idx[neg[idx] < cut].tolist()) == set(indA[:n][neg[indA[:n]] < cut].tolist()), tag
-        if tag in ("distinct", "short"):
-            assert np.array_equal(Yall[idx], Y), tag
+        # the boxes the reference returned, tie groups compared as sets (equal scores: the same RoIPool window met from
+        # different regions -- same score, boxes decoded against different anchors)
+        for v in np.unique(neg[indA[:n]]):
+            if v == cut:
+                continue
+            a = Yall[idx[neg[idx] == v]]
+            b = Y[neg[indA[:n]] == v]
+            assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])]), tag
 
 
 # ---------------------------------------------------------------- head

@@ -82,8 +82,8 @@ def test_ffi_struct_layout_matches_header():
     import ctypes
     from aznet_hip import ffi
     assert ctypes.sizeof(ffi.AzParams) == 8 + 6 * 8 + 4 * 4
-    # + spec_rows, root_deferred, static_plan, n_passes, pass_rows[16], search_form, n_reruns
-    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4 + 2 * 4
+    # + spec_rows, root_deferred, static_plan, n_passes, pass_rows[16], search_form, n_reruns, pass_levels[16]
+    assert ctypes.sizeof(ffi.AzStats) == 5 * 4 + 3 * 16 * 4 + 3 * 4 + 4 + 16 * 4 + 2 * 4 + 16 * 4
     hdr0 = open(os.path.join(os.path.dirname(__file__), "..", "include", "aznet_hip.h")).read()
     st_body = hdr0[hdr0.index("typedef struct {", hdr0.index("} az_params;")):hdr0.index("} az_stats;")]
     import re as _re
