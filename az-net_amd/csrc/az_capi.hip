@@ -70,6 +70,7 @@ int az_destroy(az_ctx *c)
         if (c->io_ev[i]) hipEventDestroy(c->io_ev[i]);
     }
     if (c->ev_hand) hipEventDestroy(c->ev_hand);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->span_ring) hipFree(c->span_ring);
     if (c->h_nms) hipHostFree(c->h_nms);
     if (c->h_nmsb) hipHostFree(c->h_nmsb);
@@ -208,6 +209,22 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
 
 }  // extern "C"
 
+// The context's two channel-last copies (and the NCHW staging buffer) hold at least n elements.
+static int ensure_feat_copies(az_ctx *c, size_t n)
+{
+    if (n <= c->feat_owned_elems) return AZ_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->twin) HIPCHK(c, hipStreamSynchronize(c->twin->stream));      // (a lane may be copying out of the old buffers)
+    if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
+    c->feat_owned[0] = c->feat_owned[1] = c->feat_stage = nullptr; c->feat_owned_elems = 0;
+    ++c->feat_gen;
+    HIPCHK(c, hipMalloc((void **)&c->feat_owned[0], n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->feat_owned[1], n * 4));
+    HIPCHK(c, hipMalloc((void **)&c->feat_stage, n * 4));
+    c->feat_owned_elems = n;
+    return AZ_OK;
+}
+
 int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W, bool wait)
 {
     int rc = check_ready(c, false);
@@ -216,16 +233,10 @@ int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C,
         return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t n = (size_t)C * H * W;
-    if (n > c->feat_owned_elems) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
-        c->feat_owned[0] = c->feat_owned[1] = c->feat_stage = nullptr; c->feat_owned_elems = 0;
-        ++c->feat_gen;
-        HIPCHK(c, hipMalloc((void **)&c->feat_owned[0], n * 4));
-        HIPCHK(c, hipMalloc((void **)&c->feat_owned[1], n * 4));
-        HIPCHK(c, hipMalloc((void **)&c->feat_stage, n * 4));
-        c->feat_owned_elems = n;
-    }
+    if ((rc = ensure_feat_copies(c, n)) != AZ_OK) return rc;
+    // a second lane may still have to take its private copy of the map this context held two hand-overs ago (the copy
+    // waits behind that lane's earlier search): the buffer is not written before it has
+    if (c->twin && c->twin->ev_copy_live) HIPCHK(c, hipStreamWaitEvent(c->stream, c->twin->ev_copy, 0));
     const float *nchw = src;
     if (src_is_host) {
         HIPCHK(c, hipMemcpyAsync(c->feat_stage, src, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -366,12 +377,27 @@ static int launch_routed(az_ctx *c, const az_params *p, const float *dev_map, in
         rc = channels_last ? az_set_feature_map_dev_nhwc(t, dev_map, C, H, W) : set_feature_map_common(t, dev_map, false, C, H, W, false);
         if (rc) { if (t != c) c->err = t->err; return rc; }
     } else if (t != c) {
-        // the map was set on the context itself: the lane reads it where it lies, behind whatever the context's stream
-        // still has to do to it (an un-awaited transpose)
-        t->feat = c->feat; t->d.H = c->d.H; t->d.W = c->d.W;
+        // the map was set on the context itself: the lane takes it behind whatever the context's stream still has to do to it
+        // (an un-awaited transpose).  A map the caller holds in the channel-last layout is read where it lies (the caller
+        // keeps it untouched until the fetch); one of the CONTEXT's own channel-last copies is copied into the lane's own
+        // buffers -- the context writes its two copies in turn, and this lane's search may be fetched (or even start) only
+        // after the context has been handed the map after next.
+        if (!c->feat) return fail(c, AZ_ERR_STATE, "no feature map set");
+        t->d.H = c->d.H; t->d.W = c->d.W;
         if (!t->ev_hand) HIPCHK(c, hipEventCreateWithFlags(&t->ev_hand, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(t->ev_hand, c->stream));
         HIPCHK(c, hipStreamWaitEvent(t->stream, t->ev_hand, 0));
+        if (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]) {
+            const size_t n = (size_t)c->d.C * c->d.H * c->d.W;
+            if ((rc = ensure_feat_copies(t, n)) != AZ_OK) { c->err = t->err; return rc; }
+            t->feat_turn ^= 1;
+            HIPCHK(c, hipMemcpyAsync(t->feat_owned[t->feat_turn], c->feat, n * 4, hipMemcpyDeviceToDevice, t->stream));
+            if (!t->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&t->ev_copy, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(t->ev_copy, t->stream));
+            t->ev_copy_live = true;
+            t->feat = t->feat_owned[t->feat_turn];
+        } else
+            t->feat = c->feat;
     }
     if (t != c) {
         if (t->cal.state == 0 && c->cal.state != 0) t->cal = c->cal;

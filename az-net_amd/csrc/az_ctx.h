@@ -152,6 +152,11 @@ struct az_ctx {
     int lanes = 1, lane_next = 0, last_fetch_lane = 0;
     std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
     hipEvent_t ev_hand = nullptr;             // (in a twin) orders the lane behind the owner's stream when it reads the owner's map
+    // (in a twin) recorded behind the lane's private copy of an owner-held map: the owner's stream waits for it before it
+    // writes its channel-last copies again (the lane may still be busy with an earlier search when the owner is handed
+    // the map after next)
+    hipEvent_t ev_copy = nullptr;
+    bool ev_copy_live = false;
     void *comm = nullptr;                     // ncclComm_t of az_rccl_init
     int comm_ranks = 0, comm_rank = 0;
     // the collective runs on a stream of its own, behind events of the lanes: in a lane's stream it would hold that lane's

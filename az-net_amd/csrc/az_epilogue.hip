@@ -6,12 +6,17 @@
 // Layer definitions: models/Pascal/VGG16/az-net/test.prototxt:16-384 (Convolution with bias_term, ReLU in place, Pooling MAX
 // kernel 2 stride 2; Caffe pools in ceil mode: a last window may be clipped by the map's edge).
 // Arithmetic is PyTorch's: fp32 add, max(., 0), max over the window -- and max(relu(y_i + b)) == relu(max(y_i) + b) bit for
-// bit (rounding is monotonic), which is the order used here.
+// bit for finite values (rounding is monotonic), which is the order used here; NaNs propagate as in torch (relu_nan, max_nan).
 #include <hip/hip_runtime.h>
 
 #include "../../include/aznet_hip.h"
 
 namespace {
+
+// NaN-propagating forms, as torch's relu / max_pool2d: a NaN (a broken checkpoint, an overflowed convolution) stays a NaN here
+// as it does in the un-fused PyTorch path, instead of being turned into 0 or dropped by a plain comparison.
+__device__ __forceinline__ float relu_nan(float v) { return !(v <= 0.f) ? v : 0.f; }
+__device__ __forceinline__ float max_nan(float a, float b) { return (a > b || a != a) ? a : b; }
 
 // y: [HW][C] (channel-last), C % 4 == 0.  One float4 per thread and turn.
 __global__ void __launch_bounds__(256) k_bias_relu_cl(float4 *__restrict__ y, const float4 *__restrict__ bias, long long n4, int C4)
@@ -21,7 +26,7 @@ __global__ void __launch_bounds__(256) k_bias_relu_cl(float4 *__restrict__ y, co
         float4 v = y[i];
         const float4 b = bias[i % C4];
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
         y[i] = v;
     }
 }
@@ -32,7 +37,7 @@ __global__ void __launch_bounds__(256) k_bias_relu_nchw(float *__restrict__ y, c
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float v = y[i] + bias[(i / hw) % C];
-        y[i] = v > 0.f ? v : 0.f;
+        y[i] = relu_nan(v);
     }
 }
 
@@ -44,7 +49,7 @@ __global__ void __launch_bounds__(256) k_bias_relu_nchw4(float4 *__restrict__ y,
         const float b = bias[(i / hw4) % C];
         float4 v = y[i];
         v.x += b; v.y += b; v.z += b; v.w += b;
-        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w);
         y[i] = v;
     }
 }
@@ -65,16 +70,16 @@ __global__ void __launch_bounds__(256) k_bias_relu_pool_nchw(const float *__rest
             const int oh = (int)(r % OH), c = (int)(r / OH);
             const float *r0 = y + ((long long)c * H + 2 * oh) * W + 4 * p;
             const float4 a = *reinterpret_cast<const float4 *>(r0);
-            float m0 = a.x > a.y ? a.x : a.y, m1 = a.z > a.w ? a.z : a.w;
+            float m0 = max_nan(a.x, a.y), m1 = max_nan(a.z, a.w);
             if (2 * oh + 1 < H) {
                 const float4 b4 = *reinterpret_cast<const float4 *>(r0 + W);
-                const float n0 = b4.x > b4.y ? b4.x : b4.y, n1 = b4.z > b4.w ? b4.z : b4.w;
-                m0 = n0 > m0 ? n0 : m0; m1 = n1 > m1 ? n1 : m1;
+                const float n0 = max_nan(b4.x, b4.y), n1 = max_nan(b4.z, b4.w);
+                m0 = max_nan(n0, m0); m1 = max_nan(n1, m1);
             }
             const float b = bias[c];
             m0 += b; m1 += b;
             float2 o;
-            o.x = m0 > 0.f ? m0 : 0.f; o.y = m1 > 0.f ? m1 : 0.f;
+            o.x = relu_nan(m0); o.y = relu_nan(m1);
             *reinterpret_cast<float2 *>(out + ((long long)c * OH + oh) * OW + 2 * p) = o;
         }
     } else {
@@ -87,10 +92,10 @@ __global__ void __launch_bounds__(256) k_bias_relu_pool_nchw(const float *__rest
             const float *r0 = y + ((long long)c * H + h0) * W + w0;
             float m = r0[0];
             const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
-            if (w1) m = r0[1] > m ? r0[1] : m;
-            if (h1) { m = r0[W] > m ? r0[W] : m; if (w1) m = r0[W + 1] > m ? r0[W + 1] : m; }
+            if (w1) m = max_nan(r0[1], m);
+            if (h1) { m = max_nan(r0[W], m); if (w1) m = max_nan(r0[W + 1], m); }
             m += bias[c];
-            out[i] = m > 0.f ? m : 0.f;
+            out[i] = relu_nan(m);
         }
     }
 }
@@ -109,13 +114,13 @@ __global__ void __launch_bounds__(256) k_bias_relu_pool_cl(const float4 *__restr
         const float4 *r0 = y + ((long long)h0 * W + w0) * C4 + c;
         float4 m = r0[0];
         auto mx = [&](const float4 &v) {
-            m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y; m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+            m.x = max_nan(v.x, m.x); m.y = max_nan(v.y, m.y); m.z = max_nan(v.z, m.z); m.w = max_nan(v.w, m.w);
         };
         if (w1) mx(r0[C4]);
         if (h1) { mx(r0[(long long)W * C4]); if (w1) mx(r0[(long long)W * C4 + C4]); }
         const float4 b = bias[c];
         m.x += b.x; m.y += b.y; m.z += b.z; m.w += b.w;
-        m.x = m.x > 0.f ? m.x : 0.f; m.y = m.y > 0.f ? m.y : 0.f; m.z = m.z > 0.f ? m.z : 0.f; m.w = m.w > 0.f ? m.w : 0.f;
+        m.x = relu_nan(m.x); m.y = relu_nan(m.y); m.z = relu_nan(m.z); m.w = relu_nan(m.w);
         out[i] = m;
     }
 }

@@ -75,14 +75,20 @@ class VGG16Conv5(object):
             if fused and (layer[1].shape[0] % 4 == 0 or not self.cl_compute):
                 y = F.conv2d(x, layer[1], None, padding=1)
                 if (y.is_contiguous(memory_format=torch.channels_last) if self.cl_compute else y.is_contiguous()) \
-                        and y.data_ptr() % 16 == 0:
+                        and y.data_ptr() % 16 == 0 and layer[2].data_ptr() % 16 == 0 and layer[2].is_contiguous():
                     from . import ffi
-                    if li + 1 < len(self.layers) and self.layers[li + 1] is None:
-                        x = ffi.bias_relu_pool(y, layer[2])
-                        skip_pool = True
-                    else:
-                        x = ffi.bias_relu_(y, layer[2])
-                    continue
+                    try:
+                        if li + 1 < len(self.layers) and self.layers[li + 1] is None:
+                            x = ffi.bias_relu_pool(y, layer[2])
+                            skip_pool = True
+                        else:
+                            x = ffi.bias_relu_(y, layer[2])
+                        continue
+                    except ffi.AzError as e:
+                        # (a layout the fused kernels decline -- AZ_ERR_INVALID, nothing was written: PyTorch's own ops)
+                        if e.code != ffi.AZ_ERR_INVALID:
+                            raise
+                        skip_pool = False
                 x = F.relu_(y + layer[2].view(1, -1, 1, 1))
                 continue
             x = F.relu_(F.conv2d(x, layer[1], layer[2], padding=1))

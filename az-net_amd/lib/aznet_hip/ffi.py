@@ -347,10 +347,14 @@ class AzContext(object):
             s = cache[int(handle)] = torch.cuda.ExternalStream(int(handle), device=torch.device("cuda", self.device))
         return s
 
-    def wait_event(self, event):
+    def wait_event(self, event, params=None):
         """Make the stream the NEXT launched search runs on wait (on the device, no host synchronisation) for a
-        torch.cuda.Event -- e.g. the one recorded behind the backbone's last kernel on torch's stream."""
-        self._ext(self.L.az_next_stream(self.h)).wait_event(event)
+        torch.cuda.Event -- e.g. the one recorded behind the backbone's last kernel on torch's stream.  params: the
+        parameters that search will be launched with -- searches that cannot be queued (a data-dependent proposal count, the
+        tuner's variant) always run on the context's first lane, whatever lane is next in turn (az_capi.hip: next_lane)."""
+        first_lane = params is not None and (not params.fixed_num or (params.reserved & 4))
+        h = self.L.az_stream(self.h) if first_lane else self.L.az_next_stream(self.h)
+        self._ext(h).wait_event(event)
 
     def set_lanes(self, lanes):
         """2: queued searches take turns between two streams of this context, so consecutive images overlap on the GPU
@@ -394,7 +398,7 @@ class AzContext(object):
             ent = ck[id(fmap)] = (ptr, C, H, W, 1 if cl else 0, weakref.ref(fmap), t.device)
         _, C, H, W, cl, _, dev = ent
         if producer_event is not None:
-            self.wait_event(producer_event)
+            self.wait_event(producer_event, params)
         elif not producer_done:
             import torch
             torch.cuda.current_stream(dev).synchronize()

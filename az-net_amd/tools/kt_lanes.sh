@@ -8,7 +8,7 @@ out=$repo/gpurun_out/$tag
 tools=$repo/az-net_amd/tools
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$repo"
-args="--steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --no-sweep --no-box --no-one-lane --event-every 1000"
+args="--steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --no-sweep --no-stream --no-box --no-one-lane --event-every 1000"
 for lanes in 2 1; do
   d=$out/l$lanes
   mkdir -p "$d"

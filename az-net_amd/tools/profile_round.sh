@@ -22,7 +22,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$repo"
 # the context's one-time measurement of head-pass costs (24 head passes at 48 .. 1408 rows, first launch) is kept out of the
 # per-kernel averages: with AZ_PASS_CAL=0 the form choice goes by the built-in figures (same forms at these workloads)
 export AZ_PASS_CAL=0
-common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-sweep --no-box --no-one-lane"
+common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-sweep --no-stream --no-box --no-one-lane"
 
 run_set() {
   name=$1; args=$2; pfx=$3; period=$4

@@ -95,26 +95,43 @@ FLOOR_NOTE = ("t_min_us_per_image = BASELINE.md section 3: sum over the LEVELS o
 
 
 def cpu_baseline(head, fmap, Tz, budget_s=20.0):
-    """The oracle (kind "port") on the host: NumPy geometry exactly as lib/detect/test.py,
-    C divide_region/RoIPool, BLAS sgemm for the fc head."""
+    """The oracle (kind "port") on the host, as SURVEY 8(d) specifies the CPU baseline: NumPy geometry exactly as
+    lib/detect/test.py (one thread), C divide_region / RoIPool, and the fc head through torch CPU `addmm` with
+    torch.set_num_threads(os.cpu_count()) as the stand-in for Caffe-CPU's sgemm.  Reports the cores used and the sgemm rate
+    that host reaches on the int6 shape, so the figure can be judged."""
+    import torch
     from oracle import az_oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_fc_backend("torch", threads=cores)
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    net = orc.OracleNet(head, feat_fn=lambda d: fmap)
-    cfg = orc.OracleCfg(Tz=Tz)
-    nets = {"full": net, "fc": net}
-    orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)          # warm-up
-    times = []
-    t0 = time.time()
-    while len(times) < 3 or (time.time() - t0 < budget_s and len(times) < 30):
-        t = time.time()
-        orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)
-        times.append(time.time() - t)
-    med = float(np.median(times))
-    return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(cores), "kind": "port",
+        net = orc.OracleNet(head, feat_fn=lambda d: fmap)
+        cfg = orc.OracleCfg(Tz=Tz)
+        nets = {"full": net, "fc": net}
+        orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)          # warm-up
+        times = []
+        t0 = time.time()
+        while len(times) < 3 or (time.time() - t0 < budget_s and len(times) < 30):
+            t = time.time()
+            orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)
+            times.append(time.time() - t)
+        med = float(np.median(times))
+        # the sgemm rate on int6's shape at the last level's row count (517 x 25088 x 4096), best of three
+        x = torch.randn(517, 25088)
+        w = torch.from_numpy(head["W6"])
+        b = torch.from_numpy(head["b6"])
+        best = 1e9
+        for _ in range(3):
+            t = time.time()
+            torch.addmm(b, x, w.t())
+            best = min(best, time.time() - t)
+        sgemm = 2.0 * 517 * 25088 * 4096 / best / 1e9
+        head_flops = 688 * HEAD_FLOP_PER_ROI if Tz <= 0 else None
+    finally:
+        orc.set_fc_backend("numpy")
+    return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(torch.get_num_threads()), "host_cpus": int(cores),
+            "kind": "port", "fc_backend": "torch CPU addmm (torch.set_num_threads(os.cpu_count())); geometry on one thread",
+            "sgemm_gflops_int6_shape": sgemm,
+            "head_gflops_per_image": (head_flops / 1e9) if head_flops else None,
             "sample": "%d images of the same 600x1000 workload at Tz=%g (median %.3f s/image), "
                       "hot path only (conv5_3 given)" % (len(times), Tz, med)}
 

@@ -187,8 +187,34 @@ def fc_plain(x, W, b, relu):
     return y
 
 
+_FC_BACKEND = "numpy"
+
+
+def set_fc_backend(name, threads=None):
+    """Which sgemm stands in for Caffe-CPU's cblas_sgemm in fc(): "numpy" (NumPy's BLAS, the default: what the parity tests
+    were pinned with) or "torch" (torch CPU addmm, its threads set with torch.set_num_threads -- SURVEY 8(d)'s CPU
+    baseline).  Same arithmetic type and layer definition either way; the summation order differs like any two BLAS
+    builds do."""
+    global _FC_BACKEND
+    if name not in ("numpy", "torch"):
+        raise ValueError("fc backend: 'numpy' or 'torch'")
+    if name == "torch":
+        import torch
+        if threads:
+            torch.set_num_threads(int(threads))
+    _FC_BACKEND = name
+
+
 def fc(x, W, b, relu):
     """InnerProduct via BLAS sgemm (stand-in for Caffe-CPU's cblas_sgemm)."""
+    if _FC_BACKEND == "torch":
+        import torch
+        xt = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        y = torch.addmm(torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)), xt,
+                        torch.from_numpy(np.ascontiguousarray(W, dtype=np.float32)).t())
+        if relu:
+            y.clamp_(min=0)
+        return y.numpy()
     y = x.astype(np.float32, copy=False) @ W.T
     y += b
     if relu:

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--noise", action="store_true", help="uniform-noise images (synth.make_image) instead of scenes")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--objects", action="store_true", help="planted-object maps + object head instead of images through the backbone")
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--replay", type=int, default=4, help="images whose same-tree replay is timed for comparison")
     args = ap.parse_args()
@@ -33,15 +34,22 @@ def main():
     H, W = 600, 1000
     dev = torch.device("cuda", 0)
     torch.backends.cudnn.benchmark = True
-    head = synth.make_head(seed=1234, **synth.FULL_DIMS)
-    backbone = VGG16Conv5(device=dev, seed=4321, channels_last_out=True, channels_last_compute=True)
-    net = HipAZNet(head, backbone=backbone, device=0, name="probe", max_regions=4096)
-    net.ctx.set_lanes(args.lanes)
-    mk_im = synth.make_image if args.noise else synth.make_scene_image
-    ims = [mk_im(j, H, W) for j in range(args.images)]
-    blob0, scales = _get_image_blob(synth.make_image(0, H, W), net)
-    backbone.normalize_output(blob0)
-    convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone().contiguous(memory_format=torch.channels_last) for x in ims]
+    if args.objects:
+        head = synth.make_object_head(seed=1234, **synth.FULL_DIMS)
+        net = HipAZNet(head, name="probe", max_regions=4096)
+        net.ctx.set_lanes(args.lanes)
+        convs = [torch.from_numpy(synth.make_object_map(j, 512, 38, 63)).cuda().contiguous(memory_format=torch.channels_last)
+                 for j in range(args.images)]
+    else:
+        head = synth.make_head(seed=1234, **synth.FULL_DIMS)
+        backbone = VGG16Conv5(device=dev, seed=4321, channels_last_out=True, channels_last_compute=True)
+        net = HipAZNet(head, backbone=backbone, device=0, name="probe", max_regions=4096)
+        net.ctx.set_lanes(args.lanes)
+        mk_im = synth.make_image if args.noise else synth.make_scene_image
+        ims = [mk_im(j, H, W) for j in range(args.images)]
+        blob0, scales = _get_image_blob(synth.make_image(0, H, W), net)
+        backbone.normalize_output(blob0)
+        convs = [net.compute_conv(_get_image_blob(x, net)[0]).clone().contiguous(memory_format=torch.channels_last) for x in ims]
     print("map rms:", ["%.2f" % float(c.pow(2).mean().sqrt()) for c in convs[:8]])
     # the tuner's pool over the set (detect.tune.tune_thresh)
     net.ctx.tune_begin(args.images * 2 * net.ctx.max_regions)
@@ -87,10 +95,10 @@ def main():
             forms[ffi.SEARCH_FORMS[int(st.search_form)]] = forms.get(ffi.SEARCH_FORMS[int(st.search_form)], 0) + 1
             reruns += int(st.n_reruns)
         print("== anchors/img %d Tz %.5f: %.4f ms/image over %d images, reruns %d, forms %s" % (a, tz, dt / n * 1e3, n, reruns, forms))
-        for i, st in stats[:args.images] if args.verbose else []:
-            print("   img %2d regions %s passes %s form %d reruns %d" % (
+        for i, st in stats[-args.images:] if args.verbose else []:
+            print("   img %2d regions %s passes %s form %d reruns %d deferred %d" % (
                 i, [int(st.level_regions[l]) for l in range(st.n_levels)], [int(x) for x in list(st.pass_rows)[:int(st.n_passes)]],
-                int(st.search_form), int(st.n_reruns)))
+                int(st.search_form), int(st.n_reruns), int(st.root_deferred)))
         # same-tree replay of a few images (history primed with the image's own tree)
         rep = []
         for i in range(min(args.replay, args.images)):
@@ -98,9 +106,15 @@ def main():
                 stream(prm, [i] * 4)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            stream(prm, [i] * 40)
+            sti = []
+            stream(prm, [i] * 40, sti)
             torch.cuda.synchronize()
             rep.append((time.perf_counter() - t0) / 40 * 1e3)
+            if args.verbose:
+                st = sti[-1][1]
+                print("   replay img %2d %.3f ms regions %s passes %s form %d deferred %d" % (
+                    i, rep[-1], [int(st.level_regions[l]) for l in range(st.n_levels)], [int(x) for x in list(st.pass_rows)[:int(st.n_passes)]],
+                    int(st.search_form), int(st.root_deferred)))
         print("   same-tree replay of images 0..%d: %s ms/image (mean %.4f); stream / replay = %.3f" % (
             len(rep) - 1, ["%.3f" % x for x in rep], float(np.mean(rep)), (dt / n * 1e3) / float(np.mean(rep))))
         trees = {}

@@ -271,3 +271,48 @@ def test_two_lanes_rerun_with_a_staged_record(mods, kind):
         for b in bufs:
             rec = azdist.unpack_device_record(b.cpu().numpy(), layout, k)
             assert rec is not None and np.array_equal(rec[0], Yw) and np.array_equal(rec[1], Sw), (kind, rnd)
+
+
+@pytest.mark.parametrize("depth", [3, 4])
+@pytest.mark.parametrize("kind", ["host", "dev_nchw"])
+def test_two_lanes_with_maps_set_on_the_context(mods, depth, kind):
+    """az_set_feature_map_* on the CONTEXT, then az_propose_launch (no map in the call), two lanes, searches queued ahead,
+    every search another map, long dense trees on one lane beside short ones on the other: the context keeps two
+    channel-last copies and writes them in turn, so the second lane takes a private copy of a map it is handed that way --
+    a lane-1 search that is fetched (or even starts) after the context has seen two more maps must still read ITS map."""
+    import torch
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    H, W, scale = 600, 1000, 1.0
+    C = synth.SMALL_DIMS["C"]
+    maps = [synth.make_scene_map(200 + i, C, 38, 63) for i in range(10)]
+    ref = HipAZNet(head, name="lanes_ctxmap_ref")
+    ref.set_conv(maps[0])
+    z = np.sort(ref.ctx.head_forward(np.hstack([np.zeros((8, 1)), ref.ctx.divide_region(
+        np.array([[0.0, 0.0, W - 1.0, H - 1.0]]), 10.0) * scale]).astype(np.float32))[0].ravel())
+    hi = float(0.5 * (z[-1] + 1.0))                        # nearly every tree ends with the root's children
+    # dense trees (Tz = 0, level by level) on the odd positions = the second lane, sparse ones on the first
+    seq = [(i % len(maps), 0.0 if i % 2 == 1 else hi) for i in range(24)]
+    want = []
+    for mi, tz in seq:
+        ref.set_conv(maps[mi])
+        want.append(ref.propose(ffi.AzContext.make_params(H, W, scale, tz, static_tree=False), want_scores=True))
+    net = HipAZNet(head, name="lanes_ctxmap")
+    net.ctx.set_lanes(2)
+    tmaps = [torch.from_numpy(m).cuda() for m in maps] if kind == "dev_nchw" else None
+
+    def launch(j):
+        mi, tz = seq[j]
+        if kind == "host":
+            net.set_conv(maps[mi])                        # az_set_feature_map_host
+        else:
+            net.set_conv(tmaps[mi], wait=False)           # az_set_feature_map_dev_async: the transpose is only enqueued
+        net.ctx.propose_launch(ffi.AzContext.make_params(H, W, scale, tz, static_tree=False))
+    got, launched = [], 0
+    for i in range(len(seq)):
+        while launched < min(len(seq), i + depth):
+            launch(launched)
+            launched += 1
+        got.append(net.ctx.propose_fetch(want_scores=True))
+    for i, ((Y, S), (Yw, Sw)) in enumerate(zip(got, want)):
+        assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (i, seq[i])

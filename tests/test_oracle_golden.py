@@ -264,3 +264,25 @@ def test_top_k_reproduces_the_reference_argsort():
         cut = neg[indA[n - 1]]
         assert set(ind[neg[ind] < cut]) == set(indA[:n][neg[indA[:n]] < cut])
         assert np.array_equal(Yall[indA[:n]], Y)
+
+
+def test_fc_backends_agree():
+    """The CPU baseline's sgemm (torch CPU addmm) and the NumPy BLAS the fixtures were pinned with give the same
+    head within fp32 summation noise; the backend switch restores itself."""
+    from aznet_hip import synth
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    fmap = synth.make_feature_map(5, synth.SMALL_DIMS["C"], 24, 32)
+    rng = np.random.RandomState(1)
+    x1, y1 = rng.uniform(0, 400, 40), rng.uniform(0, 300, 40)
+    rois = np.stack([np.zeros(40), x1, y1, x1 + rng.uniform(8, 100, 40), y1 + rng.uniform(8, 80, 40)], 1).astype(np.float32)
+    a = orc.head_forward(head, fmap[0], rois)
+    orc.set_fc_backend("torch", threads=2)
+    try:
+        b = orc.head_forward(head, fmap[0], rois)
+    finally:
+        orc.set_fc_backend("numpy")
+    c = orc.head_forward(head, fmap[0], rois)
+    for u, v, w in zip(a, b, c):
+        assert np.abs(u - v).max() <= 1e-5 and np.array_equal(u, w)
+    with pytest.raises(ValueError):
+        orc.set_fc_backend("mkl")
