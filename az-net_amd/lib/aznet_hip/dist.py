@@ -143,6 +143,11 @@ class DeviceGather(object):
         # a process group of ONE rank still runs the collective (RCCL on the one GPU) unless told otherwise: the
         # single-GPU run then exercises the code path the 8-GPU run takes
         self.collective = dist.is_initialized() if always_collective is None else bool(always_collective)
+        # a "gloo" process group (several ranks sharing one GPU, a box without RCCL: the control plane only) cannot gather
+        # device tensors: the staged records still land in the HBM send buffer device-to-device, one copy brings the
+        # batch to the host and the all-gather runs on host tensors
+        self.host_collective = (dist.is_initialized() and dist.get_backend(group) == "gloo"
+                                and torch.device(device).type == "cuda")
         self.layout = ffi.AzContext.result_record_layout(self.k)
         self.rec_bytes = self.layout[0]
         self.device = device
@@ -188,6 +193,12 @@ class DeviceGather(object):
             self.ctx.gather_records(send.data_ptr(), recv.data_ptr(), self.rows * self.rec_bytes)
             cur.wait_stream(ms)
             return recv, self.world
+        if self.host_collective:
+            import torch
+            hs = send.cpu()                                   # (synchronises torch's current stream: the pad write is in)
+            hr = torch.empty((self.world * self.rows, self.rec_bytes), dtype=torch.uint8)
+            dist.all_gather_into_tensor(hr, hs, group=self.group)
+            return hr, self.world
         if self.world > 1 or self.collective:
             # stage() copies ran on the ctx stream and are complete: az_propose_stage_result_dev re-records the event
             # propose_fetch waits for BEHIND the staging copy, and the caller has fetched every search of the batch.  The
@@ -202,7 +213,8 @@ class DeviceGather(object):
         import torch
         got, w = self._exchange(n_local, buf)
         if not to_host:
-            torch.cuda.current_stream(got.device).synchronize()
+            if got.is_cuda:
+                torch.cuda.current_stream(got.device).synchronize()
             return None
         raw = got.cpu().numpy().reshape(w, self.rows, self.rec_bytes)
         return _interleave(raw, self.rows, lambda rec: unpack_device_record(rec, self.layout, self.k))

@@ -707,8 +707,12 @@ class AzContext(object):
             return blob
         assert tuple(out.shape[-3:]) == (3, oh, ow) and out.is_contiguous() and out.is_cuda
         if stream is not None:
+            # (torch's default stream has the handle 0, which az_image_blob_dev_on reads as "the ctx stream": the default
+            #  stream is named explicitly -- hipStreamLegacy, (hipStream_t)1 -- or the upload and the front-end kernel would
+            #  run on another stream than the backbone that reads the blob)
+            sh = int(stream) or 1
             self._chk(self.L.az_image_blob_dev_on(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float), float(scale),
-                                                  ctypes.c_void_p(out.data_ptr()), oh, ow, ctypes.c_void_p(int(stream))))
+                                                  ctypes.c_void_p(out.data_ptr()), oh, ow, ctypes.c_void_p(sh)))
             return out
         self._chk(self.L.az_image_blob_dev(self.h, _p(im, ctypes.c_uint8), h, w, _p(m, ctypes.c_float),
                                            float(scale), ctypes.c_void_p(out.data_ptr()), oh, ow))

@@ -28,6 +28,9 @@ FLAGS = [
     ("--net", "caffemodel", "AZ-Net weights (.caffemodel / .npz) or synthetic[:seed]", "synthetic", str),
     ("--imdb", "imdb_name", "dataset to test", "synthetic_600x1000_8", str),
     ("--recall", "recall", "also evaluate recall against the imdb's ground truth", None, None),
+    # (extension) several ranks: "nccl" = RCCL over xGMI, one rank per GPU (the production setting); "gloo" = the exchange
+    # over host tensors -- ranks that share a GPU (fewer GPUs than ranks), or a box without a usable RCCL
+    ("--dist-backend", "dist_backend", "torch.distributed backend of a multi-rank run: nccl (default) or gloo", "nccl", str),
 ]
 
 
@@ -38,6 +41,15 @@ def load_net(spec, device, tuned=False):
     if tuned:
         import torch
         torch.backends.cudnn.benchmark = True          # (before the first forward: MIOpen's search per convolution shape)
+    if os.environ.get("AZ_BACKBONE_DETERMINISTIC", "0") not in ("", "0"):
+        # (tests that compare two PROCESSES box for box: MIOpen may otherwise pick convolution algorithms whose summation
+        #  order differs from run to run, which moves conv5_3 by ulps and a box at the MIN_SIDE limit in or out)
+        import torch
+        torch.backends.cudnn.deterministic = True
+        if os.environ["AZ_BACKBONE_DETERMINISTIC"] == "2":
+            # (MIOpen off altogether: PyTorch's own im2col + GEMM convolution -- slow, and the same bits on every run, also when
+            #  processes share the GPU)
+            torch.backends.cudnn.enabled = False
 
     def VGG16Conv5(**kw):
         return _VGG(channels_last_compute=bool(tuned), channels_last_out=bool(tuned), **kw)
@@ -68,8 +80,14 @@ def main():
     if not args.caffemodel.startswith("synthetic"):
         _cli.wait_for(args.caffemodel, args.wait)
     world, rank = _cli.ranks()
-    device = int(os.environ.get("LOCAL_RANK", args.gpu_id)) if world > 1 else args.gpu_id
     import torch
+    device = args.gpu_id
+    if world > 1:
+        # one rank per GPU; with fewer GPUs than ranks (--dist-backend gloo) the ranks take the GPUs in turn
+        n_dev = torch.cuda.device_count()              # (counting devices does not initialise the GPU)
+        device = int(os.environ.get("LOCAL_RANK", args.gpu_id))
+        if args.dist_backend == "gloo" and n_dev > 0:
+            device %= n_dev
     torch.cuda.set_device(device)
     from datasets.factory import get_imdb
     from detect.config import get_output_dir
@@ -99,7 +117,12 @@ def main():
     from utils.timer import Timer
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", device)
-    dist.init_process_group("nccl", device_id=dev)
+    if args.dist_backend == "gloo":
+        dist.init_process_group("gloo")
+    elif args.dist_backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        raise SystemExit("--dist-backend: nccl or gloo")
     n = len(imdb.image_index)
     mine = azdist.shard_indices(n, rank, world)
     rows = (n + world - 1) // world                       # short ranks pad (no image is run twice)
@@ -133,7 +156,7 @@ def main():
             Y = im_propose(nets, im, stage=(lambda j=j: gat.stage(j)) if fixed else None)
             t.toc()
             local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
-    allp = gat.gather(len(mine)) if fixed else azdist.gather_proposals(local, device=dev)
+    allp = gat.gather(len(mine)) if fixed else azdist.gather_proposals(local, device=None if args.dist_backend == "gloo" else dev)
     assert len(allp) == n
     if rank == 0:
         out_dir = get_output_dir(imdb, net)

@@ -332,7 +332,8 @@ int az_image_blob_dev(az_ctx *ctx, const uint8_t *im, int h, int w, const float 
                       double scale, float *blob_dev, int oh, int ow);
 
 /* As az_image_blob_dev, as ONE step of a pipelined harness: the upload and the kernel are only enqueued -- on `stream`
- * (a hipStream_t, e.g. the stream the backbone runs on; NULL: the ctx stream) -- and the call returns; `im` is copied to
+ * (a hipStream_t, e.g. the stream the backbone runs on; NULL: the ctx stream -- the DEFAULT stream, whose handle is also 0, is
+ * passed as hipStreamLegacy, (hipStream_t)1) -- and the call returns; `im` is copied to
  * pinned staging before that, so the caller's array may be reused at once.  Whatever is enqueued on `stream` afterwards
  * (the backbone) finds the blob complete; nothing else is synchronised. */
 int az_image_blob_dev_on(az_ctx *ctx, const uint8_t *im, int h, int w, const float *means, double scale,

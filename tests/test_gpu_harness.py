@@ -246,6 +246,108 @@ def test_prop_az_cli_fresh_process(mods):
         shutil.rmtree(out_root, ignore_errors=True)
 
 
+def test_queued_image_pipeline_reads_its_own_image(mods):
+    """detect.test's queue-ahead halves (_propose_start / _propose_finish: upload + front-end kernel + backbone + search of
+    image i+1 enqueued while image i runs) against the synchronous sequence, with a backbone that really reads the blob (a
+    narrow VGG16).  Regression: the front-end ran on the ctx stream when torch's current stream was the default stream
+    (handle 0 = "ctx stream" to az_image_blob_dev_on), so the backbone could read a blob the front-end had not written yet --
+    the previous image's, when the allocator handed the same block out again."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    from aznet_hip.backbone import VGG16Conv5
+    from detect import config as C
+    from detect import test as T
+    old_tz = C.cfg.SEAR.get("Tz", 0.0)
+    C.cfg_set_mode("Test", 0.0)
+    try:
+        bb = VGG16Conv5(device="cuda:0", seed=11, width_div=32)
+        assert bb.out_channels == synth.SMALL_DIMS["C"]
+        net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), backbone=bb, name="queued_pipeline")
+        ims = [synth.make_scene_image(300 + j, 375, 500) for j in range(6)]
+        bb.normalize_output(T._get_image_blob(ims[0], net)[0])
+        want = []
+        with redirect_stdout(io.StringIO()):
+            for im in ims:
+                blob, _ = T._get_image_blob(im, net)
+                conv = net.compute_conv(blob)
+                want.append((conv.clone(), T.im_propose(net, im)))
+            pend, got = None, []
+            order = list(range(len(ims))) * 6
+            for k in range(len(order) + 1):
+                nxt = T._propose_start(net, ims[order[k]], after=(pend["done"] if pend is not None else None)) if k < len(order) else None
+                if pend is not None:
+                    Y = T._propose_finish(net, pend)
+                    got.append((pend["conv"], Y))
+                pend = nxt
+        for k, (conv, Y) in zip(order, got):
+            assert torch.equal(conv, want[k][0]), "image %d: conv5_3 of the queued pipeline differs" % k
+            assert np.array_equal(Y, want[k][1])
+    finally:
+        C.cfg_set_mode("Test", old_tz)
+
+
+def _run_tool_ranks(world, args, timeout=900):
+    """tools/<args[0]> as `world` fresh ranks under torch.distributed.run on 127.0.0.1 (what the driver does for N > 1)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([TOOLS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(TOOLS, args[0])] + args[1:]
+    return subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("variable_count", [False, True])
+def test_prop_az_cli_two_ranks_equal_one(mods, tmp_path, variable_count):
+    """The multi-rank branch of tools/prop_az.py (shard by image, queue-ahead, staged device records, ONE gather, rank 0
+    writes proposals.pkl) as two fresh ranks sharing this box's GPU (--dist-backend gloo: the exchange over host tensors;
+    RCCL needs a GPU per rank), a ragged image count (7: rank 0 owns 4 images, rank 1 owns 3 and sends a padding record):
+    its proposals.pkl must hold, image by image, exactly the boxes the one-process run writes (test.py:492, 532-535: list
+    order = image order).  variable_count: cfg.SEAR.FIXED_PROPOSAL_NUM off -- host records of a collectively agreed size."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    from detect import config as C
+    base = "cli_ranks_%d_%d" % (os.getpid(), int(variable_count))
+    # (fixed count: full trees, 300 proposals per image; variable count: a threshold that ends most trees early)
+    common = ["--net", "synthetic", "--imdb", "synthetic_600x1000_7", "--tz", "0.35" if variable_count else "0.0",
+              "--def", "x.prototxt", "--def_fc", "y.prototxt"]
+    if variable_count:
+        yml = tmp_path / "var.yml"
+        yml.write_text("SEAR:\n  FIXED_PROPOSAL_NUM: False\n  Tc: 0.6\n")
+        common += ["--cfg", str(yml)]
+    roots = [os.path.join(C.cfg.ROOT_DIR, "output", base + s_) for s_ in ("_w1", "_w2")]
+    try:
+        r1 = _run_tool(["prop_az.py", "--gpu", "0", "--exp", base + "_w1"] + common)
+        assert r1.returncode == 0, r1.stdout[-3000:]
+        r2 = _run_tool_ranks(2, ["prop_az.py", "--exp", base + "_w2", "--dist-backend", "gloo"] + common)
+        assert r2.returncode == 0, r2.stdout[-4000:]
+        props = []
+        for root in roots:
+            pf = os.path.join(root, "synthetic_600x1000_7", "vgg16_az_net_synthetic_1234", "proposals.pkl")
+            assert os.path.exists(pf), (r1.stdout[-1500:], r2.stdout[-1500:])
+            with open(pf, "rb") as f:
+                props.append(pickle.load(f))
+        one, two = props
+        assert sorted(two.keys()) == ["boxes", "recall", "time"] and two["recall"] == 0 and isinstance(two["time"], float)
+        assert len(one["boxes"]) == len(two["boxes"]) == 7
+        counts = set()
+        for i, (a, b) in enumerate(zip(one["boxes"], two["boxes"])):
+            assert a.dtype == b.dtype == np.float64 and a.shape == b.shape, (i, a.shape, b.shape)
+            assert np.array_equal(a, b), "image %d: the two-rank run's boxes differ from the one-process run's" % i
+            counts.add(a.shape[0])
+        if variable_count:
+            assert len(counts) > 1                            # (a data-dependent number of boxes per image)
+        else:
+            assert counts == {300}
+        # every rank printed its own images' lines; rank 0 wrote the file
+        assert r2.stdout.count("proposals, evaluate") == 7 and r2.stdout.count("wrote ") == 1
+    finally:
+        for root in roots:
+            shutil.rmtree(root, ignore_errors=True)
+
+
 # ---------------------------------------------------------------- .caffemodel row (f2)
 def test_caffemodel_files_load_into_the_gpu_head(mods, tmp_path):
     """V1- and V2-format .caffemodel files (written with tests/test_caffemodel.py's protobuf encoder) read by
