@@ -96,12 +96,31 @@ FLOOR_NOTE = ("t_min_us_per_image = BASELINE.md section 3: sum over the LEVELS o
 
 def cpu_baseline(head, fmap, Tz, budget_s=20.0):
     """The oracle (kind "port") on the host, as SURVEY 8(d) specifies the CPU baseline: NumPy geometry exactly as
-    lib/detect/test.py (one thread), C divide_region / RoIPool, and the fc head through torch CPU `addmm` with
-    torch.set_num_threads(os.cpu_count()) as the stand-in for Caffe-CPU's sgemm.  Reports the cores used and the sgemm rate
-    that host reaches on the int6 shape, so the figure can be judged."""
+    lib/detect/test.py (one thread), C divide_region / RoIPool, and the fc head through torch CPU `addmm` as the stand-in for
+    Caffe-CPU's sgemm.  SURVEY names torch.set_num_threads(os.cpu_count()); on a box whose process may not use every logical
+    CPU that setting is several times SLOWER than a moderate one (256 threads: 280 GFLOP/s, 32 threads: 2200 on the round-5
+    boxes), so the thread count is the fastest of a short sweep on int6's shape -- the baseline is not handicapped -- and the
+    sweep is reported with the cores used."""
     import torch
     from oracle import az_oracle as orc
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = ncpu
+    x = torch.randn(517, 25088)
+    w = torch.from_numpy(head["W6"])
+    b = torch.from_numpy(head["b6"])
+    sweep = {}
+    for nt in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+        torch.set_num_threads(nt)
+        best = 1e9
+        for _ in range(3):
+            t = time.time()
+            torch.addmm(b, x, w.t())
+            best = min(best, time.time() - t)
+        sweep[nt] = 2.0 * 517 * 25088 * 4096 / best / 1e9
+    cores = max(sweep, key=lambda k: sweep[k])
     orc.set_fc_backend("torch", threads=cores)
     try:
         net = orc.OracleNet(head, feat_fn=lambda d: fmap)
@@ -115,23 +134,16 @@ def cpu_baseline(head, fmap, Tz, budget_s=20.0):
             orc.im_propose(nets, (H_IM, W_IM), 1.0, cfg)
             times.append(time.time() - t)
         med = float(np.median(times))
-        # the sgemm rate on int6's shape at the last level's row count (517 x 25088 x 4096), best of three
-        x = torch.randn(517, 25088)
-        w = torch.from_numpy(head["W6"])
-        b = torch.from_numpy(head["b6"])
-        best = 1e9
-        for _ in range(3):
-            t = time.time()
-            torch.addmm(b, x, w.t())
-            best = min(best, time.time() - t)
-        sgemm = 2.0 * 517 * 25088 * 4096 / best / 1e9
         head_flops = 688 * HEAD_FLOP_PER_ROI if Tz <= 0 else None
     finally:
         orc.set_fc_backend("numpy")
-    return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(torch.get_num_threads()), "host_cpus": int(cores),
-            "kind": "port", "fc_backend": "torch CPU addmm (torch.set_num_threads(os.cpu_count())); geometry on one thread",
-            "sgemm_gflops_int6_shape": sgemm,
+    return {"value": NUM_PROPOSALS / med, "unit": "proposals/s", "cores": int(cores), "host_cpus": int(ncpu),
+            "cpus_this_process_may_use": int(usable), "kind": "port",
+            "fc_backend": "torch CPU addmm, torch.set_num_threads(cores); geometry on one thread",
+            "sgemm_gflops_int6_shape": sweep[cores],
+            "sgemm_gflops_by_threads": {str(k): v for k, v in sorted(sweep.items())},
             "head_gflops_per_image": (head_flops / 1e9) if head_flops else None,
+            "achieved_head_gflops": (head_flops / 1e9 / med) if head_flops else None,
             "sample": "%d images of the same 600x1000 workload at Tz=%g (median %.3f s/image), "
                       "hot path only (conv5_3 given)" % (len(times), Tz, med)}
 
@@ -1244,8 +1256,30 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
         ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
         fl = t_min_us(ud, int(fmap.size))
         kms, by = kernel_ms(lambda: net.propose(p), 5)
+        # ... and as `value` is measured: searches queued ahead on the context's lanes (throughput; the figure above is one
+        # image at a time, i.e. latency)
+        tmap = torch.from_numpy(fmap).to("cuda:%d" % ctx.device).contiguous(memory_format=torch.channels_last)
+        dq = int(getattr(ctx, "lanes", 1)) + 1
+
+        def queued(k):
+            launched = 0
+            for i in range(k):
+                while launched < min(k, i + dq):
+                    ctx.propose_launch(p, fmap=tmap, producer_done=True)
+                    launched += 1
+                ctx.propose_fetch()
+        queued(6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        queued(n_img)
+        torch.cuda.synchronize()
+        ms_q = (time.perf_counter() - t0) / n_img * 1e3
+        net.set_conv(fmap)
         d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor": floors(std, int(fmap.size), ms * 1e3),
              "path_floor_frac": floors(std, int(fmap.size), ms * 1e3)["frac"],
+             "queued": {"ms_per_image": ms_q, "proposals_per_s": 300e3 / ms_q, "searches_launched_and_unfetched": dq,
+                        "path_floor": floors(std, int(fmap.size), ms_q * 1e3),
+                        "note": "the same searches queued ahead on the context's lanes, as `value` is measured"},
              "kernel_ms_per_image": kms, "rows_per_pass": [int(x) for x in list(std.pass_rows)[:int(std.n_passes)]]}
         if form == "level_loop":
             res["deep_tree"] = dict(d, workload="BASELINE config 4: 800x1200 image (scale 0.75), K = 7, Tz = 0",
