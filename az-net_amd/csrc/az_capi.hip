@@ -40,6 +40,8 @@ int az_destroy(az_ctx *c)
     for (auto &e : c->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+    for (hipEvent_t *e : {&c->ev_h6, &c->ev_i7, &c->ev_s2}) if (*e) { hipEventDestroy(*e); *e = nullptr; }
     clear_events(c);
     for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
     c->event_pool.clear();
@@ -117,6 +119,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         return fail(c, AZ_ERR_INVALID, "az_load_head: n71 + n72 too large for the tail kernel's LDS tile");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    c->s2_live = false; c->i7_live = false; c->part7 = nullptr;
     destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
     free_all(c);
     c->head_loaded = false;
@@ -142,6 +146,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
         A(part, pm > pw ? pm : pw);
     }
     A(h6, R * n6); A(h7, R * d.n7);
+    A(part7, (size_t)c->S7 * R * d.n7);
     if (c->gemm_parts) { A(W6p, (size_t)c->gemm_parts * azk_weight_plane_elems(n6, d.K6)); A(pool5p, (size_t)c->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
         HIPCHK(c, hipMemsetAsync(c->pool5p, 0, (size_t)c->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, c->stream)); }
 #undef A
@@ -227,7 +232,7 @@ static int ensure_feat_copies(az_ctx *c, size_t n)
 
 int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W, bool wait)
 {
-    int rc = check_ready(c, false);
+    int rc = check_ready(c, false, false);
     if (rc) return rc;
     if (!src || C != c->d.C || H <= 0 || W <= 0)
         return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
@@ -270,7 +275,7 @@ int az_set_feature_map_dev_async(az_ctx *c, const float *dev_ptr, int C, int H, 
 
 int az_set_feature_map_dev_nhwc(az_ctx *c, const float *dev_ptr, int C, int H, int W)
 {
-    int rc = check_ready(c, false);
+    int rc = check_ready(c, false, false);
     if (rc) return rc;
     if (!dev_ptr || C != c->d.C || H <= 0 || W <= 0)
         return fail(c, AZ_ERR_INVALID, "feature map: channel count must match the loaded head");
@@ -315,6 +320,7 @@ static int ensure_twin(az_ctx *c)
         A(part, p6 > p7 ? p6 : p7);
     }
     A(h6, R * d.n6); A(h7, R * d.n7);
+    A(part7, (size_t)t->S7 * R * d.n7);
     if (t->gemm_parts) {
         A(pool5p, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
         if (hipMemsetAsync(t->pool5p, 0, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, t->stream) != hipSuccess ||
@@ -354,7 +360,7 @@ void *az_last_stream(az_ctx *c)
 {
     if (!c) return nullptr;
     az_ctx *t = (!c->owner && !c->lane_order.empty() && c->lane_order.back() == 1 && c->twin) ? c->twin : c;
-    return (void *)t->stream;
+    return (void *)(t->last_s ? t->last_s : t->stream);       // (a two-stage search ends on the lane's second stream)
 }
 
 void *az_next_stream(az_ctx *c)
@@ -520,6 +526,9 @@ int az_gather_records(az_ctx *c, const void *send_dev, void *recv_dev, size_t by
         HIPCHK(c, hipEventRecord(c->comm_ev[1], c->twin->stream));
         HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->comm_ev[1], 0));
     }
+    // (two-stage searches stage their records on the lanes' second streams)
+    for (az_ctx *l : {c, c->twin})
+        if (l && l->s2_live && l->ev_s2) HIPCHK(c, hipStreamWaitEvent(c->comm_stream, l->ev_s2, 0));
     std::string why;
     if (azk_rccl_all_gather(c->comm, c->comm_stream, send_dev, recv_dev, bytes_per_rank, &why))
         return fail(c, AZ_ERR_HIP, "az_gather_records: " + why);
@@ -570,6 +579,7 @@ int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap,
     if (!n_out) return AZ_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->cand_n < 0)
         return fail(c, AZ_ERR_STATE, "az_last_candidates: no fetched search, or a later call reused the candidate buffers");
     const int n = c->cand_n;
@@ -604,6 +614,7 @@ int az_set_profiling(az_ctx *c, int on)
         // every slot starts as (first-in = ~0, last-out = 0); a slot is used once between two calls of this function
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
         if (!c->span_ring) HIPCHK(c, hipMalloc((void **)&c->span_ring, (size_t)az_ctx::SPAN_SLOTS * 16));
         std::vector<unsigned long long> init((size_t)az_ctx::SPAN_SLOTS * 2);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
@@ -625,6 +636,7 @@ int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *lev
     if (!c || !n_out) return AZ_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     const int n = (int)c->events.size();
     *n_out = n;
     if (c->event_errors) {

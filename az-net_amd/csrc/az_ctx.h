@@ -148,6 +148,24 @@ struct az_ctx {
     // Two lanes (az_set_lanes): a second stream with its own per-search buffers (`twin`, an az_ctx of its own that shares
     // this context's head weights) takes every other queued search, so that consecutive images overlap on the GPU -- one
     // image's single-workgroup geometry kernels and its small head kernels run beside the other image's GEMM.
+    // Two stages (round 5).  A search whose ONE head pass does not depend on its own geometry -- the whole-tree / closure
+    // pass, the one-pass plan: its rows are a function of the image shape -- is enqueued on two streams: stage 1 = RoIPool +
+    // int6 + slab sum on `stream`, stage 2 = int7 + heads + every geometry kernel + the selection + the result copy on
+    // `stream2`, behind an event.  The next search's stage 1 then does not queue behind this one's single-workgroup geometry
+    // kernels (which cannot get a CU while a lane's int6 holds them all), and this one's MFMA-bound int7 may run beside the
+    // next int6's HBM-bound neighbours (the other image's slab sum and RoIPool) instead of in a slot of its own.
+    //   h6 (slab sum -> int7) is the one buffer both stages touch: ev_h6 orders int7 behind the slab sum, ev_i7 the NEXT
+    //   slab sum behind this int7; int7's slabs live in `part7`, not in `part`.
+    //   ev_s2 = everything enqueued on stream2 so far: whatever is not stage 1 of another two-stage search (a search in
+    //   another form, a plan builder, a unit entry point) makes `stream` wait for it first (join_s2).
+    hipStream_t stream2 = nullptr;
+    hipStream_t gs = nullptr;                 // while a search is being enqueued: where the kernels behind its head pass go (nullptr: `stream`)
+    hipStream_t ts = nullptr;                 // ... and where profiling events are recorded (nullptr: `stream`)
+    hipStream_t last_s = nullptr;             // the stream the search launched last ends on
+    hipEvent_t ev_h6 = nullptr, ev_i7 = nullptr, ev_s2 = nullptr;
+    bool i7_live = false, s2_live = false;
+    int split_env = -1, split_now = 0, async_err = 0;
+    float *part7 = nullptr;                   // int7's split-K slabs [S7][maxR][n7]
     az_ctx *twin = nullptr, *owner = nullptr;
     int lanes = 1, lane_next = 0, last_fetch_lane = 0;
     std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
@@ -234,6 +252,7 @@ struct az_ctx {
         void *stage_dst = nullptr;          // az_propose_stage_result_dev target
         size_t stage_cap = 0;
         int slot = 0;
+        hipStream_t last_s = nullptr;       // the stream the search's last kernels and its result copy are on
         bool copied = false;                // result block already on its way to h_res[slot]
         const float *feat = nullptr;        // the map the search reads (a rerun in another form needs it again)
         int fH = 0, fW = 0;
@@ -397,13 +416,13 @@ struct Timed {
         // a failed event call drops this measurement (and is reported by az_last_kernel_times), never the search
         if (!grab(c, &a)) { on = false; ++c->event_errors; return; }
         if (!grab(c, &b)) { hipEventDestroy(a); on = false; ++c->event_errors; return; }
-        if (hipEventRecord(a, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); on = false; ++c->event_errors; }
+        if (hipEventRecord(a, c->ts ? c->ts : c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); on = false; ++c->event_errors; }
     }
     ~Timed()
     {
-        if (trace()) { const hipError_t e = hipStreamSynchronize(c->stream); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
+        if (trace()) { const hipError_t e = hipStreamSynchronize(c->ts ? c->ts : c->stream); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); }
         if (!on) return;
-        if (hipEventRecord(b, c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); ++c->event_errors; return; }
+        if (hipEventRecord(b, c->ts ? c->ts : c->stream) != hipSuccess) { hipEventDestroy(a); hipEventDestroy(b); ++c->event_errors; return; }
         c->events.push_back({name, level, a, b, -1});
     }
 };
@@ -472,6 +491,8 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
         if (f) c->gemm12_min_rows = atoi(f) > 0 ? atoi(f) : 0x7fffffff;
         c->gemm12_env = 1;
     }
+    const bool split = c->split_now && c->stream2 && c->ev_h6 && c->ev_i7;
+    hipStream_t s2 = split ? c->stream2 : c->stream;
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
                    azk_act_plane_elems(c->maxR, d.K6), c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
@@ -507,15 +528,24 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
               azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part, 1 << 30, ts6);
       } }
     c->profiling = prof_keep;
+    // (h6 is read by the int7 of the previous two-stage search of this context, which may not have run yet)
+    if (c->i7_live) { if (hipStreamWaitEvent(c->stream, c->ev_i7, 0) != hipSuccess) c->async_err = 1; c->i7_live = false; }
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
+    if (split) {
+        // stage 2 from here on: int7 behind the slab sum, everything the caller enqueues behind this pass behind int7
+        if (hipEventRecord(c->ev_h6, c->stream) != hipSuccess || hipStreamWaitEvent(s2, c->ev_h6, 0) != hipSuccess) c->async_err = 1;
+        c->gs = s2; c->ts = s2;
+    }
+    float *p7 = c->part7 ? c->part7 : c->part;
     unsigned long long *ts7 = span_slot("fc7_gemm");
     if (ts7) c->profiling &= ~(1 | 2);
     { Timed t(c, "fc7_gemm", level, 1);
-      azk_fc_gemm(c->stream, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, c->part, 1 << 30, ts7); }
+      azk_fc_gemm(s2, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, p7, 1 << 30, ts7); }
     c->profiling = prof_keep;
+    if (split) { if (hipEventRecord(c->ev_i7, s2) != hipSuccess) c->async_err = 1; c->i7_live = true; }
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
-      azk_tail(c->stream, c->part, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
+      azk_tail(s2, p7, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
                eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side,
                (keep_flags && keys) ? c->key_u : nullptr); }
 }
@@ -546,17 +576,29 @@ void free_plan(az_ctx::StaticPlan *q)
     }
 }
 
+// `stream` waits for everything the context has enqueued on its second stream (stage 2 of two-stage searches): called by
+// whatever touches the per-search buffers and is not stage 1 of another two-stage search.
+void join_s2(az_ctx *c)
+{
+    if (c && c->s2_live && c->stream2 && c->ev_s2) {
+        if (hipStreamWaitEvent(c->stream, c->ev_s2, 0) != hipSuccess) c->async_err = 1;
+        c->i7_live = false;                       // (ev_i7 lies before ev_s2 on that stream)
+    }
+}
+
 int check_geom(az_ctx *c)
 {
     if (!c) return AZ_ERR_INVALID;
+    join_s2(c);
     return ensure_geom(c);
 }
 
-int check_ready(az_ctx *c, bool need_feat)
+int check_ready(az_ctx *c, bool need_feat, bool join = true)
 {
     if (!c) return AZ_ERR_INVALID;
     if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "az_load_head has not been called");
     if (need_feat && !c->feat) return fail(c, AZ_ERR_STATE, "no feature map set");
+    if (join) join_s2(c);
     return AZ_OK;
 }
 

@@ -29,6 +29,7 @@ static double pass_us(const az_ctx *c, double rows)
     else { t = 60.0 + 1.4 * rows; t = t < 92.0 ? 92.0 : t; }
     return t + 50.0;
 }
+static inline hipStream_t geom_stream(const az_ctx *c) { return c->gs ? c->gs : c->stream; }   // (az_ctx.h: two stages)
 constexpr double PASS_OVERHEAD_US = 40.0, LOOKUP_US = 8.0;     // (PASS_OVERHEAD_US: the level's geometry kernel + boundaries)
 constexpr unsigned AZ_TAB_ROOT_HOST = 0x1FFFu;      // (az_geom_dev.h: AZ_TAB_ROOT)
 
@@ -42,6 +43,7 @@ static int calibrate_passes(az_ctx *c)
     if (k.state != 0) return AZ_OK;
     { const char *e = getenv("AZ_PASS_CAL"); if (e && !atoi(e)) { k.state = -1; return AZ_OK; } }
     if (!c->feat || !c->pend.empty() || c->d.H <= 0 || c->d.W <= 0) return AZ_OK;       // (next time)
+    join_s2(c);
     k.state = -1;                                                                      // (any failure below: literals)
     hipStream_t s = c->stream;
     const int sizes[] = {48, 112, 176, 352, 704, 1408};
@@ -245,6 +247,7 @@ static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
             use(e);
             return AZ_OK;
         }
+    join_s2(c);                        // (the pre-pass works in the per-search buffers)
     hipStream_t s = c->stream;
     azk_spec_prepass(s, c->cnt, c->B[0], c->spec_scr_B1[defer], c->child, c->spec_scr_choff[defer], c->spec_scr_urois[defer],
                      p->scale, p->min_side, c->maxR, c->maxCh, p->im_h, p->im_w, defer);
@@ -291,7 +294,7 @@ static int ensure_spec_cache(az_ctx *c, const az_params *p, const SearchPlan &q)
 // Final selection (test.py:392-400): top-k by score, or everything with score >= Tc.
 static void enqueue_select(az_ctx *c, const az_params *p, int nlev, int k)
 {
-    hipStream_t s = c->stream;
+    hipStream_t s = geom_stream(c);
     Timed t(c, "select", nlev);
     if (p->fixed_num)
         azk_topk_full(s, c->Sall, &c->cnt->ytot[nlev], c->maxCand, k, c->sel_idx, &c->cnt->nsel, c->Yall,
@@ -337,6 +340,7 @@ static int ensure_static_plan(az_ctx *c, const az_params *p, int nlev)
     for (auto *q : c->plans)
         if (plan_is_for(*q, p, nlev)) { c->plan = q; q->last_use = ++c->plan_clock; return AZ_OK; }
     c->plan = nullptr;
+    join_s2(c);                        // (the plan is built in the per-search buffers)
     hipStream_t s = c->stream;
     auto give_up = [&]() {
         if (c->nostatic.size() >= 32) c->nostatic.erase(c->nostatic.begin());
@@ -480,6 +484,7 @@ static int build_full_set(az_ctx *c, const az_params *p, int nlev, int variant)
     az_ctx::StaticPlan &k = *c->plan;
     az_ctx::StaticPlan::FullSet &f = k.fs[variant];
     const auto &sp = c->spc[0];
+    join_s2(c);
     hipStream_t s = c->stream;
     auto grab = [&](void **q, size_t bytes) { return hipMalloc(q, bytes + 256) == hipSuccess; };
     auto give_up = [&]() {
@@ -657,8 +662,8 @@ static int enqueue_static(az_ctx *c, const az_params *p, int nlev, int k)
       a.Sout = (float *)((unsigned char *)c->cnt + RES_HDR + (size_t)k * 32);
       // fixed proposal count: the same launch ranks the candidates and writes the top k (params.reserved bit 3
       // keeps the separate selection kernels, for tests)
-      if (p->fixed_num && !(p->reserved & 8) && azk_static_select(c->stream, a)) return AZ_OK;
-      azk_static_candidates(c->stream, a); }
+      if (p->fixed_num && !(p->reserved & 8) && azk_static_select(geom_stream(c), a)) return AZ_OK;
+      azk_static_candidates(geom_stream(c), a); }
     enqueue_select(c, p, nlev, k);
     return AZ_OK;
 }
@@ -727,8 +732,11 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     if (full)
         // the search's ONE head pass: the unique rois of the image shape's full tree (+ the speculative rows the plan
         // lacks), the root last; outputs by row in zoom_s / score_s / delta_s
+    {
         launch_head(c, fp->full_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 1,
                     fp->full_urois, fp->full_ubox, fp->Ufull);
+        s = geom_stream(c);            // (two stages: everything behind the one head pass goes where its int7 went)
+    }
     else if (fused && plan.cut == 2 && !defer_root)
         // early end before the third level: the first 1 + P1 rows of S = [root ; B1 ; children of all of B1]
         launch_head(c, c->spec_U[0] + 1, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
@@ -875,7 +883,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
 // One search enqueued on THIS context's stream (the public az_propose_launch picks the lane first).
 int launch_impl(az_ctx *c, const az_params *p)
 {
-    int rc = check_ready(c, true);
+    int rc = check_ready(c, true, false);          // (whether `stream` waits for the second stream is decided below)
     if (rc) return rc;
     if (!p || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) || p->batch_size <= 0 || !(p->min_side > 0))
         return fail(c, AZ_ERR_INVALID, "az_propose: bad parameters");
@@ -917,10 +925,32 @@ int launch_impl(az_ctx *c, const az_params *p)
     c->last_pair_mask = stat ? 0 : plan_search(c, p, nlev, tune).pair_mask;
     c->last_cut = stat ? 0 : plan_search(c, p, nlev, tune).cut;
     hipStream_t s = c->stream;
+    if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
+    // Two stages (az_ctx.h): a search of ONE head pass whose rows do not depend on its own geometry, on a context that runs
+    // its searches on ONE lane -- measured (round 5, 600x1000 at Tz = 0): one lane 1.20 -> 1.165 ms per image (the next image's
+    // RoIPool + int6 no longer wait for this one's int7, heads and three single-workgroup geometry kernels); with two lanes the
+    // lanes already give that overlap and the split only makes the steps burstier (1.119 -> 1.122 ms), so it is left off there.
+    // AZ_TWO_STAGE=0: never; AZ_TWO_STAGE=2: on two lanes as well (measurements).
+    if (c->split_env < 0) { const char *e = getenv("AZ_TWO_STAGE"); c->split_env = e ? atoi(e) : 1; }
+    const bool one_lane = !c->owner && c->lanes == 1;
+    c->split_now = (c->split_env && (one_lane || c->split_env == 2) && (stat || c->last_full) && p->fixed_num && !c->use_graphs &&
+                    !tune && !Timed::trace()) ? 1 : 0;
+    if (c->split_now && !c->stream2) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_h6, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_i7, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            c->split_now = 0; c->split_env = 0;          // (this device / runtime does not give a second stream: one stage)
+        }
+    }
+    if (!c->split_now) join_s2(c);                       // every kernel of this search goes to `stream`, into the per-search buffers
+    c->gs = nullptr; c->ts = nullptr; c->async_err = 0;
     auto enqueue = [&]() { c->npass = 0; prep_scale(c); return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
     // az_set_graphs / AZ_GRAPH=1: capture the launch sequence once per (parameters, feature map) and replay it
     // as a hipGraph.  Every size is read on the device, so the sequence never changes for given parameters.
-    if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
     if (c->use_graphs && !c->profiling && !(tune && c->pool)) {
         // key = the fields themselves (never the struct's bytes: padding is the caller's garbage)
         std::string key;
@@ -979,6 +1009,8 @@ int launch_impl(az_ctx *c, const az_params *p)
         if ((rc = enqueue()) != AZ_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
+    if (c->async_err) { c->gs = nullptr; c->ts = nullptr; c->split_now = 0; return fail(c, AZ_ERR_HIP, "az_propose: a stream / event call of the two-stage search failed"); }
+    s = geom_stream(c);                                  // where the search ends: its result copy follows there
     az_ctx::PendingSearch q;
     q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
     q.full = c->last_full;
@@ -996,6 +1028,10 @@ int launch_impl(az_ctx *c, const az_params *p)
         HIPCHK(c, hipEventRecord(c->ev_res[q.slot], s));
         q.copied = true;
     }
+    q.last_s = s;
+    c->last_s = s;
+    if (c->gs) { HIPCHK(c, hipEventRecord(c->ev_s2, c->stream2)); c->s2_live = true; }
+    c->gs = nullptr; c->ts = nullptr; c->split_now = 0;
     c->slot_busy[q.slot] = true;
     c->pend.push_back(q);
     return AZ_OK;
@@ -1209,10 +1245,12 @@ int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes)
     const size_t bytes = RES_HDR + (size_t)q.p.num_proposals * 36;
     if (!dst_dev || cap_bytes < bytes) return fail(c, AZ_ERR_INVALID, "az_propose_stage_result_dev: destination too small");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpyAsync(dst_dev, c->cnt, bytes, hipMemcpyDeviceToDevice, c->stream));
+    hipStream_t ls = q.last_s ? q.last_s : c->stream;
+    HIPCHK(c, hipMemcpyAsync(dst_dev, c->cnt, bytes, hipMemcpyDeviceToDevice, ls));
     // az_propose_fetch waits for the slot's event: recorded again HERE, behind the staging copy, so that "the record is
     // staged when az_propose_fetch returns" holds (the launch recorded it behind the host copy only)
-    if (q.copied) HIPCHK(c, hipEventRecord(c->ev_res[q.slot], c->stream));
+    if (q.copied) HIPCHK(c, hipEventRecord(c->ev_res[q.slot], ls));
+    if (ls == c->stream2 && c->stream2) HIPCHK(c, hipEventRecord(c->ev_s2, c->stream2));
     q.stage_dst = dst_dev; q.stage_cap = cap_bytes;
     return AZ_OK;
 }

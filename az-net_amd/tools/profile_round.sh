@@ -5,6 +5,7 @@
 #   onelane  the same on one lane (`one_lane`)                                   -> <tag>_onelane_*
 #   twopass  the same with AZ_FULL_SPEC=0 (48-row pass + 670-row pass)          -> <tag>_twopass_*
 #   onepass  the Tz <= 0 one-pass form (`one_pass`)                             -> <tag>_onepass_*
+#   stream   bench.py's stream_tz leg (distinct images at a tuned threshold)          -> <tag>_stream_*
 #   extras   calibrated Tz, deep tree (config 4), shared detection (config 3), az_nms at 100 / 300 / 2000 / 8129 boxes:
 #            the geometry / NMS / detection kernels (k_nms_*, k_divide, k_dedup_*, k_level_geom, k_spec_levels, ...)
 #                                                                               -> <tag>_extras_*
@@ -64,6 +65,9 @@ for s in $sets; do
     # one pass: k_fc_splitk12 (int6, 688 rows), k_fc_splitk (int7) = 2
     onepass) run_set onepass "--steps 100 --warmup 10 $common --no-calibrated --no-level-loop --no-extras --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
     extras)  run_set extras "--steps 10 --warmup 2 $common --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;
+    # stream_tz: distinct images in dataset order at a threshold tuned over the set (the small, weight-streaming-bound passes
+    # of pruned trees: k_fc_splitk at 9 .. ~200 rows, the single-workgroup geometry kernels, the early ends)
+    stream)  run_set stream "--steps 10 --warmup 2 ${common/--no-stream/} --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "stream_" 0 ;;
   esac
 done
 ls -la "$out"
