@@ -41,7 +41,9 @@ int az_destroy(az_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
-    for (hipEvent_t *e : {&c->ev_h6, &c->ev_i7, &c->ev_s2}) if (*e) { hipEventDestroy(*e); *e = nullptr; }
+    if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
+    for (hipEvent_t *e : {&c->ev_h6, &c->ev_i7, &c->ev_s2, &c->ev_tail, &c->ev_s3, &c->ev_geo[0], &c->ev_geo[1]})
+        if (*e) { hipEventDestroy(*e); *e = nullptr; }
     clear_events(c);
     for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
     c->event_pool.clear();
@@ -56,7 +58,7 @@ int az_destroy(az_ctx *c)
     for (auto &e : c->spec_store) for (void *q2 : {(void *)e.urois, (void *)e.B1, (void *)e.choff, (void *)e.Udev}) if (q2) hipFree(q2);
     c->spec_store.clear();
     c->plans.clear();
-    if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
+    if (c->feat_owned[0]) { for (float *f : c->feat_owned) hipFree(f); hipFree(c->feat_stage); }
     for (void *p : {c->ev_a, c->ev_b, c->ev_c, c->ev_d, c->ev_e, c->ev_f, c->ev_g, c->ev_h, (void *)c->hisB,
                     (void *)c->hisZ, (void *)c->pool, (void *)c->pool_tmp, (void *)c->pool_n, (void *)c->pool_hist})
         if (p) hipFree(p);
@@ -120,7 +122,9 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     c->s2_live = false; c->i7_live = false; c->part7 = nullptr;
+    c->s3_live = false; c->g_live[0] = c->g_live[1] = false;
     destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
     free_all(c);
     c->head_loaded = false;
@@ -220,11 +224,11 @@ static int ensure_feat_copies(az_ctx *c, size_t n)
     if (n <= c->feat_owned_elems) return AZ_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->twin) HIPCHK(c, hipStreamSynchronize(c->twin->stream));      // (a lane may be copying out of the old buffers)
-    if (c->feat_owned[0]) { hipFree(c->feat_owned[0]); hipFree(c->feat_owned[1]); hipFree(c->feat_stage); }
-    c->feat_owned[0] = c->feat_owned[1] = c->feat_stage = nullptr; c->feat_owned_elems = 0;
+    if (c->feat_owned[0]) { for (float *f : c->feat_owned) hipFree(f); hipFree(c->feat_stage); }
+    for (float *&f : c->feat_owned) f = nullptr;
+    c->feat_stage = nullptr; c->feat_owned_elems = 0;
     ++c->feat_gen;
-    HIPCHK(c, hipMalloc((void **)&c->feat_owned[0], n * 4));
-    HIPCHK(c, hipMalloc((void **)&c->feat_owned[1], n * 4));
+    for (float *&f : c->feat_owned) HIPCHK(c, hipMalloc((void **)&f, n * 4));
     HIPCHK(c, hipMalloc((void **)&c->feat_stage, n * 4));
     c->feat_owned_elems = n;
     return AZ_OK;
@@ -248,7 +252,7 @@ int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C,
         nchw = c->feat_stage;
     }
     // RoIPool reads the map channel-last: one transpose per image, outside the level loop.
-    c->feat_turn ^= 1;
+    c->feat_turn = (c->feat_turn + 1) % az_ctx::NFEAT;
     azk_nchw_to_nhwc(c->stream, nchw, c->feat_owned[c->feat_turn], C, H * W);
     if (wait) HIPCHK(c, hipStreamSynchronize(c->stream));      // the caller may now reuse / free `src`
     c->feat = c->feat_owned[c->feat_turn];
@@ -393,10 +397,10 @@ static int launch_routed(az_ctx *c, const az_params *p, const float *dev_map, in
         if (!t->ev_hand) HIPCHK(c, hipEventCreateWithFlags(&t->ev_hand, hipEventDisableTiming));
         HIPCHK(c, hipEventRecord(t->ev_hand, c->stream));
         HIPCHK(c, hipStreamWaitEvent(t->stream, t->ev_hand, 0));
-        if (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]) {
+        if (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1] || c->feat == c->feat_owned[2]) {
             const size_t n = (size_t)c->d.C * c->d.H * c->d.W;
             if ((rc = ensure_feat_copies(t, n)) != AZ_OK) { c->err = t->err; return rc; }
-            t->feat_turn ^= 1;
+            t->feat_turn = (t->feat_turn + 1) % az_ctx::NFEAT;
             HIPCHK(c, hipMemcpyAsync(t->feat_owned[t->feat_turn], c->feat, n * 4, hipMemcpyDeviceToDevice, t->stream));
             if (!t->ev_copy) HIPCHK(c, hipEventCreateWithFlags(&t->ev_copy, hipEventDisableTiming));
             HIPCHK(c, hipEventRecord(t->ev_copy, t->stream));
@@ -529,6 +533,8 @@ int az_gather_records(az_ctx *c, const void *send_dev, void *recv_dev, size_t by
     // (two-stage searches stage their records on the lanes' second streams)
     for (az_ctx *l : {c, c->twin})
         if (l && l->s2_live && l->ev_s2) HIPCHK(c, hipStreamWaitEvent(c->comm_stream, l->ev_s2, 0));
+    for (az_ctx *l : {c, c->twin})
+        if (l && l->s3_live && l->ev_s3) HIPCHK(c, hipStreamWaitEvent(c->comm_stream, l->ev_s3, 0));
     std::string why;
     if (azk_rccl_all_gather(c->comm, c->comm_stream, send_dev, recv_dev, bytes_per_rank, &why))
         return fail(c, AZ_ERR_HIP, "az_gather_records: " + why);
@@ -580,6 +586,7 @@ int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap,
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     if (c->cand_n < 0)
         return fail(c, AZ_ERR_STATE, "az_last_candidates: no fetched search, or a later call reused the candidate buffers");
     const int n = c->cand_n;
@@ -615,6 +622,7 @@ int az_set_profiling(az_ctx *c, int on)
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+        if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
         if (!c->span_ring) HIPCHK(c, hipMalloc((void **)&c->span_ring, (size_t)az_ctx::SPAN_SLOTS * 16));
         std::vector<unsigned long long> init((size_t)az_ctx::SPAN_SLOTS * 2);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0ull; }
@@ -637,6 +645,7 @@ int az_last_kernel_times(az_ctx *c, char *names_out, float *ms_out, int32_t *lev
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+    if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     const int n = (int)c->events.size();
     *n_out = n;
     if (c->event_errors) {

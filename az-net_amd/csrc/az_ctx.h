@@ -40,9 +40,11 @@ struct az_ctx {
     float *W6 = nullptr, *b6 = nullptr, *W7 = nullptr, *b7 = nullptr, *Wt = nullptr, *bt = nullptr;
     // feature map
     const float *feat = nullptr;        // channel-last copy of the current map (what RoIPool reads)
-    // [H][W][C] copies of NCHW maps, two of them used in turn: the map of a search that is still queued (and might have to
+    // [H][W][C] copies of NCHW maps, three of them used in turn (two until round 5): the map of a search that is still queued (and might have to
     // be run again in another form) survives the hand-over of the next image's map
-    float *feat_owned[2] = {nullptr, nullptr};
+    static constexpr int NFEAT = 3;      // (one per search a lane may have queued: AZ_QUEUE_MAX)
+    static constexpr int AZ_QUEUE_MAX = 3;
+    float *feat_owned[NFEAT] = {nullptr, nullptr, nullptr};
     int feat_turn = 0;
     unsigned feat_gen = 0;              // bumped when the copies are reallocated
     float *feat_stage = nullptr;        // NCHW staging for host uploads
@@ -158,7 +160,15 @@ struct az_ctx {
     //   slab sum behind this int7; int7's slabs live in `part7`, not in `part`.
     //   ev_s2 = everything enqueued on stream2 so far: whatever is not stage 1 of another two-stage search (a search in
     //   another form, a plan builder, a unit entry point) makes `stream` wait for it first (join_s2).
-    hipStream_t stream2 = nullptr;
+    //   The whole-tree / closure form goes one step further (three stages): its geometry kernels + selection + result copy
+    //   run on a THIRD stream behind the heads (ev_tail).  They are single-workgroup kernels that get a CU only between two
+    //   int6 launches; on the second stream they held the NEXT search's int7 back for ~70 us.  The head outputs they read
+    //   (zoom_s / score_s / delta_s) exist twice, used in turn (out_par); ev_geo[p] = the geometry that read set p is done.
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev_tail = nullptr, ev_s3 = nullptr, ev_geo[2] = {nullptr, nullptr};
+    bool s3_live = false, g_live[2] = {false, false};
+    int out_par = 0, three_now = 0;
+    float *zoom_s2 = nullptr, *score_s2 = nullptr, *delta_s2 = nullptr;
     hipStream_t gs = nullptr;                 // while a search is being enqueued: where the kernels behind its head pass go (nullptr: `stream`)
     hipStream_t ts = nullptr;                 // ... and where profiling events are recorded (nullptr: `stream`)
     hipStream_t last_s = nullptr;             // the stream the search launched last ends on
@@ -379,6 +389,7 @@ int ensure_geom(az_ctx *c)
     A(zoom_u, R); A(score_u, R * AZ_NSUB); A(delta_u, R * 4 * AZ_NSUB); A(Sall, CAND);
     A(zr, R); A(csrc, CH); A(choff_all, R); A(srcB[0], R); A(srcB[1], R);
     A(zoom_s, R); A(score_s, R * AZ_NSUB); A(delta_s, R * 4 * AZ_NSUB);
+    A(zoom_s2, R); A(score_s2, R * AZ_NSUB); A(delta_s2, R * 4 * AZ_NSUB);
     for (int i = 0; i < 2; ++i) { A(spec_scr_urois[i], R * 5); A(spec_scr_B1[i], R * 4); A(spec_scr_choff[i], R); }
     A(key_u, R * AZ_NSUB);
     A(choff_pair, R); A(crow, CH > 8192 ? CH : 8192);
@@ -503,6 +514,11 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
         c->events.push_back({name, level, nullptr, nullptr, sl});
         return c->span_ring + 2 * (size_t)sl;
     };
+    // int6 waits for the int7 of the previous two-stage search of this context (the RoIPool above does not): h6, which this
+    // pass's slab sum writes, is that int7's operand -- and an int6 that starts while int7's workgroups still hold CUs runs
+    // with stragglers to its end (one persistent workgroup per CU, work dealt statically: measured 1.13 -> 1.24 ms per image
+    // when the two overlapped)
+    if (c->i7_live) { if (hipStreamWaitEvent(c->stream, c->ev_i7, 0) != hipSuccess) c->async_err = 1; c->i7_live = false; }
     const int prof_keep = c->profiling;
     unsigned long long *ts6 = c->gemm_parts ? nullptr : span_slot("fc6_gemm");
     if (ts6) c->profiling &= ~(1 | 2);                     // (no event pair around a launch that times itself)
@@ -528,8 +544,6 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
               azk_fc_gemm(c->stream, c->pool5, d.K6, c->W6, d.K6, Uptr, c->maxR, d.n6, d.K6, c->S6, c->part, 1 << 30, ts6);
       } }
     c->profiling = prof_keep;
-    // (h6 is read by the int7 of the previous two-stage search of this context, which may not have run yet)
-    if (c->i7_live) { if (hipStreamWaitEvent(c->stream, c->ev_i7, 0) != hipSuccess) c->async_err = 1; c->i7_live = false; }
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
     if (split) {
@@ -544,10 +558,21 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
       azk_fc_gemm(s2, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, p7, 1 << 30, ts7); }
     c->profiling = prof_keep;
     if (split) { if (hipEventRecord(c->ev_i7, s2) != hipSuccess) c->async_err = 1; c->i7_live = true; }
+    const bool three = split && c->three_now && c->stream3 && c->ev_tail;
+    // (three stages: the heads write the output set the geometry of the search before the previous one read)
+    if (three && c->g_live[c->out_par]) {
+        if (hipStreamWaitEvent(s2, c->ev_geo[c->out_par], 0) != hipSuccess) c->async_err = 1;
+        c->g_live[c->out_par] = false;
+    }
     { Timed t(c, "tail", level);       // (finishes int7 as well: slab sum + bias + ReLU while staging its rows)
       azk_tail(s2, p7, c->S7, c->b7, d.n7, c->Wt, c->bt, ubox ? ubox : c->ubox, Uptr, c->maxR, im_h, im_w,
                eps, zoom, score, delta, c->pred_u, keep_flags ? c->keep_u : nullptr, min_side,
                (keep_flags && keys) ? c->key_u : nullptr); }
+    if (three) {
+        // stage 3 from here on: whatever the caller enqueues behind this pass goes to the third stream, behind the heads
+        if (hipEventRecord(c->ev_tail, s2) != hipSuccess || hipStreamWaitEvent(c->stream3, c->ev_tail, 0) != hipSuccess) c->async_err = 1;
+        c->gs = c->stream3; c->ts = c->stream3;
+    }
 }
 
 // Scratch slot `i` of the evaluation entry points, grown to at least `bytes`.
@@ -584,6 +609,7 @@ void join_s2(az_ctx *c)
         if (hipStreamWaitEvent(c->stream, c->ev_s2, 0) != hipSuccess) c->async_err = 1;
         c->i7_live = false;                       // (ev_i7 lies before ev_s2 on that stream)
     }
+    if (c && c->s3_live && c->stream3 && c->ev_s3 && hipStreamWaitEvent(c->stream, c->ev_s3, 0) != hipSuccess) c->async_err = 1;
 }
 
 int check_geom(az_ctx *c)

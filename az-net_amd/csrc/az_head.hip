@@ -1060,7 +1060,10 @@ int azk_fc_split(int K)
     static int big = -1;
     if (big < 0) { const char *e = getenv("AZ_SPLIT_BIG"); big = (e && atoi(e) > 0) ? atoi(e) : 16; }
     if (K >= 16384) return big;
-    if (K >= 2048) return 8;
+    // (AZ_SPLIT_MID: measurements, as AZ_SPLIT_BIG -- int7's chunk count)
+    static int mid = -1;
+    if (mid < 0) { const char *e = getenv("AZ_SPLIT_MID"); mid = (e && atoi(e) > 0) ? atoi(e) : 8; }
+    if (K >= 2048) return mid;
     if (K >= 512) return 2;
     return 1;
 }

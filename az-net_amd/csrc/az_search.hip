@@ -719,6 +719,12 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
     }
     const bool full = plan.full != 0;
     const az_ctx::StaticPlan::FullSet *fp = full ? &c->plan->fs[plan.full - 1] : nullptr;
+    // the head outputs of the speculative / whole-tree pass (three stages: two sets used in turn, az_ctx.h)
+    float *zs = c->zoom_s, *ss = c->score_s, *ds = c->delta_s;
+    if (full && c->three_now) {
+        c->out_par ^= 1;
+        if (c->out_par) { zs = c->zoom_s2; ss = c->score_s2; ds = c->delta_s2; }
+    }
     // inv_index of level l (two buffers by level parity: k_level_geom's candidate-copy workgroup reads level l's while
     // its chain workgroup writes level l+1's)
     auto INV = [&](int l) { return (l & 1) ? c->inv_odd : c->inv; };
@@ -733,19 +739,19 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         // the search's ONE head pass: the unique rois of the image shape's full tree (+ the speculative rows the plan
         // lacks), the root last; outputs by row in zoom_s / score_s / delta_s
     {
-        launch_head(c, fp->full_meta, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false, 1,
+        launch_head(c, fp->full_meta, -1, p->im_h, p->im_w, p->eps, zs, ss, ds, 0.0, false, 1,
                     fp->full_urois, fp->full_ubox, fp->Ufull);
         s = geom_stream(c);            // (two stages: everything behind the one head pass goes where its int7 went)
     }
     else if (fused && plan.cut == 2 && !defer_root)
         // early end before the third level: the first 1 + P1 rows of S = [root ; B1 ; children of all of B1]
-        launch_head(c, c->spec_U[0] + 1, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
+        launch_head(c, c->spec_U[0] + 1, -1, p->im_h, p->im_w, p->eps, zs, ss, ds, 0.0, false,
                     0, c->spec_urois[0], nullptr, 1 + c->spc[0].P1);
     else if (fused)
-        launch_head(c, c->spec_U[defer_root ? 1 : 0], -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s, 0.0, false,
+        launch_head(c, c->spec_U[defer_root ? 1 : 0], -1, p->im_h, p->im_w, p->eps, zs, ss, ds, 0.0, false,
                     0, c->spec_urois[defer_root ? 1 : 0], nullptr, c->spc[defer_root ? 1 : 0].U);
     else if (n_spec)
-        launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, c->zoom_s, c->score_s, c->delta_s);
+        launch_head(c, &c->cnt->specU, -1, p->im_h, p->im_w, p->eps, zs, ss, ds);
     if (fused) {
         Timed t(c, "spec_levels", 0);
         AzFusedArgs a;
@@ -757,7 +763,7 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         a.reset = 1; a.specP1 = c->spc[dslot].P1; a.specCH = c->spc[dslot].CH; a.specU = c->spc[dslot].U;
         a.ubox = c->ubox; a.pred_u = c->pred_u; a.Yall = c->Yall; a.Z = c->Z; a.child = c->child;
         a.zoom_u = c->zoom_u; a.score_u = c->score_u; a.delta_u = c->delta_u; a.Sall = c->Sall;
-        a.zoom_s = c->zoom_s; a.score_s = c->score_s; a.delta_s = c->delta_s;
+        a.zoom_s = zs; a.score_s = ss; a.delta_s = ds;
         a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
         a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = n_spec;
         a.capR = c->maxR; a.capCh = c->maxCh; a.capCand = c->maxCand;
@@ -801,9 +807,9 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
             a.force_root = 1; a.root_row = (defer_root && l == n_spec && !have_v) ? 1 : 0;
             a.lookup_next = full ? 2 : (pair_here ? 1 : 0);
             a.spec_next = (!full && !pair_here && ((plan.pair_mask >> (l + 1)) & 1)) ? 1 : 0;
-            a.delta_u = full ? c->delta_s : c->delta_u; a.choff_all = c->choff_pair; a.choff_next = c->choff_pair; a.crow = c->crow;
+            a.delta_u = full ? ds : c->delta_u; a.choff_all = c->choff_pair; a.choff_next = c->choff_pair; a.crow = c->crow;
             a.stab = full ? fp->htab : nullptr; a.stabT = full ? fp->hT : 0; a.root_row_full = full ? fp->Ufull - 1 : 0;
-            a.score_all = c->score_s; a.zoom_all = c->zoom_s;
+            a.score_all = ss; a.zoom_all = zs;
             a.pred_v = Vp(l + 1); a.score_v = Vs(l + 1); a.zoom_v = Vz(l + 1); a.keep_v = Vk(l + 1); a.key_v = Vy(l + 1);
             a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = c->spatial_scale;
             azk_level_geom(s, a);
@@ -823,13 +829,13 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
         if (full && !have_v && l >= n_spec) {
             // whole-tree speculation, a level on the multi-launch kernels: its outputs by window lookup, chip-wide
             Timed t(c, "full_lookup", l);
-            azk_full_lookup(s, Uptr, c->urois, c->ubox, fp->htab, fp->hT, fp->Ufull - 1, c->spatial_scale, c->delta_s, c->score_s,
-                            c->zoom_s, p->im_h, p->im_w, p->eps, p->min_side, Vp(l), Vs(l), Vz(l), Vk(l), Vy(l), &c->cnt->err);
+            azk_full_lookup(s, Uptr, c->urois, c->ubox, fp->htab, fp->hT, fp->Ufull - 1, c->spatial_scale, ds, ss,
+                            zs, p->im_h, p->im_w, p->eps, p->min_side, Vp(l), Vs(l), Vz(l), Vk(l), Vy(l), &c->cnt->err);
             have_v = true;
         }
         if (l < n_spec) {
             Timed t(c, "spec_lookup", l);
-            azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, c->zoom_s, c->score_s, c->delta_s,
+            azk_spec_lookup(s, l, Uptr, c->index, c->srcB[cur], c->ubox, zs, ss, ds,
                             p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u, c->pred_u);
         } else if (!have_v) {
             launch_head(c, (fused_lv && l <= plan.lv_limit) ? &c->cnt->PR[l] : Uptr, l, p->im_h, p->im_w, p->eps, c->zoom_u, c->score_u, c->delta_u,
@@ -903,7 +909,8 @@ int launch_impl(az_ctx *c, const az_params *p)
         if (k <= 0) return fail(c, AZ_ERR_INVALID, "az_propose: num_proposals must be positive");
         if (k > AZ_TOPK_MAX) return fail(c, AZ_ERR_CAPACITY, "az_propose: num_proposals > 4096");
     }
-    if (c->pend.size() >= 2) return fail(c, AZ_ERR_STATE, "az_propose_launch: two searches are already queued, fetch one first");
+    if ((int)c->pend.size() >= az_ctx::AZ_QUEUE_MAX)
+        return fail(c, AZ_ERR_STATE, "az_propose_launch: three searches are already queued on this lane, fetch one first");
     if (!c->pend.empty() && !(p->fixed_num && c->pend.back().copied))
         return fail(c, AZ_ERR_STATE, "az_propose_launch: queueing a search behind another needs a fixed proposal count for both");
     HIPCHK(c, hipSetDevice(c->device));
@@ -926,11 +933,11 @@ int launch_impl(az_ctx *c, const az_params *p)
     c->last_cut = stat ? 0 : plan_search(c, p, nlev, tune).cut;
     hipStream_t s = c->stream;
     if (c->use_graphs < 0) { const char *e = getenv("AZ_GRAPH"); c->use_graphs = (e && atoi(e)) ? 1 : 0; }
-    // Two stages (az_ctx.h): a search of ONE head pass whose rows do not depend on its own geometry, on a context that runs
-    // its searches on ONE lane -- measured (round 5, 600x1000 at Tz = 0): one lane 1.20 -> 1.165 ms per image (the next image's
-    // RoIPool + int6 no longer wait for this one's int7, heads and three single-workgroup geometry kernels); with two lanes the
-    // lanes already give that overlap and the split only makes the steps burstier (1.119 -> 1.122 ms), so it is left off there.
-    // AZ_TWO_STAGE=0: never; AZ_TWO_STAGE=2: on two lanes as well (measurements).
+    // Stages on streams of their own (az_ctx.h): a search of ONE head pass whose rows do not depend on its own geometry, on a
+    // context that runs its searches on ONE lane -- measured (round 5, 600x1000 at Tz = 0): one lane 1.20 -> 1.15-1.17 ms per
+    // image (the next image's RoIPool + int6 no longer wait for this one's heads and three single-workgroup geometry kernels);
+    // with two lanes the lanes already give that overlap and the split only makes the steps burstier (1.119 -> 1.122 ms), so
+    // it is left off there.  AZ_TWO_STAGE=0: never; 2: on two lanes as well; 4: two stages, never three (measurements).
     if (c->split_env < 0) { const char *e = getenv("AZ_TWO_STAGE"); c->split_env = e ? atoi(e) : 1; }
     const bool one_lane = !c->owner && c->lanes == 1;
     c->split_now = (c->split_env && (one_lane || c->split_env == 2) && (stat || c->last_full) && p->fixed_num && !c->use_graphs &&
@@ -941,11 +948,20 @@ int launch_impl(az_ctx *c, const az_params *p)
         if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_h6, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_i7, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev_s2, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_s3, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_geo[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_geo[1], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
-            c->split_now = 0; c->split_env = 0;          // (this device / runtime does not give a second stream: one stage)
+            c->split_now = 0; c->split_env = 0;          // (this device / runtime does not give the extra streams: one stage)
         }
     }
+    // three stages for the whole-tree / closure form (AZ_TWO_STAGE=4: two stages there as well: measurements)
+    c->three_now = (c->split_now && !stat && c->last_full && c->split_env != 4) ? 1 : 0;
+    // (a two-stage search's second stage works in the buffers a three-stage search's geometry may still be using)
+    if (c->split_now && !c->three_now && c->s3_live && hipStreamWaitEvent(c->stream2, c->ev_s3, 0) != hipSuccess) c->async_err = 1;
     if (!c->split_now) join_s2(c);                       // every kernel of this search goes to `stream`, into the per-search buffers
     c->gs = nullptr; c->ts = nullptr; c->async_err = 0;
     auto enqueue = [&]() { c->npass = 0; prep_scale(c); return stat ? enqueue_static(c, p, nlev, k) : enqueue_search(c, p, K, nlev, k, tune); };
@@ -1009,7 +1025,7 @@ int launch_impl(az_ctx *c, const az_params *p)
         if ((rc = enqueue()) != AZ_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
-    if (c->async_err) { c->gs = nullptr; c->ts = nullptr; c->split_now = 0; return fail(c, AZ_ERR_HIP, "az_propose: a stream / event call of the two-stage search failed"); }
+    if (c->async_err) { c->gs = nullptr; c->ts = nullptr; c->split_now = 0; c->three_now = 0; return fail(c, AZ_ERR_HIP, "az_propose: a stream / event call of the two-stage search failed"); }
     s = geom_stream(c);                                  // where the search ends: its result copy follows there
     az_ctx::PendingSearch q;
     q.p = *p; q.nlev = nlev; q.is_static = c->last_static; q.defer = c->last_defer; q.pair_mask = c->last_pair_mask;
@@ -1017,10 +1033,11 @@ int launch_impl(az_ctx *c, const az_params *p)
     q.cut = c->last_cut;
     q.npass = c->npass;
     q.feat = c->feat; q.fH = c->d.H; q.fW = c->d.W; q.feat_gen = c->feat_gen;
-    q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1]);
+    q.feat_is_copy = c->feat && (c->feat == c->feat_owned[0] || c->feat == c->feat_owned[1] || c->feat == c->feat_owned[2]);
     std::memcpy(q.pass_src, c->pass_src, sizeof(q.pass_src));
     std::memcpy(q.pass_lv, c->pass_lv, sizeof(q.pass_lv));
-    for (q.slot = 0; q.slot < 2 && c->slot_busy[q.slot]; ++q.slot) { }
+    for (q.slot = 0; q.slot < 3 && c->slot_busy[q.slot]; ++q.slot) { }
+    if (q.slot >= 3) return fail(c, AZ_ERR_STATE, "az_propose_launch: no free result slot");
     if (p->fixed_num) {
         // the result block follows the search's kernels in stream order: whatever is enqueued next (the next image's
         // search, a unit call) finds it already on its way to the host
@@ -1031,7 +1048,12 @@ int launch_impl(az_ctx *c, const az_params *p)
     q.last_s = s;
     c->last_s = s;
     if (c->gs) { HIPCHK(c, hipEventRecord(c->ev_s2, c->stream2)); c->s2_live = true; }
-    c->gs = nullptr; c->ts = nullptr; c->split_now = 0;
+    if (c->gs && c->gs == c->stream3) {
+        HIPCHK(c, hipEventRecord(c->ev_s3, c->stream3));
+        HIPCHK(c, hipEventRecord(c->ev_geo[c->out_par], c->stream3));
+        c->s3_live = true; c->g_live[c->out_par] = true;
+    }
+    c->gs = nullptr; c->ts = nullptr; c->split_now = 0; c->three_now = 0;
     c->slot_busy[q.slot] = true;
     c->pend.push_back(q);
     return AZ_OK;
@@ -1120,7 +1142,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         (void)err;
         // (a queue that is full cannot take the rerun: the caller queued ahead, so the oldest other search is collected
         //  only after this one -- make room by running this rerun with the queue drained)
-        if (c->pend.size() >= 2) return fail(c, AZ_ERR_STATE, "az_propose_fetch: no room to rerun a search in another form");
+        if ((int)c->pend.size() >= az_ctx::AZ_QUEUE_MAX) return fail(c, AZ_ERR_STATE, "az_propose_fetch: no room to rerun a search in another form");
         // the rerun reads THIS search's map (a later one may have been handed over since)
         if (q.feat_is_copy && q.feat_gen != c->feat_gen)
             return fail(c, AZ_ERR_STATE, "az_propose_fetch: the queued search has to be rerun but its feature map copy was reallocated");
@@ -1251,6 +1273,7 @@ int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes)
     // staged when az_propose_fetch returns" holds (the launch recorded it behind the host copy only)
     if (q.copied) HIPCHK(c, hipEventRecord(c->ev_res[q.slot], ls));
     if (ls == c->stream2 && c->stream2) HIPCHK(c, hipEventRecord(c->ev_s2, c->stream2));
+    if (ls == c->stream3 && c->stream3) HIPCHK(c, hipEventRecord(c->ev_s3, c->stream3));
     q.stage_dst = dst_dev; q.stage_cap = cap_bytes;
     return AZ_OK;
 }

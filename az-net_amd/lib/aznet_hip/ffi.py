@@ -372,7 +372,7 @@ class AzContext(object):
         synchronisation of torch's current stream (the caller knows the map is complete); producer_event (a
         torch.cuda.Event recorded behind the map's producer) orders the search behind it ON THE DEVICE instead, so the
         host can go on and enqueue the next image's backbone while this search runs.
-        Up to two searches may be launched before the first is fetched (fixed proposal count): the host then enqueues
+        Up to three searches per lane may be launched before the first is fetched (fixed proposal count): the host then enqueues
         the next image's launch sequence while the GPU still works on the current one -- same stream, the searches do not
         overlap on the GPU; propose_fetch returns them oldest first."""
         self._last_params = params
@@ -404,9 +404,9 @@ class AzContext(object):
             torch.cuda.current_stream(dev).synchronize()
         self._chk(self.L.az_propose_launch_on(self.h, ctypes.byref(params), ctypes.c_void_p(ptr), C, H, W, cl))
         self._queued.append(params)
-        # (up to four searches may be queued -- two per lane: their maps stay referenced until they are long fetched)
+        # (up to six searches may be queued -- three per lane: their maps stay referenced until they are long fetched)
         import collections
-        self.__dict__.setdefault("_feat_keep", collections.deque(maxlen=6)).append(fmap)
+        self.__dict__.setdefault("_feat_keep", collections.deque(maxlen=10)).append(fmap)
         self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
 

@@ -661,7 +661,7 @@ def main():
 
         def f(k):
             # (same host pattern as the main loop: `depth` searches launched and unfetched; a context on one lane queues two)
-            dd = min(depth, 2 * int(getattr(cn.ctx, "lanes", 1)))
+            dd = min(depth, 3 * int(getattr(cn.ctx, "lanes", 1)))
             launched = 0
             for i in range(k):
                 while launched < min(k, i + dd):

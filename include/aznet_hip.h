@@ -194,7 +194,7 @@ int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap,
  * stream and a second stream with per-search buffers of its own (the head's weights are shared): while one image's GEMM holds
  * the matrix cores, the other image's single-workgroup geometry kernels and small head kernels run beside it, so a loop that
  * keeps two searches queued gets consecutive images OVERLAPPED on the GPU (~6 % more images per second at 600x1000).  Results,
- * order of az_propose_fetch (oldest first) and every other call are unchanged; a lane queues up to two searches; the
+ * order of az_propose_fetch (oldest first) and every other call are unchanged; a lane queues up to three searches; the
  * synchronous az_propose, the tuner's variant and variable proposal counts stay on the first lane.  Costs the second lane's
  * buffers (pool5, split-K slabs, geometry: ~1.5 GB at max_regions 4096).  Call with nothing queued.
  * az_next_stream: the hipStream_t the NEXT az_propose_launch(_on) will run on (make it wait for the map's producer there);

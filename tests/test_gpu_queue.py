@@ -63,11 +63,13 @@ def test_queue_depth_is_two_and_needs_fixed_counts(mods):
     p = ffi.AzContext.make_params(600, 1000, 1.0, 0.0)
     net.ctx.propose_launch(p, fmap=m)
     net.ctx.propose_launch(p, fmap=m)
+    net.ctx.propose_launch(p, fmap=m)               # (three per lane since round 5: a search's result may trail it by a whole image)
     with pytest.raises(ffi.AzError):
-        net.ctx.propose_launch(p, fmap=m)           # a third one: fetch first
+        net.ctx.propose_launch(p, fmap=m)           # a fourth one: fetch first
     a = net.ctx.propose_fetch(want_scores=True)
     b = net.ctx.propose_fetch(want_scores=True)
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c3 = net.ctx.propose_fetch(want_scores=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], c3[0]) and np.array_equal(a[1], c3[1])
     with pytest.raises(ffi.AzError):
         net.ctx.propose_fetch()
     # a search with a data-dependent proposal count cannot have another queued behind it, nor be queued behind one
@@ -139,7 +141,7 @@ def test_rerun_under_graph_replay_with_a_staged_record(mods, kind):
 def test_two_lanes_equal_one_lane_bit_for_bit(mods, nan_zoom):
     """Same sequence as test_queue_ahead_equals_alternating with az_set_lanes(2): mixed shapes, forms and reruns (NaN zoom
     under the one-pass plan; a level that outgrows the fused kernels), results oldest first, equal to the one-at-a-time
-    context.  Then depth: each lane queues two searches, so four may be pending."""
+    context.  Then depth: each lane queues up to three searches, so six may be pending."""
     import torch
     ffi, synth, HipAZNet = mods
     head = synth.make_head(seed=77, **synth.SMALL_DIMS)
@@ -155,7 +157,7 @@ def test_two_lanes_equal_one_lane_bit_for_bit(mods, nan_zoom):
     net = HipAZNet(head, name="l_two")
     net.ctx.set_lanes(2)
     seq = list(range(len(cases))) * 3
-    for depth in (2, 4):
+    for depth in (2, 4, 6):
         got, q = [], 0
         for j in range(len(seq) + depth - 1):
             if j < len(seq):
