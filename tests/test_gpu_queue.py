@@ -318,3 +318,76 @@ def test_two_lanes_with_maps_set_on_the_context(mods, depth, kind):
         got.append(net.ctx.propose_fetch(want_scores=True))
     for i, ((Y, S), (Yw, Sw)) in enumerate(zip(got, want)):
         assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (i, seq[i])
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_staged_searches_on_one_lane(mods, depth):
+    """One-lane contexts enqueue a search of one head pass in stages on streams of their own (round 5: RoIPool + int6 + slab sum
+    | int7 + heads | geometry + selection + result copy).  A sequence that mixes staged searches (the one-pass plan, the
+    whole-tree pass after two full trees, the closure) with searches in other forms (sparse trees level by level, the plain
+    loop, a data-dependent proposal count), two image shapes, different maps, unit calls in between and records staged for the
+    exchange, queued up to three deep: every result as the one-at-a-time reference gives it."""
+    import torch
+    ffi, synth, HipAZNet = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    C = synth.SMALL_DIMS["C"]
+    shapes = [(600, 1000, 1.0), (375, 500, 1.6)]
+    maps = {}
+    for si, (H, W, sc) in enumerate(shapes):
+        fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+        maps[si] = [synth.make_scene_map(400 + 10 * si + j, C, fh, fw) for j in range(3)]
+    ref = HipAZNet(head, name="staged_ref")
+    net = HipAZNet(head, name="staged")
+    ref.set_conv(maps[0][0])
+    z = np.sort(ref.ctx.head_forward(np.hstack([np.zeros((8, 1)), ref.ctx.divide_region(
+        np.array([[0.0, 0.0, 999.0, 599.0]]), 10.0)]).astype(np.float32))[0].ravel())
+    sparse = float(0.5 * (z[3] + z[4]))
+    mk = ffi.AzContext.make_params
+    kinds = [dict(Tz=0.0),                                            # one-pass plan: two stages
+             dict(Tz=0.0, static_tree=False),                         # level loop, then (history: full trees) the whole-tree pass
+             dict(Tz=0.0, static_tree=False),
+             dict(Tz=0.0, static_tree=False),
+             dict(Tz=sparse, static_tree=False),                      # a pruned tree: other forms, all on the context's stream
+             dict(Tz=0.0, static_tree=False, full_spec="closure"),    # closure pass: three stages
+             dict(Tz=0.0, static_tree=False, full_spec=True),
+             dict(Tz=sparse, static_tree=False, speculate=False, fused=False, fused_levels=False, pair_spec=False, full_spec=False),
+             dict(Tz=0.0)]
+    seq = []
+    for rnd in range(3):
+        for ki, kw in enumerate(kinds):
+            si = (ki + rnd) % 2
+            seq.append((si, (ki + rnd) % 3, kw))
+    want = []
+    for si, mi, kw in seq:
+        H, W, sc = shapes[si]
+        ref.set_conv(maps[si][mi])
+        want.append(ref.propose(mk(H, W, sc, kw["Tz"], static_tree=False, speculate=False, fused=False, fused_levels=False,
+                                   pair_spec=False, full_spec=False, early_end=False), want_scores=True))
+    tmaps = {si: [torch.from_numpy(m).cuda().contiguous(memory_format=torch.channels_last) for m in maps[si]] for si in maps}
+    layout = ffi.AzContext.result_record_layout(300)
+    stage = torch.zeros((len(seq), layout[0]), dtype=torch.uint8, device="cuda")
+    got, launched = [], 0
+    for i in range(len(seq)):
+        while launched < min(len(seq), i + depth):
+            si, mi, kw = seq[launched]
+            H, W, sc = shapes[si]
+            kw2 = dict(kw)
+            tz = kw2.pop("Tz")
+            net.ctx.propose_launch(mk(H, W, sc, tz, **kw2), fmap=tmaps[si][mi], producer_done=True)
+            net.ctx.stage_result(stage[launched].data_ptr(), layout[0])
+            launched += 1
+        got.append(net.ctx.propose_fetch(want_scores=True, want_stats=True))
+        if i % 5 == 4 and launched == i + 1:
+            # a unit call between searches (nothing queued): works in the per-search buffers
+            assert np.array_equal(net.ctx.divide_region(np.array([[0.0, 0.0, 999.0, 599.0]]), 10.0),
+                                  ref.ctx.divide_region(np.array([[0.0, 0.0, 999.0, 599.0]]), 10.0))
+    torch.cuda.synchronize()
+    raw = stage.cpu().numpy()
+    from aznet_hip import dist as azdist
+    forms = set()
+    for i, ((Y, S, st), (Yw, Sw)) in enumerate(zip(got, want)):
+        assert np.array_equal(Y, Yw) and np.array_equal(S, Sw), (i, seq[i][2], int(st.search_form))
+        rec = azdist.unpack_device_record(raw[i], layout, 300)
+        assert np.array_equal(rec[0], Yw) and np.array_equal(rec[1], Sw), ("staged record", i)
+        forms.add(int(st.search_form))
+    assert {2, 3, 4} <= forms, forms                       # the whole-tree pass, the closure pass and the one-pass plan all ran
