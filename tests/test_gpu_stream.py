@@ -151,3 +151,31 @@ def test_stream_of_mixed_shapes_and_densities(mods, anchors):
         fh, fw = _fmap_hw(synth, H, W, sc)
         items.append((H, W, sc, synth.make_scene_map(j, C, fh, fw)))
     _check_set(mods, head, items, anchors, 2, 3)
+
+
+@pytest.mark.parametrize("lanes,depth", [(2, 3), (1, 3)])
+def test_stream_against_the_reference_run_g14(mods, lanes, depth):
+    """g14 (oracle/gen_golden_stream.py): the REFERENCE's own tune_thresh over 12 planted-object images and its own im_propose
+    on each at that threshold (lib/detect/tune.py:318-366, lib/detect/test.py:346-414; head on the CPU).  The GPU tuner finds
+    the reference's threshold; the stream of the 12 images -- queued, two passes -- forwards the reference's number of unique
+    rois at every level of every image and returns its proposals (1e-4-driven tolerances: the reference's head ran on BLAS)."""
+    from helpers import load
+    ffi, synth, HipAZNet, orc = mods
+    g = load("g14_stream.npz")
+    n, H, W, Tz = int(g["n_img"]), int(g["H"]), int(g["W"]), float(g["Tz"])
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    items = [(H, W, 1.0, synth.make_object_map(j, synth.SMALL_DIMS["C"], 38, 63)) for j in range(n)]
+    net = HipAZNet(head, name="g14")
+    net.ctx.set_lanes(lanes)
+    tz_gpu, npool = _tune_on_gpu(ffi, net, items, int(g["anchors_per_img"]))
+    assert npool == int(g["pool_size"]) and abs(tz_gpu - float(g["thresh"])) <= 1e-4, (tz_gpu, float(g["thresh"]))
+    order = list(range(n)) * 2
+    got = _stream(ffi, net, items, Tz, order, depth)
+    for k, (Y, S, st) in zip(order, got):
+        calls = [int(x) for x in g["calls%d" % k]]
+        assert [int(st.level_unique[l]) for l in range(st.n_levels) if st.level_unique[l] > 0] == calls, (k, calls)
+        ref = g["Y%d" % k]
+        assert Y.shape == ref.shape, (k, Y.shape, ref.shape)
+        # every proposal of the reference within reach of one of ours (a tie at the cut may swap the last ones)
+        hit = [np.abs(Y - r).max(axis=1).min() <= 1e-3 for r in ref]
+        assert np.mean(hit) >= 0.97, (k, float(np.mean(hit)))

@@ -286,3 +286,29 @@ def test_fc_backends_agree():
         assert np.abs(u - v).max() <= 1e-5 and np.array_equal(u, w)
     with pytest.raises(ValueError):
         orc.set_fc_backend("mkl")
+
+
+def test_stream_at_the_reference_tuned_threshold_g14():
+    """g14 (oracle/gen_golden_stream.py): the reference's own tune_thresh over 12 planted-object images and its im_propose on
+    every one of them at that threshold.  The oracle's tuner and loop give the same threshold, the same forwards and the same
+    proposals, image by image."""
+    from aznet_hip import synth
+    g = load("g14_stream.npz")
+    n, H, W, Tz = int(g["n_img"]), int(g["H"]), int(g["W"]), float(g["Tz"])
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    maps = [synth.make_object_map(j, synth.SMALL_DIMS["C"], 38, 63) for j in range(n)]
+    lists = []
+    for m in maps:
+        net = orc.OracleNet(head, feat_fn=lambda d, m=m: m)
+        _, Bhis = orc.im_propose_tune({"full": net, "fc": net}, (H, W), 1.0, orc.OracleCfg(Tz=0.0))
+        lists.append(Bhis[:, 4])
+    assert sum(x.size for x in lists) == int(g["pool_size"])
+    assert float(orc.tune_thresh(lists, n * int(g["anchors_per_img"]))) == float(g["thresh"])
+    trees = set()
+    for i, m in enumerate(maps):
+        net = orc.OracleNet(head, feat_fn=lambda d, m=m: m)
+        Y, tr = orc.im_propose({"full": net, "fc": net}, (H, W), 1.0, orc.OracleCfg(Tz=Tz), return_trace=True)
+        assert [sum(f["U"] for f in lv["fwd"]) for lv in tr["levels"]] == [int(x) for x in g["calls%d" % i]]
+        np.testing.assert_allclose(Y, g["Y%d" % i], rtol=1e-6, atol=1e-9)
+        trees.add(tuple(int(x) for x in g["calls%d" % i]))
+    assert len(trees) >= 8                                  # different trees, from the root's children only to five levels
