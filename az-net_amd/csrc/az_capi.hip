@@ -30,11 +30,13 @@ int az_create(int device, az_ctx **out)
 }
 
 static void destroy_twin(az_ctx *c);
+static void destroy_batch(az_ctx *c);
 
 int az_destroy(az_ctx *c)
 {
     if (!c) return AZ_ERR_INVALID;
     destroy_twin(c);
+    destroy_batch(c);
     if (c->comm) { if (c->comm_stream) hipStreamSynchronize(c->comm_stream); azk_rccl_destroy(c->comm); c->comm = nullptr; }
     if (c->comm_stream) { hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
     for (auto &e : c->comm_ev) if (e) { hipEventDestroy(e); e = nullptr; }
@@ -126,6 +128,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     c->s2_live = false; c->i7_live = false; c->part7 = nullptr;
     c->s3_live = false; c->g_live[0] = c->g_live[1] = false;
     destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
+    destroy_batch(c);
     free_all(c);
     c->head_loaded = false;
     {
@@ -260,6 +263,34 @@ int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C,
     return AZ_OK;
 }
 
+// The head buffers of a lane: pool5, split-K slabs, h6, h7 (a second lane has them from the start; a batch slot gets them
+// when one of its searches has to be run again on its own).
+int ensure_lane_head(az_ctx *t)
+{
+    if (!t || t->head_bufs) return AZ_OK;
+    int rc;
+    HIPCHK(t, hipSetDevice(t->device));
+    const size_t R = (size_t)t->maxR;
+    const AzHeadDims &d = t->d;
+#define A(p, n) if ((rc = dalloc(t, &t->p, (n))) != AZ_OK) return rc
+    A(pool5, R * d.K6);
+    {
+        const size_t p6 = (size_t)t->S6 * R * d.n6, p7 = (size_t)t->S7 * R * d.n7;
+        A(part, p6 > p7 ? p6 : p7);
+    }
+    A(h6, R * d.n6); A(h7, R * d.n7);
+    A(part7, (size_t)t->S7 * R * d.n7);
+    if (t->gemm_parts) {
+        A(pool5p, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
+        if (hipMemsetAsync(t->pool5p, 0, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, t->stream) != hipSuccess ||
+            hipMemsetAsync(t->gscale, 0, 4 * sizeof(float), t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess)
+            return fail(t, AZ_ERR_HIP, "lane: clearing the operand planes");
+    }
+#undef A
+    t->head_bufs = true;
+    return AZ_OK;
+}
+
 extern "C" {
 
 int az_set_feature_map_dev(az_ctx *c, const float *dev_ptr, int C, int H, int W)
@@ -300,41 +331,52 @@ static void destroy_twin(az_ctx *c)
     c->lane_next = 0;
 }
 
-// The second lane: an az_ctx with its own stream, staging and per-search buffers that READS this context's weights.
-static int ensure_twin(az_ctx *c)
+// The image slots and pass buffers of the batches this lane has run (az_batch_launch).
+static void destroy_batch(az_ctx *c)
 {
-    if (c->twin) return AZ_OK;
-    if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "two lanes need a loaded head");
+    if (!c) return;
+    auto &B = c->batch;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (az_ctx *t : B.slots) az_destroy(t);
+    B.slots.clear();
+    for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev}) if (q) hipFree(q);
+    if (B.args_host) hipHostFree(B.args_host);
+    B = az_ctx::Batch();
+    c->batch_order.clear();
+    c->batch_next = 0;
+}
+
+// A lane of context c: an az_ctx with its own stream, staging and per-search buffers that READS c's weights.
+static int make_lane(az_ctx *c, az_ctx **out, bool with_head, const char *what)
+{
+    *out = nullptr;
+    if (!c->head_loaded) return fail(c, AZ_ERR_STATE, std::string(what) + " needs a loaded head");
     az_ctx *t = nullptr;
     int rc = az_create(c->device, &t);
-    if (rc) return fail(c, rc, "az_set_lanes: could not create the second lane");
+    if (rc) return fail(c, rc, std::string(what) + ": could not create the lane");
     t->owner = c;
     t->maxR = c->maxR; t->maxCand = c->maxCand; t->maxCh = c->maxCh;
-    auto bail = [&](int code, const char *msg) { c->err = t->err.empty() ? msg : t->err; az_destroy(t); return code; };
-    if ((rc = ensure_geom(t)) != AZ_OK) return bail(rc, "second lane: geometry buffers");
+    auto bail = [&](int code, const char *msg) { c->err = t->err.empty() ? std::string(what) + ": " + msg : t->err; az_destroy(t); return code; };
+    if ((rc = ensure_geom(t)) != AZ_OK) return bail(rc, "geometry buffers");
     t->d = c->d; t->d.H = t->d.W = 0;
     t->S6 = c->S6; t->S7 = c->S7; t->gemm_parts = c->gemm_parts; t->w6_scale = c->w6_scale; t->spatial_scale = c->spatial_scale;
     t->W6 = c->W6; t->b6 = c->b6; t->W7 = c->W7; t->b7 = c->b7; t->Wt = c->Wt; t->bt = c->bt; t->W6p = c->W6p;
-    const size_t R = (size_t)t->maxR;
-    const AzHeadDims &d = t->d;
-#define A(p, n) if ((rc = dalloc(t, &t->p, (n))) != AZ_OK) return bail(rc, "second lane: head buffers")
-    A(pool5, R * d.K6);
-    {
-        const size_t p6 = (size_t)t->S6 * R * d.n6, p7 = (size_t)t->S7 * R * d.n7;
-        A(part, p6 > p7 ? p6 : p7);
-    }
-    A(h6, R * d.n6); A(h7, R * d.n7);
-    A(part7, (size_t)t->S7 * R * d.n7);
-    if (t->gemm_parts) {
-        A(pool5p, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
-        if (hipMemsetAsync(t->pool5p, 0, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, t->stream) != hipSuccess ||
-            hipMemsetAsync(t->gscale, 0, 4 * sizeof(float), t->stream) != hipSuccess || hipStreamSynchronize(t->stream) != hipSuccess)
-            return bail(AZ_ERR_HIP, "second lane: clearing the operand planes");
-    }
-#undef A
+    t->head_bufs = false;
+    if (with_head && (rc = ensure_lane_head(t)) != AZ_OK) return bail(rc, "head buffers");
     t->gemm12_env = c->gemm12_env; t->gemm12_min_rows = c->gemm12_min_rows; t->gemm12_dual_rows = c->gemm12_dual_rows;
     t->head_loaded = true;
     t->profiling = c->profiling; t->use_graphs = c->use_graphs; t->cal = c->cal;
+    *out = t;
+    return AZ_OK;
+}
+
+// The second lane.
+static int ensure_twin(az_ctx *c)
+{
+    if (c->twin) return AZ_OK;
+    az_ctx *t = nullptr;
+    const int rc = make_lane(c, &t, true, "az_set_lanes");
+    if (rc) return rc;
     c->twin = t;
     return AZ_OK;
 }
@@ -444,6 +486,98 @@ int az_propose_fetch(az_ctx *c, double *boxes_out, float *scores_out, int cap, i
     c->last_fetch_lane = lane;
     const int rc = fetch_entry(t, 0, boxes_out, scores_out, cap, n_out, st);
     if (rc && t != c) c->err = t->err;
+    return rc;
+}
+
+// ---- a batch of images in lockstep (az_search.hip: batch_launch_impl) --------------------------------------------------
+static az_ctx *batch_lane(az_ctx *c, int *lane_out, int *rc_out)
+{
+    *lane_out = 0; *rc_out = AZ_OK;
+    if (c->lanes != 2 || c->batch_next == 0) return c;
+    if ((*rc_out = ensure_twin(c)) != AZ_OK) return nullptr;
+    *lane_out = 1;
+    return c->twin;
+}
+
+void *az_batch_next_stream(az_ctx *c)
+{
+    if (!c || c->owner) return c ? (void *)c->stream : nullptr;
+    int lane, rc;
+    az_ctx *L = batch_lane(c, &lane, &rc);
+    return (void *)(L ? L->stream : c->stream);
+}
+
+int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *maps, int C, int H, int W)
+{
+    if (!c || c->owner) return fail(c, AZ_ERR_INVALID, "az_batch_launch: the context itself, not a lane");
+    if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "az_load_head has not been called");
+    if (!p || !maps || n < 1 || n > AZ_BATCH_MAX || C != c->d.C || H <= 0 || W <= 0)
+        return fail(c, AZ_ERR_INVALID, "az_batch_launch: 1 .. AZ_BATCH_MAX maps of the loaded head's channel count");
+    int lane, rc;
+    az_ctx *L = batch_lane(c, &lane, &rc);
+    if (!L) return rc;
+    auto &B = L->batch;
+    if (B.n_live) return fail(c, AZ_ERR_STATE, "az_batch_launch: the lane's previous batch has not been fetched");
+    HIPCHK(c, hipSetDevice(c->device));
+    while ((int)B.slots.size() < n) {
+        az_ctx *t = nullptr;
+        if ((rc = make_lane(c, &t, false, "az_batch_launch")) != AZ_OK) return rc;
+        t->batch_lane = L;
+        B.slots.push_back(t);
+    }
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = B.slots[b];
+        if (t->cal.state == 0 && c->cal.state != 0) t->cal = c->cal;
+        t->profiling = 0; t->use_graphs = 0;
+    }
+    if (L != c) { if (L->cal.state == 0 && c->cal.state != 0) L->cal = c->cal; }
+    int not_taken = 0;
+    rc = batch_launch_impl(L, n, B.slots.data(), p, maps, H, W, &not_taken);
+    if (rc && !not_taken) { if (L != c) c->err = L->err; return rc; }
+    B.lockstep = !not_taken;
+    if (not_taken) {
+        // this shape / these settings: one search per image, each on its slot's own stream, behind whatever the caller made
+        // the batch's stream wait for
+        if (!L->ev_hand) HIPCHK(c, hipEventCreateWithFlags(&L->ev_hand, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(L->ev_hand, L->stream));
+        for (int b = 0; b < n; ++b) {
+            az_ctx *t = B.slots[b];
+            if (!maps[b]) return fail(c, AZ_ERR_INVALID, "az_batch_launch: null map");
+            HIPCHK(c, hipStreamWaitEvent(t->stream, L->ev_hand, 0));
+            t->feat = maps[b]; t->d.H = H; t->d.W = W;
+            if ((rc = launch_impl(t, p)) != AZ_OK) {
+                c->err = t->err;
+                // (the images launched so far are dropped: nothing of this batch can be fetched)
+                for (int q = 0; q < b; ++q) { double bx[4]; int nn; (void)fetch_entry(B.slots[q], 0, bx, nullptr, 0, &nn, nullptr); B.slots[q]->pend.clear(); for (bool &sb : B.slots[q]->slot_busy) sb = false; }
+                return rc;
+            }
+        }
+    }
+    B.n_live = n; B.next_fetch = 0;
+    for (int &r : B.rows_acc) r = 0;
+    c->batch_order.push_back(lane);
+    if (c->lanes == 2) c->batch_next ^= 1;
+    return AZ_OK;
+}
+
+int az_batch_fetch(az_ctx *c, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
+{
+    if (!c || c->owner || c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_batch_fetch without az_batch_launch");
+    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_batch_fetch: bad arguments");
+    const int lane = c->batch_order.front();
+    az_ctx *L = lane ? c->twin : c;
+    if (!L) return fail(c, AZ_ERR_STATE, "az_batch_fetch: the lane is gone");
+    auto &B = L->batch;
+    if (i != B.next_fetch || i >= B.n_live) return fail(c, AZ_ERR_INVALID, "az_batch_fetch: the images of a batch are fetched in order, each once");
+    az_ctx *t = B.slots[i];
+    int rc = t->pend.empty() ? fail(t, AZ_ERR_STATE, "az_batch_fetch: the image's search is not queued") :
+                               fetch_entry(t, 0, boxes_out, scores_out, cap, n_out, st);
+    if (rc) c->err = t->err;
+    if (++B.next_fetch == B.n_live) {
+        if (B.lockstep) for (int l = 0; l < AZ_MAX_LEVELS; ++l) B.rows_hint[l] = B.rows_acc[l];
+        B.n_live = 0; B.next_fetch = 0;
+        c->batch_order.pop_front();
+    }
     return rc;
 }
 

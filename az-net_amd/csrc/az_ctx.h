@@ -177,6 +177,27 @@ struct az_ctx {
     int split_env = -1, split_now = 0, async_err = 0;
     float *part7 = nullptr;                   // int7's split-K slabs [S7][maxR][n7]
     az_ctx *twin = nullptr, *owner = nullptr;
+    // A batch of images searched in lockstep (az_batch_launch; az_search.hip: batch_launch_impl, az_batch.hip).  Held by the
+    // lane whose head buffers the batch's passes run in (the context, or its twin for every other batch when two lanes are
+    // on); every image of the batch has a SLOT: an az_ctx of its own for the tree (regions, counters, candidates, result
+    // slots, history), created without head buffers -- it gets them if one of its searches ever has to be run again alone.
+    struct Batch {
+        std::vector<az_ctx *> slots;
+        int *off = nullptr;                   // device: AzGatherArgs::off_out of the pass being enqueued, [AZ_BATCH_MAX + 2]
+        float *rois_cat = nullptr;            // the pass's rois / anchors / map table
+        double *ubox_cat = nullptr;
+        const float **feats = nullptr;
+        unsigned char *args_dev = nullptr, *args_host = nullptr;   // the geometry kernels' arguments, one block per image and launch
+        size_t args_cap = 0;
+        int n_live = 0, next_fetch = 0;       // images of the batch in flight; the one az_batch_fetch returns next
+        bool lockstep = false;                // false: the batch's images were launched one after the other on their slots
+        int rows_hint[AZ_MAX_LEVELS] = {0};   // rows of the passes of the last fetched batch (which int6 kernel takes a level)
+        int rows_acc[AZ_MAX_LEVELS] = {0};
+    } batch;
+    std::deque<int> batch_order;              // (owner) lanes of the batches in flight, oldest first
+    int batch_next = 0;
+    bool head_bufs = true;                    // false: a batch slot that has not needed pool5 / slabs / h6 / h7 yet
+    az_ctx *batch_lane = nullptr;             // (a batch slot) the lane whose passes its rois ride in
     int lanes = 1, lane_next = 0, last_fetch_lane = 0;
     std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
     hipEvent_t ev_hand = nullptr;             // (in a twin) orders the lane behind the owner's stream when it reads the owner's map
@@ -268,6 +289,7 @@ struct az_ctx {
         int fH = 0, fW = 0;
         unsigned feat_gen = 0;
         bool feat_is_copy = false;          // `feat` is one of the ctx's own channel-last copies (gone if they are reallocated)
+        int batch = 0;                      // 1: an image of a lockstep batch (az_batch_launch)
     };
     std::deque<PendingSearch> pend;
     unsigned char *h_res[3] = {nullptr, nullptr, nullptr};
@@ -654,5 +676,9 @@ bool nms_keep_tagged(const long long *hk, int n, unsigned tag, long spins)
 int launch_impl(az_ctx *c, const az_params *p);
 int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st);
 int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes);
+// n images of one shape in lockstep on lane L (whose head buffers the passes use), image b on slots[b] with map maps[b];
+// AZ_ERR_STATE + *not_taken = 1: this shape / these settings do not take the lockstep form (nothing enqueued)
+int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken);
 // ---- az_capi.hip --------------------------------------------------------------------------------------------------------
 int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W, bool wait = true);
+int ensure_lane_head(az_ctx *t);          // the head buffers of a lane / batch slot created without them

@@ -81,6 +81,16 @@ static __device__ __forceinline__ unsigned score_key(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// A kernel argument block read from device memory at a workgroup-uniform address (the batched geometry kernels: image
+// blockIdx.y's block of an array the host uploaded before the launch): through the constant address space, so that the
+// fields are scalar loads into SGPRs like by-value kernel arguments -- through a generic pointer the compiler keeps every
+// field in VGPRs (k_level_geom_b: 128 VGPRs + spills against 98).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AZ_UNIFORM_ARGS(T, dst, ptr) T dst; __builtin_memcpy(&dst, (const __attribute__((address_space(4))) T *)(uintptr_t)(ptr), sizeof(T))
+#else
+#define AZ_UNIFORM_ARGS(T, dst, ptr) T dst = *(ptr)
+#endif
+
 // A launch's own span on the constant 100 MHz clock (s_memrealtime): thread 0 of every workgroup folds its entry time
 // into ts[0] (min) and its exit time into ts[1] (max); ts == nullptr: nothing.  The host initialises a slot to (~0, 0).
 struct AzSpan {
@@ -164,6 +174,7 @@ struct AzFinalArgs {
     float *Sout;
 };
 void azk_final_select(hipStream_t s, const AzFinalArgs &a);
+void azk_final_select_batch(hipStream_t s, const AzFinalArgs *args_dev, int n);      // image b: args_dev[b], workgroups (*, b)
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u);
 void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src);
 // whole-tree speculation: window table over a plan's rows (root_row gets the marker row), map of the speculative rows
@@ -220,6 +231,7 @@ void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, do
                       float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w,
                       int defer_root);
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a);
+void azk_spec_levels_batch(hipStream_t s, const AzFusedArgs *args_dev, int n);
 
 // ---- launcher (az_level.hip): one level's geometry (and the final selection) in one workgroup ------
 struct AzLevelArgs {
@@ -256,6 +268,29 @@ struct AzLevelArgs {
     int batch, capR, capCh, capCand, force_root;
 };
 void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
+void azk_level_geom_batch(hipStream_t s, const AzLevelArgs *args_dev, int n);
+
+// ---- launchers (az_batch.hip): several images of one shape searched in lockstep, every level's rois in ONE head pass ----
+struct AzGatherArgs {
+    int n, capR;                              // images in the batch; rows the head's buffers hold
+    const int *rows[AZ_BATCH_MAX];            // rows image b forwards in this pass (its counters, or a shape constant)
+    int *err[AZ_BATCH_MAX];                   // its search's error word: nonzero = the image forwards nothing more (NULL: not looked at)
+    const float *rois[AZ_BATCH_MAX];          // its rois [rows][5]
+    const double *ubox[AZ_BATCH_MAX];         // its anchor boxes [rows][4] (NULL: the pass decodes nothing)
+    const float *feat[AZ_BATCH_MAX];          // its channel-last map
+    int *off_out;                             // [AZ_BATCH_MAX + 2]: first row of every image, off_out[n] = off_out[AZ_BATCH_MAX + 1] = rows of the pass
+    float *rois_cat; double *ubox_cat;        // the pass's rois (column 0 = image index: Caffe's roi_batch_ind) and anchors
+    const float **feats_out;                  // device table RoIPool reads the maps from
+};
+struct AzScatterArgs {
+    int n;
+    const int *off;                           // AzGatherArgs::off_out of the pass
+    const float *zoom, *score; const double *pred; const unsigned char *keep; const unsigned *key;   // the head's outputs by row (key may be NULL)
+    float *zoom_d[AZ_BATCH_MAX], *score_d[AZ_BATCH_MAX]; double *pred_d[AZ_BATCH_MAX];
+    unsigned char *keep_d[AZ_BATCH_MAX]; unsigned *key_d[AZ_BATCH_MAX];
+};
+void azk_batch_gather(hipStream_t s, const AzGatherArgs &a);
+void azk_batch_scatter(hipStream_t s, const AzScatterArgs &a);
 
 // ---- launchers (az_head.hip) -----------------------------------------------------------
 // feat_nhwc: the conv map transposed to [H][W][C] (azk_nchw_to_nhwc, once per image);
@@ -265,7 +300,8 @@ void azk_level_geom(hipStream_t s, const AzLevelArgs &a);
 // pool5, for the GEMM on the 16-bit matrix cores (az_head_terms.hip).
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
-                  size_t plane_stride, int parts, int min_strips, int coop_tail = 0, const float *xscale = nullptr);
+                  size_t plane_stride, int parts, int min_strips, int coop_tail = 0, const float *xscale = nullptr,
+                  const float *const *feats = nullptr);     // feats (device table): the map of roi row r is feats[(int)roi[0]]
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
 // rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);

@@ -157,7 +157,7 @@ constexpr int SPEC_PRE = 64;     // rows of the speculative pass whose outputs a
 #endif
 constexpr int NTL = AZ_NTL;         // threads of the fused-levels workgroup: levels 1-3 hold <= a few hundred elements per stage,
                                  // and every stage boundary costs a barrier across all waves
-__global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
+static __device__ __forceinline__ void spec_levels_body(const AzFusedArgs &a)
 {
     __shared__ double sB[2][FL_R * 4];
     __shared__ int ssrc[2][FL_R];
@@ -479,6 +479,10 @@ __global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a)
     }
 }
 
+__global__ void __launch_bounds__(NTL) k_spec_levels(AzFusedArgs a) { spec_levels_body(a); }
+// a batch of images searched in lockstep (az_batch.hip): workgroup (0, b) is image b's, its arguments in device memory
+__global__ void __launch_bounds__(NTL) k_spec_levels_b(const AzFusedArgs *args) { AZ_UNIFORM_ARGS(AzFusedArgs, a, args + blockIdx.y); spec_levels_body(a); }
+
 // ------------------------------------------------------------------------------------------
 void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, double *child, int *choff_all,
                       float *urois, double scale, double min_side, int capR, int capCh, int im_h, int im_w,
@@ -491,4 +495,9 @@ void azk_spec_prepass(hipStream_t s, AzCounts *cnt, double *root, double *B1, do
 void azk_spec_levels(hipStream_t s, const AzFusedArgs &a)
 {
     hipLaunchKernelGGL(k_spec_levels, dim3(1), dim3(NTL), 0, s, a);
+}
+
+void azk_spec_levels_batch(hipStream_t s, const AzFusedArgs *args_dev, int n)
+{
+    hipLaunchKernelGGL(k_spec_levels_b, dim3(1, n), dim3(NTL), 0, s, args_dev);
 }

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                                                   const int *Uptr, float *__restrict__ pool5,
                                                   unsigned short *__restrict__ planes, size_t plane_stride,
                                                   int parts, int min_strips, int coop_tail,
-                                                  const float *__restrict__ xscale)
+                                                  const float *__restrict__ xscale, const float *const *feats)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     __shared__ __attribute__((aligned(16))) float spart[4][512];
@@ -133,6 +133,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
             const int u = item / PP, p = item - u * PP;
             const int ph = p / P, pw = p - ph * P;
             const float *roi = urois + 5 * (size_t)u;
+            // (a batch of images, az_batch.hip: roi[0] is the image's index in the batch -- Caffe's roi_batch_ind)
+            const float *fm = feats ? feats[(int)roi[0]] : feat;
             const int rsw = (int)roundf(roi[1] * spatial_scale);
             const int rsh = (int)roundf(roi[2] * spatial_scale);
             const int rew = (int)roundf(roi[3] * spatial_scale);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
     #pragma unroll
                 for (int j = 0; j < 8; ++j) m[j] = empty ? 0.0f : -FLT_MAX;
                 for (int h = hs; h < he; ++h) {
-                    const float *row = feat + ((size_t)h * d.W + ws) * d.C + cb + lane;
+                    const float *row = fm + ((size_t)h * d.W + ws) * d.C + cb + lane;
                     for (int w = ws; w < we; ++w, row += d.C) {
                         float v[8];
     #pragma unroll
@@ -182,6 +184,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         const int u = item / PP, p = item - u * PP;
         const int ph = p / P, pw = p - ph * P;
         const float *roi = urois + 5 * (size_t)u;
+        const float *fm = feats ? feats[(int)roi[0]] : feat;
         const int rsw = (int)roundf(roi[1] * spatial_scale);
         const int rsh = (int)roundf(roi[2] * spatial_scale);
         const int rew = (int)roundf(roi[3] * spatial_scale);
@@ -210,7 +213,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                 for (int q = 0; q < 4; ++q) {
                     const int ii = min(i + 4 * q, ncell - 1);      // a repeated cell cannot change a max
                     const int hh = ii / nw;
-                    const float *cell = feat + ((size_t)(hs + hh) * d.W + (ws + ii - hh * nw)) * d.C;
+                    const float *cell = fm + ((size_t)(hs + hh) * d.W + (ws + ii - hh * nw)) * d.C;
                     v0[q] = *reinterpret_cast<const float4 *>(cell + c0);
                     v1[q] = *reinterpret_cast<const float4 *>(cell + c1);
                 }
@@ -1029,11 +1032,11 @@ __global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int n
 // --------------------------------------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
                   const int *Uptr, int capU, float *pool5, unsigned short *planes, size_t plane_stride, int parts,
-                  int min_strips, int coop_tail, const float *xscale)
+                  int min_strips, int coop_tail, const float *xscale, const float *const *feats)
 {
     (void)capU;
     hipLaunchKernelGGL(k_roi_pool, dim3(4096), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
-                       planes, plane_stride, parts, min_strips, coop_tail, xscale);
+                       planes, plane_stride, parts, min_strips, coop_tail, xscale, feats);
 }
 
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)

@@ -52,7 +52,7 @@ static_assert(W_TMP2 + LV_C <= W_CHOFF, "pair-speculation sort scratch overlaps 
 #define TREPORT() do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
+static __device__ __forceinline__ void level_geom_body(const AzLevelArgs &a)
 {
 #ifdef AZ_LEVEL_TIMING
     __shared__ unsigned long long ts[32];
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     const int P = cnt->P[l];
     const int U = *a.Uptr;
     const int ybase = cnt->ytot[l];
-    if (cnt->err & 8) return;                              // an earlier fused stage overflowed: the host reruns
+    if (cnt->err & (8 | 2048)) return;                     // an earlier fused stage overflowed (2048: a batch's pass did): the host reruns
     // (an overflow also records the level: the host then keeps the levels before it on the fused kernels)
     if (P > LV_R || U + a.root_row > LV_R) { if (tid == 0 && chain) { atomicOr(&cnt->err, 8); cnt->scratch[5] = l + 1; } return; }
     // the deferred root is the LAST row of this level's head pass (behind any pair-speculation rows)
@@ -377,6 +377,10 @@ __global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a)
     TREPORT();
 }
 
+__global__ void __launch_bounds__(NT) k_level_geom(AzLevelArgs a) { level_geom_body(a); }
+// a batch of images searched in lockstep (az_batch.hip): workgroups (0..1, b) are image b's, its arguments in device memory
+__global__ void __launch_bounds__(NT) k_level_geom_b(const AzLevelArgs *args) { AZ_UNIFORM_ARGS(AzLevelArgs, a, args + blockIdx.y); level_geom_body(a); }
+
 }  // namespace
 
 void azk_level_geom(hipStream_t s, const AzLevelArgs &a)
@@ -384,4 +388,9 @@ void azk_level_geom(hipStream_t s, const AzLevelArgs &a)
     static int two = -1;                 // AZ_LEVEL_WGS=1: one workgroup does both roles (measurements)
     if (two < 0) { const char *e = getenv("AZ_LEVEL_WGS"); two = (e && atoi(e) == 1) ? 0 : 1; }
     hipLaunchKernelGGL(k_level_geom, dim3(two ? 2 : 1), dim3(NT), 0, s, a);
+}
+
+void azk_level_geom_batch(hipStream_t s, const AzLevelArgs *args_dev, int n)
+{
+    hipLaunchKernelGGL(k_level_geom_b, dim3(2, n), dim3(NT), 0, s, args_dev);
 }

@@ -911,6 +911,7 @@ int launch_impl(az_ctx *c, const az_params *p)
     }
     if ((int)c->pend.size() >= az_ctx::AZ_QUEUE_MAX)
         return fail(c, AZ_ERR_STATE, "az_propose_launch: three searches are already queued on this lane, fetch one first");
+    if (!c->head_bufs && (rc = ensure_lane_head(c)) != AZ_OK) return rc;   // (a batch slot searching on its own for the first time)
     if (!c->pend.empty() && !(p->fixed_num && c->pend.back().copied))
         return fail(c, AZ_ERR_STATE, "az_propose_launch: queueing a search behind another needs a fixed proposal count for both");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1106,7 +1107,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         st->spec_rows = h.specU;
         st->root_deferred = q.defer;
         st->static_plan = q.is_static;
-        st->search_form = q.is_static ? 4 : (q.full == 2 ? 3 : (q.full == 1 ? 2 : (q.pair_mask ? 1 : 0)));
+        st->search_form = q.batch ? 5 : (q.is_static ? 4 : (q.full == 2 ? 3 : (q.full == 1 ? 2 : (q.pair_mask ? 1 : 0))));
         st->n_reruns = q.reruns;
         const int *hc = reinterpret_cast<const int *>(&h);
         for (int i = 0; i < q.npass && i < AZ_MAX_LEVELS; ++i) {
@@ -1118,6 +1119,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
             int mask;
             if (lv < 0) {
                 if (q.is_static || q.full) mask = (1 << nlev) - 1;
+                else if (q.batch) mask = 3;                                    // (the root and its children)
                 else mask = (q.cut == 2 ? 3 : 7) & ~(q.defer ? 1 : 0);
             } else {
                 mask = 1 << lv;
@@ -1158,6 +1160,13 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         if (q.stage_dst && (rc2 = stage_impl(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
         return fetch_entry(c, c->pend.size() - 1, boxes_out, scores_out, cap, n_out, st);
     };
+    if (q.batch && c->batch_lane)
+        for (int l = 0; l < nlev; ++l) c->batch_lane->batch.rows_acc[l] += (l < 2) ? (l == 0 ? h.specU : 0) : h.PR[l];
+    if ((h.err & 2048) && q.batch) {
+        // a level of the batch held more rois than the head's buffers take rows: every image of it runs again on its own
+        az_params p2 = q.p;
+        return rerun(p2);
+    }
     if ((h.err & 32) && q.is_static) {
         // a zoom score of the tree is not >= Tz (NaN): the one-pass plan's premise fails for this image -> level loop
         az_params p2 = q.p;
@@ -1275,5 +1284,233 @@ int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes)
     if (ls == c->stream2 && c->stream2) HIPCHK(c, hipEventRecord(c->ev_s2, c->stream2));
     if (ls == c->stream3 && c->stream3) HIPCHK(c, hipEventRecord(c->ev_s3, c->stream3));
     q.stage_dst = dst_dev; q.stage_cap = cap_bytes;
+    return AZ_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// A batch of images of one shape searched in lockstep (include/aznet_hip.h: az_batch_launch; az_batch.hip).
+// Image b's tree lives in slots[b] (an az_ctx of its own); the head passes run in lane L's buffers on L's stream:
+//   pass 0   the root and its children of every image (rows that depend on the image shape only: the first 1 + |B1| rows of
+//            the cached speculative pre-pass), outputs straight into L's zoom_s / score_s / delta_s -- image b's at row
+//            b * (1 + |B1|), a host-known offset; k_spec_levels (two fused levels) of every image in one launch
+//   level l  (l = 2 .. nlev-1) gather of the images' unique rois -> ONE head pass -> scatter -> k_level_geom of every image
+//            in one launch (the last level: k_final_select, which also makes the top-k into the image's result block)
+// then every image's result block on its way to the host, as for a search launched alone.
+namespace {
+
+template <typename T> T *args_at(unsigned char *base, size_t &off, int n)
+{
+    off = (off + 15) & ~(size_t)15;
+    T *p = reinterpret_cast<T *>(base + off);
+    off += sizeof(T) * (size_t)n;
+    return p;
+}
+
+void head_pass_batch(az_ctx *L, const AzHeadDims &d, const int *Mptr, int im_h, int im_w, double eps, float *zoom, float *score,
+                     float *delta, double min_side, bool keep_flags, bool keys, bool many_rows)
+{
+    hipStream_t s = L->stream;
+    azk_roi_pool(s, nullptr, d, L->spatial_scale, L->batch.rois_cat, Mptr, L->maxR, L->pool5, nullptr, 0, 0, 0, 0, nullptr,
+                 L->batch.feats);
+    const bool can12 = (d.n6 / 128) * L->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
+                       azk_fc_chunk(d.K6, L->S6) * L->S6 == d.K6 && azk_fc_chunk(d.K6, L->S6) >= 64 &&
+                       L->gemm12_min_rows < 0x7fffffff;
+    // (only the device knows the row count; both kernels are correct and bit-identical for any: the last batch's rows decide)
+    if (can12 && many_rows)
+        azk_fc_gemm12(s, L->pool5, d.K6, L->W6, d.K6, Mptr, L->maxR, d.n6, d.K6, L->S6, azk_fc_chunk(d.K6, L->S6), L->part, 0, nullptr);
+    else
+        azk_fc_gemm(s, L->pool5, d.K6, L->W6, d.K6, Mptr, L->maxR, d.n6, d.K6, L->S6, L->part, 1 << 30, nullptr);
+    azk_fc_reduce(s, L->part, L->b6, Mptr, L->maxR, d.n6, L->S6, L->h6, d.n6, 1);
+    float *p7 = L->part7 ? L->part7 : L->part;
+    azk_fc_gemm(s, L->h6, d.n6, L->W7, d.n6, Mptr, L->maxR, d.n7, d.n6, L->S7, p7, 1 << 30, nullptr);
+    azk_tail(s, p7, L->S7, L->b7, d.n7, L->Wt, L->bt, L->batch.ubox_cat, Mptr, L->maxR, im_h, im_w, eps, zoom, score, delta,
+             L->pred_u, keep_flags ? L->keep_u : nullptr, min_side, (keep_flags && keys) ? L->key_u : nullptr);
+}
+
+}  // namespace
+
+int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken)
+{
+    *not_taken = 0;
+    int rc = check_ready(L, false, true);          // (join: the passes work in the lane's per-search head buffers)
+    if (rc) return rc;
+    if (!p || n < 1 || n > AZ_BATCH_MAX || !slots || !maps || H <= 0 || W <= 0 || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) ||
+        p->batch_size <= 0 || !(p->min_side > 0))
+        return fail(L, AZ_ERR_INVALID, "az_batch_launch: bad arguments");
+    if (!p->fixed_num || (p->reserved & 4)) return fail(L, AZ_ERR_INVALID, "az_batch_launch: fixed proposal count, not the tuner's variant");
+    const int k = p->num_proposals;
+    if (k <= 0) return fail(L, AZ_ERR_INVALID, "az_batch_launch: num_proposals must be positive");
+    if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
+    const int nlev = num_levels(p->im_h, p->im_w, p->min_side) - 1;
+    auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
+    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts) return skip();
+    if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
+    if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
+        return skip();
+    for (const auto &e : L->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = slots[b];
+        if (!t || !maps[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
+        if (!t->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
+        // (what an image's own reruns have taught its slot about the shape holds for the batch as well)
+        if ((p->im_h == t->nofuse_h && p->im_w == t->nofuse_w) || (p->im_h == t->nofuse_lv_h && p->im_w == t->nofuse_lv_w)) return skip();
+        for (const auto &e : t->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+    }
+    HIPCHK(L, hipSetDevice(L->device));
+    // the shape's pre-pass (B1, the rois of root + B1, counters): cached per shape on the lane
+    {
+        SearchPlan q{};
+        q.fused = true; q.defer_root = false;
+        if ((rc = ensure_spec_cache(L, p, q)) != AZ_OK) return rc;
+        if (L->spc[0].h != p->im_h || L->spc[0].w != p->im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
+    }
+    const int P1 = L->spc[0].P1, rows0 = 1 + P1;
+    if ((size_t)rows0 * n > (size_t)L->maxR) return skip();
+    auto &B = L->batch;
+    hipStream_t s = L->stream;
+    if (!B.off) {
+        HIPCHK(L, hipMalloc((void **)&B.off, (AZ_BATCH_MAX + 2) * sizeof(int)));
+        HIPCHK(L, hipMalloc((void **)&B.rois_cat, (size_t)L->maxR * 5 * sizeof(float)));
+        HIPCHK(L, hipMalloc((void **)&B.ubox_cat, (size_t)L->maxR * 4 * sizeof(double)));
+        HIPCHK(L, hipMalloc((void **)&B.feats, AZ_BATCH_MAX * sizeof(float *)));
+        HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
+    }
+    const size_t need = 64 + ((sizeof(AzFusedArgs) + 16) + (sizeof(AzLevelArgs) + 16) * (size_t)nlev + (sizeof(AzFinalArgs) + 16)) * AZ_BATCH_MAX;
+    if (B.args_cap < need) {
+        if (B.args_dev) { HIPCHK(L, hipStreamSynchronize(s)); hipFree(B.args_dev); hipHostFree(B.args_host); B.args_dev = nullptr; B.args_host = nullptr; B.args_cap = 0; }
+        HIPCHK(L, hipMalloc((void **)&B.args_dev, need));
+        HIPCHK(L, hipHostMalloc((void **)&B.args_host, need));
+        B.args_cap = need;
+    }
+    AzHeadDims d = L->d;
+    d.H = H; d.W = W;
+    // ---- the geometry kernels' arguments, all levels, all images: one block, one copy
+    size_t off = 0;
+    AzFusedArgs *fa = args_at<AzFusedArgs>(B.args_host, off, n);
+    const size_t off_fa = (size_t)((unsigned char *)fa - B.args_host);
+    std::vector<size_t> off_lv(nlev, 0);
+    std::vector<AzLevelArgs *> la(nlev, nullptr);
+    for (int l = 2; l + 1 < nlev; ++l) { la[l] = args_at<AzLevelArgs>(B.args_host, off, n); off_lv[l] = (size_t)((unsigned char *)la[l] - B.args_host); }
+    AzFinalArgs *fin = args_at<AzFinalArgs>(B.args_host, off, n);
+    const size_t off_fin = (size_t)((unsigned char *)fin - B.args_host);
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = slots[b];
+        auto INV = [&](int l) { return (l & 1) ? t->inv_odd : t->inv; };
+        {
+            AzFusedArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.cnt = t->cnt;
+            a.B[0] = t->B[0]; a.B[1] = t->B[1]; a.srcB[0] = t->srcB[0]; a.srcB[1] = t->srcB[1];
+            a.index = t->index; a.inv = INV(2); a.zr = t->zr; a.choff = t->choff; a.csrc = t->csrc;
+            a.choff_all = L->spec_choff[0]; a.specB1 = L->specB1[0];
+            a.reset = 1; a.specP1 = P1; a.specCH = L->spc[0].CH; a.specU = rows0;
+            a.ubox = t->ubox; a.pred_u = t->pred_u; a.Yall = t->Yall; a.Z = t->Z; a.child = t->child;
+            a.zoom_u = t->zoom_u; a.score_u = t->score_u; a.delta_u = t->delta_u; a.Sall = t->Sall;
+            a.zoom_s = L->zoom_s + (size_t)b * rows0; a.score_s = L->score_s + (size_t)b * rows0 * AZ_NSUB;
+            a.delta_s = L->delta_s + (size_t)b * rows0 * 4 * AZ_NSUB;
+            a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
+            a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = 2;
+            a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
+            a.rois = t->rois; a.urois = t->urois; a.next_dedup = 1; a.defer_root = 0; a.cut_next = 0; a.cut_short = 0;
+            a.spec_next = 0; a.choff_next = t->choff_pair; a.crow = t->crow; a.spatial_scale = L->spatial_scale;
+            a.row_map = nullptr; a.root_row = 0; a.stab = nullptr; a.stabT = 0;
+            a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
+            fa[b] = a;
+        }
+        for (int l = 2; l + 1 < nlev; ++l) {
+            AzLevelArgs a;
+            std::memset(&a, 0, sizeof(a));
+            const int cur = l & 1;
+            a.cnt = t->cnt; a.level = l; a.nlev = nlev; a.cut_next = 0;
+            a.B = t->B[cur]; a.Bnext = t->B[cur ^ 1];
+            a.pred_u = t->pred_u; a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.keep_u = t->keep_u; a.Uptr = &t->cnt->U[l];
+            a.urois = t->urois; a.index = t->index; a.inv = INV(l); a.inv_next = INV(l + 1); a.ubox = t->ubox;
+            a.Yall = t->Yall; a.Sall = t->Sall;
+            a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
+            a.batch = p->batch_size; a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
+            a.force_root = 1; a.root_row = 0; a.lookup_next = 0; a.spec_next = 0;
+            a.delta_u = t->delta_u; a.choff_all = t->choff_pair; a.choff_next = t->choff_pair; a.crow = t->crow;
+            a.stab = nullptr; a.stabT = 0; a.root_row_full = 0; a.score_all = t->score_s; a.zoom_all = t->zoom_s;
+            a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
+            a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = L->spatial_scale;
+            la[l][b] = a;
+        }
+        {
+            AzFinalArgs a;
+            std::memset(&a, 0, sizeof(a));
+            const int l = nlev - 1;
+            a.cnt = t->cnt; a.level = l; a.inv = INV(l); a.key_u = t->key_u; a.pred_u = t->pred_u;
+            a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.Yall = t->Yall; a.Sall = t->Sall; a.Tz = p->Tz;
+            a.force_root = 0; a.capCand = t->maxCand; a.k = k;
+            a.Yout = (double *)((unsigned char *)t->cnt + RES_HDR);
+            a.Sout = (float *)((unsigned char *)t->cnt + RES_HDR + (size_t)k * 32);
+            fin[b] = a;
+        }
+    }
+    HIPCHK(L, hipMemcpyAsync(B.args_dev, B.args_host, off, hipMemcpyHostToDevice, s));
+
+    // ---- pass 0: root + B1 of every image
+    AzGatherArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n; g.capR = L->maxR; g.off_out = B.off; g.rois_cat = B.rois_cat; g.ubox_cat = B.ubox_cat; g.feats_out = B.feats;
+    for (int b = 0; b < n; ++b) {
+        g.rows[b] = L->spec_U[0] + 1;                 // (ensure_spec_cache: the pass without the third level's rows)
+        g.err[b] = nullptr;                           // (the image's counters are cleared by k_spec_levels, behind this pass)
+        g.rois[b] = L->spec_urois[0]; g.ubox[b] = nullptr; g.feat[b] = maps[b];
+    }
+    azk_batch_gather(s, g);
+    const int *Mptr = B.off + AZ_BATCH_MAX + 1;
+    head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
+                    rows0 * n >= L->gemm12_dual_rows);
+    azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
+    // ---- the levels
+    for (int l = 2; l < nlev; ++l) {
+        const bool last = l + 1 == nlev;
+        for (int b = 0; b < n; ++b) {
+            az_ctx *t = slots[b];
+            g.rows[b] = &t->cnt->PR[l]; g.err[b] = &t->cnt->err; g.rois[b] = t->urois; g.ubox[b] = t->ubox; g.feat[b] = maps[b];
+        }
+        azk_batch_gather(s, g);
+        head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
+                        B.rows_hint[l] >= L->gemm12_dual_rows);
+        AzScatterArgs sc;
+        std::memset(&sc, 0, sizeof(sc));
+        sc.n = n; sc.off = B.off; sc.zoom = L->zoom_u; sc.score = L->score_u; sc.pred = L->pred_u; sc.keep = L->keep_u;
+        sc.key = last ? L->key_u : nullptr;
+        for (int b = 0; b < n; ++b) {
+            az_ctx *t = slots[b];
+            sc.zoom_d[b] = t->zoom_u; sc.score_d[b] = t->score_u; sc.pred_d[b] = t->pred_u; sc.keep_d[b] = t->keep_u; sc.key_d[b] = t->key_u;
+        }
+        azk_batch_scatter(s, sc);
+        if (!last) azk_level_geom_batch(s, reinterpret_cast<const AzLevelArgs *>(B.args_dev + off_lv[l]), n);
+        else azk_final_select_batch(s, reinterpret_cast<const AzFinalArgs *>(B.args_dev + off_fin), n);
+    }
+    HIPCHK(L, hipGetLastError());
+    // ---- every image's record on its way to the host; the searches enter the slots' queues
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = slots[b];
+        az_ctx::PendingSearch q;
+        q.p = *p; q.nlev = nlev; q.batch = 1;
+        q.npass = 0;
+        q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -rows0 - 1;
+        for (int l = 2; l < nlev; ++l) {
+            q.pass_lv[q.npass] = l;
+            q.pass_src[q.npass++] = (int)(&t->cnt->PR[l] - reinterpret_cast<int *>(t->cnt));
+        }
+        t->feat = maps[b]; t->d.H = H; t->d.W = W;
+        q.feat = maps[b]; q.fH = H; q.fW = W; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
+        for (q.slot = 0; q.slot < 3 && t->slot_busy[q.slot]; ++q.slot) { }
+        if (q.slot >= 3) return fail(L, AZ_ERR_STATE, "az_batch_launch: no free result slot");
+        HIPCHK(L, hipMemcpyAsync(t->h_res[q.slot], t->cnt, RES_HDR + (size_t)k * 36, hipMemcpyDeviceToHost, s));
+        HIPCHK(L, hipEventRecord(t->ev_res[q.slot], s));
+        q.copied = true;
+        q.last_s = s;
+        t->last_s = s;
+        t->cand_n = -1;
+        t->slot_busy[q.slot] = true;
+        t->pend.push_back(q);
+    }
+    L->last_s = s;
     return AZ_OK;
 }

@@ -263,7 +263,7 @@ __device__ __forceinline__ unsigned final_key(const AzFinalArgs &a, int prev, in
 constexpr int FIN_NBC = 48;        // writer workgroups (1024 slots each per turn)
 constexpr int FIN_NBR = 512;       // ranking workgroups (32 slots each per turn)
 
-__global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
+static __device__ __forceinline__ void final_select_body(const AzFinalArgs &a)
 {
     constexpr int nbC = FIN_NBC;
     __shared__ int red[16];
@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
     __shared__ int part[16][SEL_I];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (a.cnt->err & 8) return;        // a fused level overflowed: its outputs are not there, the host reruns the search
+    if (a.cnt->err & (8 | 2048)) return;   // a fused level (2048: a batch's pass) overflowed: its outputs are not there, the host reruns the search
     const int P = a.cnt->P[a.level], prev = a.cnt->ytot[a.level];
     const int Ns = P * AZ_NSUB, Nv = prev + Ns;
     if ((int)blockIdx.x < nbC) {
@@ -386,6 +386,10 @@ __global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a)
     }
 }
 
+__global__ void __launch_bounds__(SC_NT) k_final_select(AzFinalArgs a) { final_select_body(a); }
+// a batch of images searched in lockstep (az_batch.hip): workgroups (*, b) are image b's, its arguments in device memory
+__global__ void __launch_bounds__(SC_NT) k_final_select_b(const AzFinalArgs *args) { AZ_UNIFORM_ARGS(AzFinalArgs, a, args + blockIdx.y); final_select_body(a); }
+
 }  // namespace
 
 void azk_plan_rows(hipStream_t s, const int *inv, const int *Pptr, int capR, int roff, int uoff, int *reg_u)
@@ -406,6 +410,11 @@ bool azk_static_select(hipStream_t s, const AzStaticArgs &a)
 void azk_final_select(hipStream_t s, const AzFinalArgs &a)
 {
     k_final_select<<<dim3(FIN_NBC + 1 + FIN_NBR), dim3(SC_NT), 0, s>>>(a);
+}
+
+void azk_final_select_batch(hipStream_t s, const AzFinalArgs *args_dev, int n)
+{
+    k_final_select_b<<<dim3(FIN_NBC + 1 + FIN_NBR, n), dim3(SC_NT), 0, s>>>(args_dev);
 }
 
 void azk_plan_cands(hipStream_t s, const int *reg_u, int Rtot, int *cand_src)

@@ -35,7 +35,7 @@ SYMBOLS = [
     "az_propose_launch_on", "az_set_feature_map_dev_nhwc", "az_set_pass_costs", "az_get_pass_costs",
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
     "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
-    "az_bias_relu", "az_bias_relu_pool",
+    "az_bias_relu", "az_bias_relu_pool", "az_batch_launch", "az_batch_fetch", "az_batch_next_stream",
 ]
 
 
@@ -61,7 +61,8 @@ class AzStats(ctypes.Structure):
                 ("pass_levels", ctypes.c_int32 * AZ_MAX_LEVELS)]
 
 
-SEARCH_FORMS = {0: "level_loop", 1: "pair_speculation", 2: "whole_tree_pass", 3: "closure_pass", 4: "one_pass_plan"}
+SEARCH_FORMS = {0: "level_loop", 1: "pair_speculation", 2: "whole_tree_pass", 3: "closure_pass", 4: "one_pass_plan",
+                5: "batch_level_loop"}
 
 
 class AzError(RuntimeError):
@@ -149,6 +150,10 @@ def load_library(path=None):
     L.az_next_stream.argtypes = [vp]
     L.az_last_stream.restype = vp
     L.az_last_stream.argtypes = [vp]
+    L.az_batch_next_stream.restype = vp
+    L.az_batch_next_stream.argtypes = [vp]
+    L.az_batch_launch.argtypes = [vp, ci, ctypes.POINTER(AzParams), ctypes.POINTER(vp), ci, ci, ci]
+    L.az_batch_fetch.argtypes = [vp, ci, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
@@ -166,7 +171,8 @@ def load_library(path=None):
     L.az_bias_relu.argtypes = [vp, vp, vp, ci, ctypes.c_longlong, ci]
     L.az_bias_relu_pool.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci]
     for name in SYMBOLS:
-        if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream", "az_comm_stream"):
+        if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream", "az_comm_stream",
+                        "az_batch_next_stream"):
             getattr(L, name).restype = ci
     if path is None:
         _lib = L
@@ -409,6 +415,60 @@ class AzContext(object):
         self.__dict__.setdefault("_feat_keep", collections.deque(maxlen=10)).append(fmap)
         self._feat_keepalive = fmap
         self.feat_shape = (C, H, W)
+
+    # ---- a batch of images in lockstep (az_batch_launch) ------------------------------------------------------------
+    def batch_launch(self, params, fmaps, producer_done=False, producer_event=None):
+        """The images of consecutive iterations of the dataset loop (lib/detect/test.py:508-513), all of ONE shape, searched
+        together: every level's rois of all of them in one head pass (az_batch_launch).  fmaps: CUDA tensors [1,C,H,W] /
+        [C,H,W] on this GPU, one per image (torch.channels_last ones are read where they lie, others are converted by torch);
+        they must stay untouched until the batch's last batch_fetch.  producer_done / producer_event as propose_launch.
+        Results: batch_fetch(i), i = 0 .. len(fmaps)-1 in order; each is what propose gives for that image alone."""
+        import torch
+        maps, ptrs, shape = [], [], None
+        converted = False
+        for f in fmaps:
+            t = f if f.dim() == 4 else f[None]
+            assert t.is_cuda and t.dtype == torch.float32 and t.device.index == self.device and t.shape[0] == 1
+            if not t.is_contiguous(memory_format=torch.channels_last):
+                t = t.contiguous(memory_format=torch.channels_last)
+                converted = True
+            C, H, W = (int(x) for x in t.shape[1:])
+            assert shape in (None, (C, H, W)), "the maps of a batch have one shape"
+            shape = (C, H, W)
+            maps.append(t)
+            ptrs.append(t.data_ptr())
+        C, H, W = shape
+        dev = maps[0].device
+        if producer_event is not None and not converted:
+            self._ext(self.L.az_batch_next_stream(self.h)).wait_event(producer_event)
+        elif converted or not producer_done:
+            torch.cuda.current_stream(dev).synchronize()
+        arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        self._chk(self.L.az_batch_launch(self.h, len(ptrs), ctypes.byref(params), arr, C, H, W))
+        import collections
+        q = self.__dict__.setdefault("_batches", collections.deque())
+        q.append((params, maps))
+        self.feat_shape = (C, H, W)
+
+    def batch_fetch(self, i, want_scores=False, want_stats=False):
+        params, maps = self._batches[0]
+        cap = params.num_proposals
+        boxes = np.empty((cap, 4), dtype=np.float64)
+        scores = np.empty((cap,), dtype=np.float32)
+        n = ctypes.c_int(0)
+        st = AzStats()
+        try:
+            self._chk(self.L.az_batch_fetch(self.h, int(i), _p(boxes, ctypes.c_double), _p(scores, ctypes.c_float),
+                                            cap, ctypes.byref(n), ctypes.byref(st)))
+        finally:
+            if i == len(maps) - 1:
+                self._batches.popleft()
+        out = [boxes[:n.value].copy()]
+        if want_scores:
+            out.append(scores[:n.value].copy())
+        if want_stats:
+            out.append(st)
+        return out[0] if len(out) == 1 else tuple(out)
 
     def propose_fetch(self, want_scores=False, want_stats=False):
         params = self._queued.pop(0) if getattr(self, "_queued", None) else self._last_params

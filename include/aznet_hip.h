@@ -43,6 +43,7 @@ typedef enum {
 
 #define AZ_MAX_LEVELS 16
 #define AZ_NUM_SUBREG 11      /* len(cfg.SEAR.SUBREGION), lib/detect/config.py:149-155 */
+#define AZ_BATCH_MAX 16        /* images az_batch_launch searches in lockstep */
 
 /* Search parameters = the cfg keys lib/detect/test.py reads on this path. */
 typedef struct {
@@ -112,7 +113,9 @@ typedef struct {
                                              head pass per level (levels 1-3 in one speculative pass); 1 some passes also
                                              carried the next level's rows (pair speculation); 2 ONE pass over the unique rois
                                              of the image shape's full tree; 3 ONE pass over the closure rows (every region any
-                                             pruning of the shape's tree can produce); 4 the Tz <= 0 one-pass plan          */
+                                             pruning of the shape's tree can produce); 4 the Tz <= 0 one-pass plan; 5 level by
+                                             level in lockstep with the other images of its batch (az_batch_launch: the root and
+                                             its children in the first pass, then one pass per level, shared by the batch)      */
     int32_t n_reruns;                     /* times this search had to be run again in another form before it gave this
                                              result (0 normally; e.g. a whole-tree pass over the full tree's rows that lacked
                                              a window the pruned tree needed)                                               */
@@ -202,6 +205,24 @@ int az_propose_fetch(az_ctx *ctx, double *boxes_out, float *scores_out, int cap,
 int az_set_lanes(az_ctx *ctx, int lanes);
 void *az_next_stream(az_ctx *ctx);
 void *az_last_stream(az_ctx *ctx);
+/* A batch of images of ONE shape searched in lockstep -- the images of consecutive iterations of the dataset loop
+ * (lib/detect/test.py:508-513), each with its own tree, but every level's rois of ALL of them forwarded in ONE head pass
+ * (the reference's roi blob carries Caffe's batch index in column 0, test.py:93-97; there it is always 0).  At a tuned
+ * threshold a level of one image is a few dozen rois: passes that are weight streams for one image become matrix work for
+ * eight, and the latency chain between two passes (slab sum, int7, heads, geometry kernel) is paid once per level, not once
+ * per level and image.  Every image's result is what az_propose gives for it alone, bit for bit (stats: search_form 5).
+ *   maps: n device pointers to channel-last maps [H][W][C] (az_set_feature_map_dev_nhwc's layout), valid and unmodified
+ *   until the batch's last az_batch_fetch; p: fixed proposal count, not the tuner's variant; 1 <= n <= AZ_BATCH_MAX.
+ * The search is level by level for every image (root + its children in the first pass); an image whose tree outgrows a
+ * fused kernel's tables, or a batch whose level outgrows max_regions rows, is run again on its own by az_batch_fetch.
+ * Shapes / settings the lockstep form does not take (fewer than three levels, params.reserved bits 0 / 1 / 4, int6 on the
+ * 16-bit matrix cores) are searched one image after the other, same results.  az_batch_fetch returns the images of the
+ * OLDEST unfetched batch, i = 0 .. n-1 in order.  With two lanes (az_set_lanes) two batches may be in flight, else one.
+ * Uses max_regions-sized geometry buffers per image slot (~25 KB per region), allocated at the first batch. */
+int az_batch_launch(az_ctx *ctx, int n, const az_params *p, const float *const *maps_nhwc_dev, int C, int H, int W);
+int az_batch_fetch(az_ctx *ctx, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);
+/* the hipStream_t the NEXT az_batch_launch runs on: make it wait for the maps' producers there */
+void *az_batch_next_stream(az_ctx *ctx);
 /* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size
  * records; the reference itself is single-process).  A fixed-count search (params.fixed_num) leaves
  * its result in HBM as ONE record of az_result_record_layout(k) bytes: int32 n at n_offset,

@@ -1,0 +1,223 @@
+"""A batch of images of one shape searched in lockstep (az_batch_launch; az-net_amd/csrc/az_batch.hip, az_search.hip:
+batch_launch_impl) -- the images of consecutive iterations of the reference's dataset loop (lib/detect/test.py:508-513), each
+with its own tree, every level's rois of all of them in ONE head pass.  Whatever shares a pass with an image, its result is
+what the plain level loop (and the CPU oracle) give for that image alone: boxes, scores, every counter, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import torch
+    from aznet_hip import ffi, synth
+    from aznet_hip.net import HipAZNet
+    from oracle import az_oracle as orc
+    return torch, ffi, synth, HipAZNet, orc
+
+
+def _plain(ffi, H, W, scale, Tz, **kw):
+    return ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, fused_levels=False, static_tree=False,
+                                     pair_spec=False, full_spec=False, early_end=False, **kw)
+
+
+def _cl(torch, fmap):
+    return torch.from_numpy(np.ascontiguousarray(fmap)).cuda().contiguous(memory_format=torch.channels_last)
+
+
+def _same(st, sr):
+    assert st.n_levels == sr.n_levels and st.num_eval == sr.num_eval and st.depth == sr.depth
+    assert st.n_candidates == sr.n_candidates and st.n_proposals == sr.n_proposals
+    for l in range(sr.n_levels):
+        assert st.level_regions[l] == sr.level_regions[l] and st.level_unique[l] == sr.level_unique[l]
+        assert st.level_zoomed[l] == sr.level_zoomed[l]
+
+
+def _covered(st):
+    cover = 0
+    for i in range(int(st.n_passes)):
+        assert cover & int(st.pass_levels[i]) == 0
+        cover |= int(st.pass_levels[i])
+    for l in range(st.n_levels):
+        if st.level_unique[l] > 0:
+            assert (cover >> l) & 1
+
+
+def _object_set(synth, n, H=600, W=1000, scale=1.0):
+    fh, fw = synth.conv_out_size(int(round(H * scale))), synth.conv_out_size(int(round(W * scale)))
+    return [synth.make_object_map(j, synth.SMALL_DIMS["C"], fh, fw) for j in range(n)]
+
+
+def _reference(ffi, ref, H, W, scale, Tz, fmaps, **kw):
+    out = []
+    for f in fmaps:
+        ref.set_conv(f)
+        out.append(ref.propose(_plain(ffi, H, W, scale, Tz, **kw), want_scores=True, want_stats=True))
+    return out
+
+
+TZ_OBJ = 0.6226829886436462        # (tests/golden/g14_stream.npz: the reference's tuned threshold over the object images)
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 16])
+def test_batch_equals_every_image_alone(mods, n):
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = _object_set(synth, 16)[:n]
+    ref = HipAZNet(head, name="batch_ref")
+    want = _reference(ffi, ref, H, W, sc, TZ_OBJ, fmaps)
+    assert len({tuple(int(s.level_regions[l]) for l in range(s.n_levels)) for _, _, s in want}) >= min(n, 4) or n < 4
+    net = HipAZNet(head, name="batch")
+    prm = ffi.AzContext.make_params(H, W, sc, TZ_OBJ)
+    tm = [_cl(torch, f) for f in fmaps]
+    for rep in range(3):                       # (the slots are used again: nothing of the previous batch may leak)
+        net.ctx.batch_launch(prm, tm if rep < 2 else tm[::-1], producer_done=True)
+        order = list(range(n)) if rep < 2 else list(range(n))[::-1]
+        for i in range(n):
+            Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+            Yr, Sr, sr = want[order[i]]
+            assert np.array_equal(Y, Yr) and np.array_equal(S, Sr), (rep, i)
+            _same(st, sr)
+            assert st.search_form == 5 and st.n_reruns == 0
+            assert st.n_passes == sum(1 for l in range(2, st.n_levels) if st.level_unique[l] > 0) + 1
+            assert st.pass_rows[0] == 9 and st.pass_levels[0] == 3
+            _covered(st)
+
+
+def test_batch_against_the_cpu_oracle(mods):
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = _object_set(synth, 6)
+    net = HipAZNet(head, name="batch_orc")
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, TZ_OBJ), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i, f in enumerate(fmaps):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        onet = orc.OracleNet(head, feat_fn=lambda d, f=f: f)
+        Yo, tr = orc.im_propose({"full": onet, "fc": onet}, (H, W), sc, orc.OracleCfg(Tz=TZ_OBJ), return_trace=True)
+        assert [int(st.level_regions[l]) for l in range(len(tr["levels"]))] == [lv["B"].shape[0] for lv in tr["levels"]]
+        assert st.num_eval == tr["num_eval"] and st.depth == tr["depth"] and st.n_candidates == tr["Y_all"].shape[0]
+        assert Y.shape == Yo.shape
+        hit = [np.abs(Y - r).max(axis=1).min() <= 1e-3 for r in Yo]
+        assert np.mean(hit) >= 0.97
+
+
+@pytest.mark.parametrize("shape", [(375, 500, 1.6), (480, 640, 1.25), (333, 500, 600.0 / 333), (600, 1000, 1.0)])
+@pytest.mark.parametrize("tz", [0.0, 0.35, 0.9])
+def test_batch_shapes_and_thresholds(mods, shape, tz):
+    """Random weights (the trees are whatever the threshold makes of them: full at 0, the root's children only at 0.9)."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = shape
+    fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+    fmaps = [synth.make_scene_map(j, synth.SMALL_DIMS["C"], fh, fw) for j in range(5)]
+    ref = HipAZNet(head, name="bs_ref")
+    want = _reference(ffi, ref, H, W, sc, tz, fmaps)
+    net = HipAZNet(head, name="bs")
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, tz, static_tree=False), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i in range(5):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), i
+        _same(st, want[i][2])
+
+
+def test_a_level_that_outgrows_the_head_buffers(mods):
+    """max_regions 1024 and five full trees of 564 unique rois at the last level: the pass does not fit, every image of the
+    batch is run again on its own by batch_fetch -- same results, n_reruns 1."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = [synth.make_scene_map(j, synth.SMALL_DIMS["C"], 38, 63) for j in range(5)]
+    ref = HipAZNet(head, name="ovf_ref", max_regions=1024)
+    want = _reference(ffi, ref, H, W, sc, 0.0, fmaps)
+    assert int(want[0][2].level_unique[4]) == 564
+    net = HipAZNet(head, name="ovf", max_regions=1024)
+    for rep in range(2):
+        net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, 0.0, static_tree=False), [_cl(torch, f) for f in fmaps], producer_done=True)
+        for i in range(5):
+            Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+            assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), i
+            _same(st, want[i][2])
+            assert st.n_reruns == 1 and st.search_form != 5
+
+
+def test_shapes_the_lockstep_form_does_not_take(mods):
+    """A 40x60 image has two levels: its batch is searched image by image, same results."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 40, 60, 15.0
+    fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+    fmaps = [synth.make_scene_map(j, synth.SMALL_DIMS["C"], fh, fw) for j in range(3)]
+    ref = HipAZNet(head, name="small_ref")
+    want = _reference(ffi, ref, H, W, sc, 0.3, fmaps)
+    assert want[0][2].n_levels < 3
+    net = HipAZNet(head, name="small")
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, 0.3), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i in range(3):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
+        assert st.search_form != 5
+
+
+def test_two_batches_in_flight_and_single_searches_in_between(mods):
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = _object_set(synth, 24)
+    ref = HipAZNet(head, name="two_ref")
+    want = _reference(ffi, ref, H, W, sc, TZ_OBJ, fmaps)
+    net = HipAZNet(head, name="two")
+    net.ctx.set_lanes(2)
+    prm = ffi.AzContext.make_params(H, W, sc, TZ_OBJ)
+    tm = [_cl(torch, f) for f in fmaps]
+    with pytest.raises(ffi.AzError):
+        net.ctx.batch_fetch(0)                                         # nothing launched
+    groups = [list(range(0, 8)), list(range(8, 16)), list(range(16, 24)), [3, 4, 5], [23]]
+    launched = 0
+    for gi in range(len(groups)):
+        while launched < min(len(groups), gi + 2):
+            net.ctx.batch_launch(prm, [tm[j] for j in groups[launched]], producer_done=True)
+            launched += 1
+        if gi == 0:
+            with pytest.raises(ffi.AzError):
+                net.ctx.batch_launch(prm, [tm[0]], producer_done=True)     # both lanes hold a batch
+            with pytest.raises(ffi.AzError):
+                net.ctx._chk(net.ctx.L.az_batch_fetch(net.ctx.h, 1, None, None, 0, None, None))
+        for i, j in enumerate(groups[gi]):
+            Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+            assert np.array_equal(Y, want[j][0]) and np.array_equal(S, want[j][1]), (gi, i)
+            _same(st, want[j][2])
+        if gi == 1:
+            # a search launched the usual way between two batches, on the same context
+            net.ctx.propose_launch(prm, fmap=tm[7], producer_done=True)
+            Y, S = net.ctx.propose_fetch(want_scores=True)
+            assert np.array_equal(Y, want[7][0]) and np.array_equal(S, want[7][1])
+
+
+def test_batch_with_the_full_head(mods):
+    """Launch sizes of the head (512 channels, int6 25088 -> 4096): 8 object images in lockstep against each alone."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=1234, **synth.FULL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = [synth.make_object_map(j, 512, 38, 63) for j in range(8)]
+    net = HipAZNet(head, name="full_batch", max_regions=4096)
+    ref = net
+    # a threshold from the set itself, as the tuner gives it (ANCHORS_PER_IMG = 20)
+    net.ctx.tune_begin(8 * 2 * net.ctx.max_regions)
+    for f in fmaps:
+        net.set_conv(f)
+        net.propose(ffi.AzContext.make_params(H, W, sc, 0.0, tune=True))
+    tz, _ = net.ctx.tune_kth_largest(8 * 20)
+    net.ctx.tune_end()
+    tz = float(tz) - 1e-4
+    want = _reference(ffi, ref, H, W, sc, tz, fmaps)
+    trees = {tuple(int(s.level_regions[l]) for l in range(s.n_levels)) for _, _, s in want}
+    assert len(trees) >= 4
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, tz), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i in range(8):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), i
+        _same(st, want[i][2])
+        assert st.search_form == 5 and st.n_reruns == 0
