@@ -451,6 +451,8 @@ class AzContext(object):
         self.feat_shape = (C, H, W)
 
     def batch_fetch(self, i, want_scores=False, want_stats=False):
+        if not getattr(self, "_batches", None):
+            raise AzError(-4, "batch_fetch without batch_launch")
         params, maps = self._batches[0]
         cap = params.num_proposals
         boxes = np.empty((cap, 4), dtype=np.float64)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--objects", action="store_true", help="planted-object maps + object head instead of images through the backbone")
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--replay", type=int, default=4, help="images whose same-tree replay is timed for comparison")
+    ap.add_argument("--batch", default="", help="also: the set in lockstep batches of these sizes (az_batch_launch), e.g. 4,8,16")
     args = ap.parse_args()
     import torch
     from aznet_hip import ffi, synth
@@ -95,6 +96,33 @@ def main():
             forms[ffi.SEARCH_FORMS[int(st.search_form)]] = forms.get(ffi.SEARCH_FORMS[int(st.search_form)], 0) + 1
             reruns += int(st.n_reruns)
         print("== anchors/img %d Tz %.5f: %.4f ms/image over %d images, reruns %d, forms %s" % (a, tz, dt / n * 1e3, n, reruns, forms))
+        for bs in [int(x) for x in args.batch.split(",") if x]:
+            groups = [order[i:i + bs] for i in range(0, len(order), bs)]
+            inflight = args.lanes
+
+            def run_batches(collect=None):
+                launched = 0
+                for gi in range(len(groups)):
+                    while launched < min(len(groups), gi + inflight):
+                        net.ctx.batch_launch(prm, [convs[j] for j in groups[launched]], producer_done=True)
+                        launched += 1
+                    for i in range(len(groups[gi])):
+                        r = net.ctx.batch_fetch(i, want_stats=collect is not None)
+                        if collect is not None:
+                            collect.append(r[1])
+            run_batches()
+            run_batches()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.passes):
+                run_batches()
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            sts = []
+            run_batches(sts)
+            print("   lockstep batches of %2d (%d in flight): %.4f ms/image; reruns %d, forms %s" % (
+                bs, inflight, dtb / (args.passes * len(order)) * 1e3, sum(int(s.n_reruns) for s in sts),
+                sorted({int(s.search_form) for s in sts})))
         for i, st in stats[-args.images:] if args.verbose else []:
             print("   img %2d regions %s passes %s form %d reruns %d deferred %d" % (
                 i, [int(st.level_regions[l]) for l in range(st.n_levels)], [int(x) for x in list(st.pass_rows)[:int(st.n_passes)]],
