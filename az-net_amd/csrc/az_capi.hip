@@ -337,10 +337,15 @@ static void destroy_batch(az_ctx *c)
     if (!c) return;
     auto &B = c->batch;
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (az_ctx *t : B.slots) az_destroy(t);
+    for (az_ctx *t : B.slots) {
+        if (t->stream) hipStreamSynchronize(t->stream);
+        if (t->h_res_own0) { t->h_res[0] = t->h_res_own0; t->h_res_own0 = nullptr; }     // (its own block again: az_destroy frees that)
+        az_destroy(t);
+    }
     B.slots.clear();
-    for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev}) if (q) hipFree(q);
+    for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev, (void *)B.res_dev}) if (q) hipFree(q);
     if (B.args_host) hipHostFree(B.args_host);
+    if (B.res_host) hipHostFree(B.res_host);
     B = az_ctx::Batch();
     c->batch_order.clear();
     c->batch_next = 0;

@@ -189,6 +189,10 @@ struct az_ctx {
         const float **feats = nullptr;
         unsigned char *args_dev = nullptr, *args_host = nullptr;   // the geometry kernels' arguments, one block per image and launch
         size_t args_cap = 0;
+        // the images' result blocks (counters + selected boxes and scores) lie side by side, on the device and in pinned host
+        // memory: ONE device-to-host copy per batch (eight copies of 12 KB cost 75 us of stream time, one of 95 KB ~10)
+        unsigned char *res_dev = nullptr, *res_host = nullptr;
+        int gemm12_rows = -1;                 // rows of a pass from which int6 takes the many-row kernel (AZ_BATCH_GEMM12_ROWS)
         int n_live = 0, next_fetch = 0;       // images of the batch in flight; the one az_batch_fetch returns next
         bool lockstep = false;                // false: the batch's images were launched one after the other on their slots
         int rows_hint[AZ_MAX_LEVELS] = {0};   // rows of the passes of the last fetched batch (which int6 kernel takes a level)
@@ -198,6 +202,9 @@ struct az_ctx {
     int batch_next = 0;
     bool head_bufs = true;                    // false: a batch slot that has not needed pool5 / slabs / h6 / h7 yet
     az_ctx *batch_lane = nullptr;             // (a batch slot) the lane whose passes its rois ride in
+    // (a batch slot) its counters / result block and its first host result slot are slices of the lane's arenas
+    // (Batch::res_dev / res_host); the slot's own allocations stay in its lists and are freed with it
+    unsigned char *h_res_own0 = nullptr;
     int lanes = 1, lane_next = 0, last_fetch_lane = 0;
     std::deque<int> lane_order;               // lanes of the searches launched through the public entry points, oldest first
     hipEvent_t ev_hand = nullptr;             // (in a twin) orders the lane behind the owner's stream when it reads the owner's map

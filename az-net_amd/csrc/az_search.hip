@@ -1376,6 +1376,21 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         HIPCHK(L, hipMalloc((void **)&B.feats, AZ_BATCH_MAX * sizeof(float *)));
         HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
     }
+    const size_t res_slot = RES_HDR + (size_t)AZ_TOPK_MAX * 36;
+    if (!B.res_dev) {
+        HIPCHK(L, hipMalloc((void **)&B.res_dev, res_slot * AZ_BATCH_MAX));
+        HIPCHK(L, hipHostMalloc((void **)&B.res_host, res_slot * AZ_BATCH_MAX));
+        HIPCHK(L, hipMemsetAsync(B.res_dev, 0, res_slot * AZ_BATCH_MAX, s));
+    }
+    // this batch's blocks: k proposals each, side by side
+    const size_t res_stride = (RES_HDR + (size_t)k * 36 + 255) & ~(size_t)255;
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = slots[b];
+        if (!t->h_res_own0) t->h_res_own0 = t->h_res[0];
+        t->cnt = reinterpret_cast<AzCounts *>(B.res_dev + (size_t)b * res_stride);
+        t->h_res[0] = B.res_host + (size_t)b * res_stride;
+    }
+    if (B.gemm12_rows < 0) { const char *e = getenv("AZ_BATCH_GEMM12_ROWS"); B.gemm12_rows = e ? atoi(e) : L->gemm12_dual_rows; }
     const size_t need = 64 + ((sizeof(AzFusedArgs) + 16) + (sizeof(AzLevelArgs) + 16) * (size_t)nlev + (sizeof(AzFinalArgs) + 16)) * AZ_BATCH_MAX;
     if (B.args_cap < need) {
         if (B.args_dev) { HIPCHK(L, hipStreamSynchronize(s)); hipFree(B.args_dev); hipHostFree(B.args_host); B.args_dev = nullptr; B.args_host = nullptr; B.args_cap = 0; }
@@ -1462,7 +1477,7 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     azk_batch_gather(s, g);
     const int *Mptr = B.off + AZ_BATCH_MAX + 1;
     head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
-                    rows0 * n >= L->gemm12_dual_rows);
+                    rows0 * n >= B.gemm12_rows);
     azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
     // ---- the levels
     for (int l = 2; l < nlev; ++l) {
@@ -1473,7 +1488,7 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         }
         azk_batch_gather(s, g);
         head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
-                        B.rows_hint[l] >= L->gemm12_dual_rows);
+                        B.rows_hint[l] >= B.gemm12_rows);
         AzScatterArgs sc;
         std::memset(&sc, 0, sizeof(sc));
         sc.n = n; sc.off = B.off; sc.zoom = L->zoom_u; sc.score = L->score_u; sc.pred = L->pred_u; sc.keep = L->keep_u;
@@ -1500,9 +1515,8 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         }
         t->feat = maps[b]; t->d.H = H; t->d.W = W;
         q.feat = maps[b]; q.fH = H; q.fW = W; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
-        for (q.slot = 0; q.slot < 3 && t->slot_busy[q.slot]; ++q.slot) { }
-        if (q.slot >= 3) return fail(L, AZ_ERR_STATE, "az_batch_launch: no free result slot");
-        HIPCHK(L, hipMemcpyAsync(t->h_res[q.slot], t->cnt, RES_HDR + (size_t)k * 36, hipMemcpyDeviceToHost, s));
+        q.slot = 0;                                   // (the slot's queue is empty: its first result slot, a slice of the arena)
+        if (b == 0) HIPCHK(L, hipMemcpyAsync(B.res_host, B.res_dev, res_stride * n, hipMemcpyDeviceToHost, s));
         HIPCHK(L, hipEventRecord(t->ev_res[q.slot], s));
         q.copied = true;
         q.last_s = s;

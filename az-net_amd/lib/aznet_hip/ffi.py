@@ -444,11 +444,16 @@ class AzContext(object):
         elif converted or not producer_done:
             torch.cuda.current_stream(dev).synchronize()
         arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        self._batch_stream = self._ext(self.L.az_batch_next_stream(self.h))       # (the stream this batch runs on)
         self._chk(self.L.az_batch_launch(self.h, len(ptrs), ctypes.byref(params), arr, C, H, W))
         import collections
         q = self.__dict__.setdefault("_batches", collections.deque())
         q.append((params, maps))
         self.feat_shape = (C, H, W)
+
+    def batch_record_event(self):
+        """A torch.cuda.Event recorded now on the stream of the batch launched last: behind that batch."""
+        return self._batch_stream.record_event()
 
     def batch_fetch(self, i, want_scores=False, want_stats=False):
         if not getattr(self, "_batches", None):

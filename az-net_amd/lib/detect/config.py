@@ -53,7 +53,9 @@ def _defaults():
         NMS=0.5,             # apply_nms threshold (post-detection only, test.py:467-484)
         SVM=False, BBOX_REG=True, DISPLAY=False,
         NUM_PROPOSALS=300,
-        PREFETCH=2)          # (not in the reference) images test_proposals reads ahead in a worker thread; 0: none
+        PREFETCH=2,          # (not in the reference) images test_proposals reads ahead in a worker thread; 0: none
+        BATCH_IMAGES=1)      # (not in the reference) > 1: test_proposals searches up to that many consecutive images of one shape
+                             # in lockstep (az_batch_launch): same boxes per image, every level's rois of the batch in one head pass
     # the 11 adjacency templates, relative to a region (config.py:149-154)
     subregion = [[0, 0, 1, 1],
                  [-0.5, 0, 0.5, 1], [0.5, 0, 1.5, 1], [0, -0.5, 1, 0.5], [0, 0.5, 1, 1.5],

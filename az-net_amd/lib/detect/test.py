@@ -176,6 +176,53 @@ def _propose_finish(net, h, return_conv=False):
     return Y
 
 
+def _batch_backbones(net, ims, after=None):
+    """Upload + front-end + backbone of the images of one lockstep batch (cfg.TEST.BATCH_IMAGES), enqueued on torch's stream
+    behind `after` (the previous batch's search); the event marks the last map complete."""
+    import torch
+    hnet = net["full"] if isinstance(net, dict) else net
+    dev = hnet.backbone.device
+    if after is not None:
+        torch.cuda.current_stream(dev).wait_event(after)
+    scale = _im_scale(ims[0].shape)
+    if len(scale) != 1:
+        raise NotImplementedError("one test scale (cfg.TEST.SCALES), as in every config of the reference")
+    convs, blobs = [], []
+    for im in ims:
+        blob = hnet.image_blob_enqueue(_as_uint8(im), cfg.PIXEL_MEANS, scale[0])
+        blobs.append(blob)
+        convs.append(hnet.backbone(blob))
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return {"shape": ims[0].shape, "n": len(ims), "convs": convs, "blobs": blobs, "maps_done": ev,
+            "params": _params(ims[0].shape, scale[0], None)}
+
+
+def _batch_launch(net, h):
+    """The batch's search behind its maps (az_batch_launch: every level's rois of all its images in ONE head pass)."""
+    hnet = net["full"] if isinstance(net, dict) else net
+    hnet.ctx.batch_launch(h["params"], h["convs"], producer_event=h["maps_done"])
+    hnet._conv = h["convs"][-1]
+    h["done"] = hnet.ctx.batch_record_event()
+    return h
+
+
+def _batch_finish(net, h, i):
+    """Image i of the batch, formatted as im_propose formats it."""
+    hnet = net["full"] if isinstance(net, dict) else net
+    Y, st = hnet.ctx.batch_fetch(i, want_stats=True)
+    shape = h["shape"]
+    if cfg.SEAR.APPEND_BOXES:
+        Y = _append_boxes(Y)
+        Y[:, 0::4] = np.maximum(Y[:, 0::4], 0)
+        Y[:, 1::4] = np.maximum(Y[:, 1::4], 0)
+        Y[:, 2::4] = np.minimum(Y[:, 2::4], shape[1] - 1)
+        Y[:, 3::4] = np.minimum(Y[:, 3::4], shape[0] - 1)
+    print('{0} proposals, evaluate {1} regions, reaches depth {2}.'
+          .format(Y.shape[0], st.num_eval, st.depth))
+    return Y
+
+
 def _prefetched(imdb, indices, depth=2):
     """imdb.image_at(i) for i in indices, in order, read up to `depth` images ahead by a worker thread (decoding a JPEG or
     reading an .npy takes as long as the GPU needs for an image).  depth <= 0: read in the caller's thread."""
@@ -285,7 +332,36 @@ def test_proposals(net, imdb):
     _t = {'im_prop': Timer()}
     num_boxes = 0.0
     images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
-    if _can_queue(hnet):
+    nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
+    if nb > 1 and _can_queue(hnet) and cfg.SEAR.FIXED_PROPOSAL_NUM:
+        # cfg.TEST.BATCH_IMAGES (an extension: the reference has no such key): up to that many CONSECUTIVE images of one
+        # shape walk their zoom trees in lockstep (az_batch_launch).  Every image's boxes are what im_propose gives for it
+        # alone, the printed lines and their order are the reference's; while one batch is searched the host enqueues the
+        # next batch's front-ends and backbones behind it.
+        def groups():
+            cur = []
+            for i in range(num_images):
+                im = next(images)
+                if cur and (im.shape != cur[0].shape or len(cur) == nb):
+                    yield cur
+                    cur = []
+                cur.append(im)
+            if cur:
+                yield cur
+        pend, done_i = None, 0
+        _t['im_prop'].tic()
+        import itertools
+        for grp in itertools.chain(groups(), [None]):
+            nxt = _batch_backbones(net, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
+            if pend is not None:
+                for i in range(pend["n"]):
+                    prop_boxes[done_i] = _batch_finish(net, pend, i)
+                    done_i += 1
+                    _t['im_prop'].toc()
+                    print('im_prop: {:d}/{:d} {:.3f}s'.format(done_i, num_images, _t['im_prop'].average_time))
+                    _t['im_prop'].tic()
+            pend = _batch_launch(net, nxt) if nxt is not None else None
+    elif _can_queue(hnet):
         # One image ahead: while the GPU works on image i the host reads image i+1 and enqueues its whole pipeline behind
         # it.  Same boxes, same printed lines in the same order; the timer counts from one finished image to the next
         # (what a per-image tic/toc adds up to when nothing overlaps).

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Steady-state timeline from a rocprofv3 --kernel-trace CSV: every kernel of a few consecutive searches from the middle
 of the trace with start, end, duration (us), one column per HIP queue (= lane).  Shows which kernels of the two lanes
-overlap and which wait for the other lane's GEMM.   usage: lane_timeline.py kernel_trace.csv [searches=4]"""
+overlap and which wait for the other lane's GEMM.
+usage: lane_timeline.py kernel_trace.csv [searches=4] [kernel-name prefixes that end a search, comma separated]"""
 import csv
 import re
 import sys
@@ -10,13 +11,14 @@ import sys
 def main():
     rd = list(csv.DictReader(open(sys.argv[1])))
     nsearch = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    ends = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("k_final_select", "k_static_select")
     qk = next((k for k in ("Queue_Id", "Stream_Id") if rd and k in rd[0]), None)
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
              re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:24], r.get(qk, "?") if qk else "?")
             for r in rd]
     rows.sort()
     # a search ends with its selection kernel (k_final_select; the one-pass plan: k_static_select)
-    idx = [i for i, r in enumerate(rows) if r[2].startswith(("k_final_select", "k_static_select"))]
+    idx = [i for i, r in enumerate(rows) if r[2].startswith(ends)]
     if len(idx) < nsearch + 2:
         print("too few searches in the trace (%d)" % len(idx))
         return

@@ -31,6 +31,8 @@ FLAGS = [
     # (extension) several ranks: "nccl" = RCCL over xGMI, one rank per GPU (the production setting); "gloo" = the exchange
     # over host tensors -- ranks that share a GPU (fewer GPUs than ranks), or a box without a usable RCCL
     ("--dist-backend", "dist_backend", "torch.distributed backend of a multi-rank run: nccl (default) or gloo", "nccl", str),
+    # (extension) cfg.TEST.BATCH_IMAGES: consecutive images of one shape searched in lockstep (one process; same boxes)
+    ("--batch-images", "batch_images", "search up to N consecutive images of one shape in lockstep (default 1: one by one)", 1, int),
 ]
 
 
@@ -92,6 +94,7 @@ def main():
     from datasets.factory import get_imdb
     from detect.config import get_output_dir
     from detect.test import test_proposals, im_propose, _propose_start, _propose_finish, _prefetched, _can_queue
+    cfg.TEST.BATCH_IMAGES = max(1, int(getattr(args, "batch_images", 1) or 1))
     net = load_net(args.caffemodel, device, tuned=bool(getattr(args, "tune_backbone", False)))
     nets = {"full": net, "fc": net}
     imdb = get_imdb(args.imdb_name)

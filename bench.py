@@ -77,6 +77,28 @@ def merged_floor_us(unique_per_level, pass_levels, fmap_elems):
     return tot * 1e6
 
 
+def merged_floor_batches(sts, bs, fmap_elems):
+    """(floor in us per image, mean rows per pass) of lockstep batches (az_batch_launch) from the per-image az_stats, `bs`
+    consecutive ones per batch: a batch's first pass covers tree levels 1-2 of all its images, every later pass one level of
+    all of them; a pass streams the weights ONCE for the batch and does the flops of all its rows."""
+    tot, n_img, rows = 0.0, 0, []
+    for g0 in range(0, len(sts), bs):
+        grp = sts[g0:g0 + bs]
+        nlev = int(grp[0].n_levels)
+        uq = [[int(st.level_unique[l]) for l in range(nlev)] for st in grp]
+        per_pass = [sum(u[0] + u[1] for u in uq)] + [sum(u[l] for u in uq) for l in range(2, nlev)]
+        rows.append(per_pass)
+        for U in per_pass:
+            if U <= 0:
+                continue
+            b = 432239616 + 21728 + 4 * fmap_elems * len(grp) + U * 244
+            tot += max(b / HBM_PEAK, U * HEAD_FLOP_PER_ROI / (PEAK_F32_MFMA_TFLOPS * 1e12))
+        n_img += len(grp)
+    width = max(len(r) for r in rows)
+    mean_rows = [float(np.mean([r[i] if i < len(r) else 0 for r in rows])) for i in range(width)]
+    return tot * 1e6 / max(n_img, 1), mean_rows
+
+
 def floors(st, fmap_elems, measured_us):
     """path_floor entry of one search from its az_stats: BASELINE.md section 3's per-level floor and the merged-pass floor
     of the form that ran, with `frac` = merged-pass floor / measured (<= 1 by construction)."""
@@ -1174,10 +1196,46 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
             r_ms = (time.perf_counter() - t0) / 30 * 1e3
             rep.append(r_ms)
             fracs.append(floors(st_i[-1][1], fm, 1.0)["merged_pass_t_min_us"])
+        # the same set in lockstep batches (az_batch_launch): the images of B consecutive iterations of the dataset loop walk
+        # their trees together, every level's rois of all of them in ONE head pass; as many batches in flight as lanes
+        lock = {}
+        lanes = int(getattr(cnet.ctx, "lanes", 1))
+        for bs in (4, 8, 16):
+            groups = [order[i:i + bs] for i in range(0, len(order), bs)]
+
+            def run_batches(collect=None):
+                launched = 0
+                for gi in range(len(groups)):
+                    while launched < min(len(groups), gi + lanes):
+                        cnet.ctx.batch_launch(prm, [maps[j] for j in groups[launched]], producer_done=True)
+                        launched += 1
+                    for i in range(len(groups[gi])):
+                        r = cnet.ctx.batch_fetch(i, want_stats=collect is not None)
+                        if collect is not None:
+                            collect.append(r[1])
+            for _ in range(4 if bs == 4 else 2):          # (untimed: slots, row hints; the first size also takes the idle gap)
+                run_batches()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                run_batches()
+            torch.cuda.synchronize()
+            b_ms = (time.perf_counter() - t0) / (passes * len(order)) * 1e3
+            sts = []
+            run_batches(sts)
+            bforms = {}
+            for st in sts:
+                f = ffi.SEARCH_FORMS.get(int(st.search_form), "?")
+                bforms[f] = bforms.get(f, 0) + 1
+            lock[str(bs)] = {"ms_per_image": b_ms, "value": NUM_PROPOSALS * 1e3 / b_ms, "vs_one_image_at_a_time": ms / b_ms,
+                             "searches_run_twice": sum(int(st.n_reruns) for st in sts), "search_forms": bforms,
+                             "rows_per_pass_mean": merged_floor_batches(sts, bs, fm)[1],
+                             "merged_pass_floor_frac": merged_floor_batches(sts, bs, fm)[0] / (b_ms * 1e3)}
         gc.enable()
         merged_mean = float(np.mean(fracs))
         reg = np.array([t + [0] * (8 - len(t)) for t in trees])[:, :len(trees[0])]
         return {"set": label, "anchors_per_img": anchors, "Tz": tz, "ms_per_image": ms, "value": NUM_PROPOSALS * 1e3 / ms,
+                "lockstep_batches": lock,
                 "unit": "proposals/s", "timed_images": n, "searches_run_twice": reruns, "rerun_rate": reruns / float(n),
                 "search_forms": forms,
                 "same_tree_replay_ms_per_image": float(np.mean(rep)), "stream_over_replay": ms / float(np.mean(rep)),
@@ -1210,7 +1268,10 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
                    "priming; rerun_rate = searches that had to be run twice (an early end that missed, a whole-tree pass that "
                    "lacked a window) / timed images; stream_over_replay = ms_per_image over the mean of every image's own "
                    "history-primed replay (what calibrated_tz / tz_sweep measure for ONE image); merged_pass_floor.frac = mean "
-                   "of the images' merged-pass floors (of their replay's passes) over ms_per_image")
+                   "of the images' merged-pass floors (of their replay's passes) over ms_per_image; lockstep_batches = the same "
+                   "set, B consecutive images per az_batch_launch (each image's result identical to its search alone: "
+                   "tests/test_gpu_batch.py), as many batches in flight as lanes; its floor charges one weight stream per pass of "
+                   "a BATCH")
     return res
 
 

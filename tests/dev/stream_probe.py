@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--objects", action="store_true", help="planted-object maps + object head instead of images through the backbone")
     ap.add_argument("--depth", type=int, default=0)
     ap.add_argument("--replay", type=int, default=4, help="images whose same-tree replay is timed for comparison")
+    ap.add_argument("--batch-only", action="store_true", help="skip the one-image-at-a-time stream and the replays")
     ap.add_argument("--batch", default="", help="also: the set in lockstep batches of these sizes (az_batch_launch), e.g. 4,8,16")
     args = ap.parse_args()
     import torch
@@ -85,7 +86,7 @@ def main():
         stats = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.passes):
+        for _ in range(1 if args.batch_only else args.passes):
             stream(prm, order, stats)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -127,6 +128,8 @@ def main():
             print("   img %2d regions %s passes %s form %d reruns %d deferred %d" % (
                 i, [int(st.level_regions[l]) for l in range(st.n_levels)], [int(x) for x in list(st.pass_rows)[:int(st.n_passes)]],
                 int(st.search_form), int(st.n_reruns), int(st.root_deferred)))
+        if args.batch_only:
+            continue
         # same-tree replay of a few images (history primed with the image's own tree)
         rep = []
         for i in range(min(args.replay, args.images)):

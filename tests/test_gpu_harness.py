@@ -137,6 +137,31 @@ def test_test_proposals_matches_the_reference_run(rig, mods):
         assert np.array_equal(again, b)
 
 
+@pytest.mark.parametrize("nb", [2, 3, 16])
+def test_test_proposals_in_lockstep_batches(rig, mods, nb):
+    """cfg.TEST.BATCH_IMAGES: consecutive images searched in lockstep -- the printed lines (the reference run's, g13) and every
+    image's boxes are those of the one-by-one loop, bit for bit."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    g, net, dnet, imdb, C = rig
+    from detect import test as T
+    with redirect_stdout(io.StringIO()):
+        with open(T.test_proposals({"full": net, "fc": net}, imdb), "rb") as f:
+            one_by_one = pickle.load(f)
+    C.cfg.TEST.BATCH_IMAGES = nb
+    try:
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            prop_file = T.test_proposals({"full": net, "fc": net}, imdb)
+    finally:
+        C.cfg.TEST.BATCH_IMAGES = 1
+    assert scrub(buf.getvalue()) == str(g["prop_stdout"])
+    with open(prop_file, "rb") as f:
+        prop = pickle.load(f)
+    assert len(prop["boxes"]) == int(g["n_img"]) == len(one_by_one["boxes"])
+    for a, b in zip(prop["boxes"], one_by_one["boxes"]):
+        assert a.dtype == np.float64 and np.array_equal(a, b)
+
+
 def test_test_net_shared_matches_the_reference_run(rig, mods):
     """detections.pkl / evaluate_detections input of test_net_shared (BASELINE config 3)."""
     torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
