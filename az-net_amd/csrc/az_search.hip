@@ -1311,13 +1311,18 @@ void head_pass_batch(az_ctx *L, const AzHeadDims &d, const int *Mptr, int im_h, 
                      float *delta, double min_side, bool keep_flags, bool keys, bool many_rows)
 {
     hipStream_t s = L->stream;
-    azk_roi_pool(s, nullptr, d, L->spatial_scale, L->batch.rois_cat, Mptr, L->maxR, L->pool5, nullptr, 0, 0, 0, 0, nullptr,
-                 L->batch.feats);
+    // (gemm mode 3 -- int6 on the 16-bit matrix cores, every fp32 operand as three bf16 terms: the planes carry no per-map
+    //  scale, so the images of a batch share a pass there as well; mode 2's fp16 terms are scaled per map: not taken)
+    azk_roi_pool(s, nullptr, d, L->spatial_scale, L->batch.rois_cat, Mptr, L->maxR, L->pool5, L->pool5p,
+                 azk_act_plane_elems(L->maxR, d.K6), L->gemm_parts, 0, 0, nullptr, L->batch.feats);
     const bool can12 = (d.n6 / 128) * L->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
                        azk_fc_chunk(d.K6, L->S6) * L->S6 == d.K6 && azk_fc_chunk(d.K6, L->S6) >= 64 &&
                        L->gemm12_min_rows < 0x7fffffff;
     // (only the device knows the row count; both kernels are correct and bit-identical for any: the last batch's rows decide)
-    if (can12 && many_rows)
+    if (L->gemm_parts)
+        azk_fc_gemm_terms(s, L->pool5p, d.K6, azk_act_plane_elems(L->maxR, d.K6), L->W6p, d.K6, azk_weight_plane_elems(d.n6, d.K6), Mptr,
+                          L->maxR, d.n6, d.K6, L->S6, azk_fc_chunk(d.K6, L->S6), L->part, L->gemm_parts, L->gscale);
+    else if (can12 && many_rows)
         azk_fc_gemm12(s, L->pool5, d.K6, L->W6, d.K6, Mptr, L->maxR, d.n6, d.K6, L->S6, azk_fc_chunk(d.K6, L->S6), L->part, 0, nullptr);
     else
         azk_fc_gemm(s, L->pool5, d.K6, L->W6, d.K6, Mptr, L->maxR, d.n6, d.K6, L->S6, L->part, 1 << 30, nullptr);
@@ -1344,7 +1349,7 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
     const int nlev = num_levels(p->im_h, p->im_w, p->min_side) - 1;
     auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
-    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts) return skip();
+    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
     if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
     if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
         return skip();

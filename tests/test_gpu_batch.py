@@ -196,13 +196,14 @@ def test_two_batches_in_flight_and_single_searches_in_between(mods):
             assert np.array_equal(Y, want[7][0]) and np.array_equal(S, want[7][1])
 
 
-def test_batch_with_the_full_head(mods):
-    """Launch sizes of the head (512 channels, int6 25088 -> 4096): 8 object images in lockstep against each alone."""
+def test_batch_with_the_full_head(mods, gemm_mode):
+    """Launch sizes of the head (512 channels, int6 25088 -> 4096): 8 object images in lockstep against each alone -- on the
+    fp32 MFMA and with int6 as three bf16 terms per operand (no per-map scale: the images share passes there as well)."""
     torch, ffi, synth, HipAZNet, orc = mods
     head = synth.make_object_head(seed=1234, **synth.FULL_DIMS)
     H, W, sc = 600, 1000, 1.0
     fmaps = [synth.make_object_map(j, 512, 38, 63) for j in range(8)]
-    net = HipAZNet(head, name="full_batch", max_regions=4096)
+    net = HipAZNet(head, name="full_batch", max_regions=4096, gemm_mode=gemm_mode)
     ref = net
     # a threshold from the set itself, as the tuner gives it (ANCHORS_PER_IMG = 20)
     net.ctx.tune_begin(8 * 2 * net.ctx.max_regions)
@@ -221,3 +222,18 @@ def test_batch_with_the_full_head(mods):
         assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), i
         _same(st, want[i][2])
         assert st.search_form == 5 and st.n_reruns == 0
+
+
+def test_two_fp16_terms_keep_their_images_apart(mods):
+    """az_set_gemm_mode 2 scales pool5 per map: a batch there is searched image by image, same results."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    fmaps = _object_set(synth, 4)
+    net = HipAZNet(head, name="m2", gemm_mode=2)
+    want = _reference(ffi, net, H, W, sc, TZ_OBJ, fmaps)
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, TZ_OBJ), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i in range(4):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
+        assert st.search_form != 5
