@@ -389,7 +389,8 @@ static int ensure_twin(az_ctx *c)
 int az_set_lanes(az_ctx *c, int lanes)
 {
     if (!c || c->owner || (lanes != 1 && lanes != 2)) return fail(c, AZ_ERR_INVALID, "az_set_lanes: 1 or 2");
-    if (!c->lane_order.empty() || !c->pend.empty()) return fail(c, AZ_ERR_STATE, "az_set_lanes: searches are still queued");
+    if (!c->lane_order.empty() || !c->pend.empty() || !c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_set_lanes: searches are still queued");
+    c->batch_next = 0;
     c->lanes = lanes;
     c->lane_next = 0;
     return AZ_OK;

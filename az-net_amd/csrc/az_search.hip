@@ -1348,39 +1348,14 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     if (k <= 0) return fail(L, AZ_ERR_INVALID, "az_batch_launch: num_proposals must be positive");
     if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
     const int nlev = num_levels(p->im_h, p->im_w, p->min_side) - 1;
-    auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
-    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
-    if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
-    if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
-        return skip();
-    for (const auto &e : L->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
     for (int b = 0; b < n; ++b) {
-        az_ctx *t = slots[b];
-        if (!t || !maps[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
-        if (!t->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
-        // (what an image's own reruns have taught its slot about the shape holds for the batch as well)
-        if ((p->im_h == t->nofuse_h && p->im_w == t->nofuse_w) || (p->im_h == t->nofuse_lv_h && p->im_w == t->nofuse_lv_w)) return skip();
-        for (const auto &e : t->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+        if (!slots[b] || !maps[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
+        if (!slots[b]->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
     }
     HIPCHK(L, hipSetDevice(L->device));
-    // the shape's pre-pass (B1, the rois of root + B1, counters): cached per shape on the lane
-    {
-        SearchPlan q{};
-        q.fused = true; q.defer_root = false;
-        if ((rc = ensure_spec_cache(L, p, q)) != AZ_OK) return rc;
-        if (L->spc[0].h != p->im_h || L->spc[0].w != p->im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
-    }
-    const int P1 = L->spc[0].P1, rows0 = 1 + P1;
-    if ((size_t)rows0 * n > (size_t)L->maxR) return skip();
     auto &B = L->batch;
     hipStream_t s = L->stream;
-    if (!B.off) {
-        HIPCHK(L, hipMalloc((void **)&B.off, (AZ_BATCH_MAX + 2) * sizeof(int)));
-        HIPCHK(L, hipMalloc((void **)&B.rois_cat, (size_t)L->maxR * 5 * sizeof(float)));
-        HIPCHK(L, hipMalloc((void **)&B.ubox_cat, (size_t)L->maxR * 4 * sizeof(double)));
-        HIPCHK(L, hipMalloc((void **)&B.feats, AZ_BATCH_MAX * sizeof(float *)));
-        HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
-    }
+    // (before anything can decide that the images are searched one by one: those searches use the slices, too)
     const size_t res_slot = RES_HDR + (size_t)AZ_TOPK_MAX * 36;
     if (!B.res_dev) {
         HIPCHK(L, hipMalloc((void **)&B.res_dev, res_slot * AZ_BATCH_MAX));
@@ -1394,6 +1369,34 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         if (!t->h_res_own0) t->h_res_own0 = t->h_res[0];
         t->cnt = reinterpret_cast<AzCounts *>(B.res_dev + (size_t)b * res_stride);
         t->h_res[0] = B.res_host + (size_t)b * res_stride;
+    }
+    auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
+    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
+    if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
+    if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
+        return skip();
+    for (const auto &e : L->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+    for (int b = 0; b < n; ++b) {
+        az_ctx *t = slots[b];
+        // (what an image's own reruns have taught its slot about the shape holds for the batch as well)
+        if ((p->im_h == t->nofuse_h && p->im_w == t->nofuse_w) || (p->im_h == t->nofuse_lv_h && p->im_w == t->nofuse_lv_w)) return skip();
+        for (const auto &e : t->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+    }
+    // the shape's pre-pass (B1, the rois of root + B1, counters): cached per shape on the lane
+    {
+        SearchPlan q{};
+        q.fused = true; q.defer_root = false;
+        if ((rc = ensure_spec_cache(L, p, q)) != AZ_OK) return rc;
+        if (L->spc[0].h != p->im_h || L->spc[0].w != p->im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
+    }
+    const int P1 = L->spc[0].P1, rows0 = 1 + P1;
+    if ((size_t)rows0 * n > (size_t)L->maxR) return skip();
+    if (!B.off) {
+        HIPCHK(L, hipMalloc((void **)&B.off, (AZ_BATCH_MAX + 2) * sizeof(int)));
+        HIPCHK(L, hipMalloc((void **)&B.rois_cat, (size_t)L->maxR * 5 * sizeof(float)));
+        HIPCHK(L, hipMalloc((void **)&B.ubox_cat, (size_t)L->maxR * 4 * sizeof(double)));
+        HIPCHK(L, hipMalloc((void **)&B.feats, AZ_BATCH_MAX * sizeof(float *)));
+        HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
     }
     if (B.gemm12_rows < 0) { const char *e = getenv("AZ_BATCH_GEMM12_ROWS"); B.gemm12_rows = e ? atoi(e) : L->gemm12_dual_rows; }
     const size_t need = 64 + ((sizeof(AzFusedArgs) + 16) + (sizeof(AzLevelArgs) + 16) * (size_t)nlev + (sizeof(AzFinalArgs) + 16)) * AZ_BATCH_MAX;

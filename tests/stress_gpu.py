@@ -120,6 +120,29 @@ def run_case(net, case):
                 q -= 1
         if not all(np.array_equal(g[0], b[0]) and np.array_equal(g[1], b[1]) for g in got) or len(got) != len(forms):
             return False, desc, "queued searches differ from the plain one"
+    if fixed:
+        # a lockstep batch (az_batch_launch) of this image and up to four more maps of its shape, with the case's settings:
+        # every image as its plain search gives it (a BATCH_SIZE that chunks a level's dedup, a shape with two levels, an
+        # overflowing table: those batches end up searched image by image or rerun, same results)
+        import torch
+        nb = int(rng.randint(1, 6))
+        C = (synth.FULL_DIMS if FULL else synth.SMALL_DIMS)["C"]
+        maps = [fmap] + [synth.make_feature_map(50000 + 7 * case + j, C, fh, fw) for j in range(nb - 1)]
+        want = [b]
+        for m in maps[1:]:
+            net.set_conv(m)
+            want.append(net.propose(ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, radix_select=True, **kw),
+                                    want_scores=True, want_stats=True))
+        order = [int(x) for x in rng.permutation(nb)]
+        net.ctx.batch_launch(forms[0], [torch.from_numpy(maps[j]).cuda() for j in order])
+        for i, j in enumerate(order):
+            g = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+            if not (np.array_equal(g[0], want[j][0]) and np.array_equal(g[1], want[j][1]) and g[2].num_eval == want[j][2].num_eval and
+                    list(g[2].level_unique) == list(want[j][2].level_unique) and list(g[2].level_zoomed) == list(want[j][2].level_zoomed)):
+                return False, desc, "image %d of a lockstep batch of %d differs from its plain search (form %d reruns %d)" % (
+                    i, nb, g[2].search_form, g[2].n_reruns)
+        net.set_conv(fmap)
+        desc += " batch %d" % nb
     desc += " levels %d eval %d cand %d" % (a[2].n_levels, a[2].num_eval, Ya.shape[0])
     if case % (16 if FULL else 4):
         return True, desc, ""
