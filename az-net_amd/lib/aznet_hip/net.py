@@ -97,6 +97,13 @@ class HipAZNet(object):
         return self.ctx.propose_fetch(want_scores=want_scores, want_stats=want_stats)
 
     # ---- pycaffe-shaped surface ----------------------------------------------------------
+    def propose_batch(self, params, convs, want_scores=False, want_stats=False):
+        """The images of consecutive iterations of the dataset loop (lib/detect/test.py:508-513), all of one shape, searched
+        in lockstep (AzContext.batch_launch / batch_fetch): a list with every image's im_propose result."""
+        self.ctx.batch_launch(params, convs)
+        self._conv = convs[-1]
+        return [self.ctx.batch_fetch(i, want_scores=want_scores, want_stats=want_stats) for i in range(len(convs))]
+
     def forward(self, blobs=None, **kw):
         rois = np.ascontiguousarray(kw["rois"], dtype=np.float32)
         if "conv5_3" in kw:
