@@ -712,6 +712,44 @@ int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
 }
 
 
+// The records of the batch launched last, image i to dst_dev + i * pitch: ONE strided device-to-device copy behind the batch
+// (its result blocks lie side by side); an image that az_batch_fetch has to search again alone is staged again there.
+int az_batch_stage_results_dev(az_ctx *c, void *dst_dev, size_t pitch_bytes, size_t cap_bytes)
+{
+    if (!c || c->owner || c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev without az_batch_launch");
+    az_ctx *L = c->batch_order.back() ? c->twin : c;
+    if (!L || !L->batch.n_live) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: no batch in flight");
+    auto &B = L->batch;
+    const int n = B.n_live;
+    if (B.next_fetch) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: call it right behind az_batch_launch");
+    az_ctx *t0 = B.slots[0];
+    if (t0->pend.empty()) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: nothing queued");
+    const size_t bytes = RES_HDR + (size_t)t0->pend.back().p.num_proposals * 36;
+    if (!dst_dev || pitch_bytes < bytes || cap_bytes < pitch_bytes * (size_t)(n - 1) + bytes)
+        return fail(c, AZ_ERR_INVALID, "az_batch_stage_results_dev: destination too small");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!B.lockstep) {
+        // (the images were launched one by one on their slots: one copy each, on the slot's stream)
+        for (int i = 0; i < n; ++i) {
+            const int rc = stage_impl(B.slots[i], (unsigned char *)dst_dev + (size_t)i * pitch_bytes, bytes);
+            if (rc) { c->err = B.slots[i]->err; return rc; }
+        }
+        return AZ_OK;
+    }
+    const size_t src_pitch = (size_t)((unsigned char *)B.slots[n > 1 ? 1 : 0]->cnt - (unsigned char *)B.slots[0]->cnt);
+    hipStream_t s = L->stream;
+    if (n > 1) HIPCHK(c, hipMemcpy2DAsync(dst_dev, pitch_bytes, B.res_dev, src_pitch, bytes, (size_t)n, hipMemcpyDeviceToDevice, s));
+    else HIPCHK(c, hipMemcpyAsync(dst_dev, B.res_dev, bytes, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < n; ++i) {
+        az_ctx *t = B.slots[i];
+        auto &q = t->pend.back();
+        q.stage_dst = (unsigned char *)dst_dev + (size_t)i * pitch_bytes; q.stage_cap = bytes;
+        // ("the record is staged when the fetch returns": the slot's event again, behind the staging copy)
+        if (q.copied) HIPCHK(c, hipEventRecord(t->ev_res[q.slot], s));
+    }
+    return AZ_OK;
+}
+
 int az_last_candidates(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out)
 {
     if (c && !c->owner && c->last_fetch_lane == 1 && c->twin) {

@@ -178,6 +178,13 @@ class DeviceGather(object):
                                "or stage into the other pair)" % buf)
         self.ctx.stage_result(self.bufs[buf][0].data_ptr() + j * self.rec_bytes, self.rec_bytes)
 
+    def stage_batch(self, j0, n, buf=0):
+        """Right behind ctx.batch_launch of n images: their records into rows j0 .. j0 + n - 1 (one strided copy)."""
+        assert 0 <= j0 and j0 + n <= self.rows
+        if self._busy[buf]:
+            raise RuntimeError("DeviceGather.stage_batch: buffer pair %d still has an exchange in flight" % buf)
+        self.ctx.batch_stage_results(self.bufs[buf][0].data_ptr() + j0 * self.rec_bytes, self.rec_bytes, n * self.rec_bytes)
+
     def _exchange(self, n_local, buf):
         import torch.distributed as dist
         send, recv = self.bufs[buf]

@@ -36,6 +36,7 @@ SYMBOLS = [
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
     "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
     "az_bias_relu", "az_bias_relu_pool", "az_batch_launch", "az_batch_fetch", "az_batch_next_stream",
+    "az_batch_stage_results_dev",
 ]
 
 
@@ -154,6 +155,7 @@ def load_library(path=None):
     L.az_batch_next_stream.argtypes = [vp]
     L.az_batch_launch.argtypes = [vp, ci, ctypes.POINTER(AzParams), ctypes.POINTER(vp), ci, ci, ci]
     L.az_batch_fetch.argtypes = [vp, ci, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
+    L.az_batch_stage_results_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
@@ -450,6 +452,11 @@ class AzContext(object):
         q = self.__dict__.setdefault("_batches", collections.deque())
         q.append((params, maps))
         self.feat_shape = (C, H, W)
+
+    def batch_stage_results(self, dst_ptr, pitch_bytes, cap_bytes):
+        """Right behind batch_launch: the batch's result records to dst_ptr + i * pitch_bytes (a raw device pointer, e.g. rows
+        of the RCCL send buffer), device to device; image i's is complete when batch_fetch(i) returns."""
+        self._chk(self.L.az_batch_stage_results_dev(self.h, ctypes.c_void_p(int(dst_ptr)), int(pitch_bytes), int(cap_bytes)))
 
     def batch_record_event(self):
         """A torch.cuda.Event recorded now on the stream of the batch launched last: behind that batch."""

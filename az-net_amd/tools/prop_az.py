@@ -136,7 +136,39 @@ def main():
     t = Timer()
     local = []
     images = _prefetched(imdb, mine, depth=int(cfg.TEST.get("PREFETCH", 2)))
-    if fixed and _can_queue(net):
+    nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
+    if fixed and _can_queue(net) and nb > 1:
+        # --batch-images: the rank's consecutive images of one shape in lockstep batches (detect.test.test_proposals does the
+        # same in a one-process run); a batch's records go to the send buffer in one strided device-to-device copy
+        import itertools
+        from detect.test import _batch_backbones, _batch_launch, _batch_finish
+
+        def groups():
+            cur = []
+            for _ in range(len(mine)):
+                im = next(images)
+                if cur and (im.shape != cur[0].shape or len(cur) == nb):
+                    yield cur
+                    cur = []
+                cur.append(im)
+            if cur:
+                yield cur
+        pend, j0 = None, 0
+        t.tic()
+        for grp in itertools.chain(groups(), [None]):
+            nxt = _batch_backbones(nets, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
+            if pend is not None:
+                for i in range(pend["n"]):
+                    Y = _batch_finish(nets, pend, i)
+                    t.toc()
+                    t.tic()
+                    local.append((Y, np.zeros(Y.shape[0], dtype=np.float32)))
+            if nxt is not None:
+                _batch_launch(nets, nxt)
+                gat.stage_batch(j0, nxt["n"])
+                j0 += nxt["n"]
+            pend = nxt
+    elif fixed and _can_queue(net):
         # one image ahead, as detect.test.test_proposals: image j+1's pipeline (and the staging of its record) is enqueued
         # while the GPU works on image j
         pend = None

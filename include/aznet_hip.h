@@ -223,6 +223,9 @@ int az_batch_launch(az_ctx *ctx, int n, const az_params *p, const float *const *
 int az_batch_fetch(az_ctx *ctx, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);
 /* the hipStream_t the NEXT az_batch_launch runs on: make it wait for the maps' producers there */
 void *az_batch_next_stream(az_ctx *ctx);
+/* az_propose_stage_result_dev for the batch launched last (call it right behind az_batch_launch): image i's record to
+ * dst_dev + i * pitch_bytes, complete when az_batch_fetch(i) returns -- one strided device-to-device copy for the batch. */
+int az_batch_stage_results_dev(az_ctx *ctx, void *dst_dev, size_t pitch_bytes, size_t cap_bytes);
 /* Multi-GPU exchange of proposals (image-sharded ranks, one all-gather of fixed-size
  * records; the reference itself is single-process).  A fixed-count search (params.fixed_num) leaves
  * its result in HBM as ONE record of az_result_record_layout(k) bytes: int32 n at n_offset,

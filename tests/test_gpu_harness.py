@@ -215,8 +215,9 @@ def test_test_net_shared_matches_the_reference_run(rig, mods):
             assert abs(all_boxes[j][i].shape[0] - ref.shape[0]) <= 5
 
 
-def _run_tool(args, timeout=900):
+def _run_tool(args, timeout=900, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env["PYTHONPATH"] = os.pathsep.join([TOOLS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
     return subprocess.run([sys.executable, os.path.join(TOOLS, args[0])] + args[1:], env=env, cwd=REPO,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
@@ -310,7 +311,7 @@ def test_queued_image_pipeline_reads_its_own_image(mods):
         C.cfg_set_mode("Test", old_tz)
 
 
-def _run_tool_ranks(world, args, timeout=900):
+def _run_tool_ranks(world, args, timeout=900, extra_env=None):
     """tools/<args[0]> as `world` fresh ranks under torch.distributed.run on 127.0.0.1 (what the driver does for N > 1)."""
     import socket
     s = socket.socket()
@@ -318,6 +319,7 @@ def _run_tool_ranks(world, args, timeout=900):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
+    env.update(extra_env or {})
     env["PYTHONPATH"] = os.pathsep.join([TOOLS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -368,6 +370,44 @@ def test_prop_az_cli_two_ranks_equal_one(mods, tmp_path, variable_count):
             assert counts == {300}
         # every rank printed its own images' lines; rank 0 wrote the file
         assert r2.stdout.count("proposals, evaluate") == 7 and r2.stdout.count("wrote ") == 1
+    finally:
+        for root in roots:
+            shutil.rmtree(root, ignore_errors=True)
+
+
+def test_prop_az_cli_lockstep_batches_one_and_two_ranks(mods):
+    """--batch-images 3 (cfg.TEST.BATCH_IMAGES): the one-process run and two fresh ranks (each searching ITS images in
+    lockstep batches, the batch's records staged into the send buffer by one strided copy) write the proposals.pkl of the
+    plain one-process run, box for box."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    from detect import config as C
+    base = "cli_batches_%d" % os.getpid()
+    common = ["--net", "synthetic", "--imdb", "synthetic_600x1000_7", "--tz", "0.35", "--def", "x.prototxt", "--def_fc", "y.prototxt"]
+    roots = [os.path.join(C.cfg.ROOT_DIR, "output", base + s_) for s_ in ("_w1", "_w1b", "_w2b")]
+    try:
+        # (three PROCESSES compared box for box: the backbone's convolutions with the same summation order in each)
+        det = {"AZ_BACKBONE_DETERMINISTIC": "1"}
+        r1 = _run_tool(["prop_az.py", "--gpu", "0", "--exp", base + "_w1"] + common, extra_env=det)
+        assert r1.returncode == 0, r1.stdout[-3000:]
+        r1b = _run_tool(["prop_az.py", "--gpu", "0", "--exp", base + "_w1b", "--batch-images", "3"] + common, extra_env=det)
+        assert r1b.returncode == 0, r1b.stdout[-3000:]
+        r2b = _run_tool_ranks(2, ["prop_az.py", "--exp", base + "_w2b", "--dist-backend", "gloo", "--batch-images", "3"] + common,
+                              extra_env=det)
+        assert r2b.returncode == 0, r2b.stdout[-4000:]
+        props = []
+        for root in roots:
+            pf = os.path.join(root, "synthetic_600x1000_7", "vgg16_az_net_synthetic_1234", "proposals.pkl")
+            assert os.path.exists(pf), (r1b.stdout[-1500:], r2b.stdout[-1500:])
+            with open(pf, "rb") as f:
+                props.append(pickle.load(f))
+        for other in props[1:]:
+            assert len(other["boxes"]) == 7
+            for i, (a, b) in enumerate(zip(props[0]["boxes"], other["boxes"])):
+                assert a.dtype == b.dtype == np.float64 and np.array_equal(a, b), i
+        assert r2b.stdout.count("proposals, evaluate") == 7 and r2b.stdout.count("wrote ") == 1
+        # the per-image lines of the one-process runs agree (same counts, same order)
+        lines = [[ln for ln in r.stdout.splitlines() if "proposals, evaluate" in ln] for r in (r1, r1b)]
+        assert lines[0] == lines[1] and len(lines[0]) == 7
     finally:
         for root in roots:
             shutil.rmtree(root, ignore_errors=True)
