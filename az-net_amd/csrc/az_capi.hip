@@ -554,7 +554,12 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
             if ((rc = launch_impl(t, p)) != AZ_OK) {
                 c->err = t->err;
                 // (the images launched so far are dropped: nothing of this batch can be fetched)
-                for (int q = 0; q < b; ++q) { double bx[4]; int nn; (void)fetch_entry(B.slots[q], 0, bx, nullptr, 0, &nn, nullptr); B.slots[q]->pend.clear(); for (bool &sb : B.slots[q]->slot_busy) sb = false; }
+                for (int q = 0; q < b; ++q) {
+                    az_ctx *u = B.slots[q];
+                    (void)hipStreamSynchronize(u->stream);
+                    u->pend.clear();
+                    for (bool &sb : u->slot_busy) sb = false;
+                }
                 return rc;
             }
         }

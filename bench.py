@@ -1200,7 +1200,7 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
         # their trees together, every level's rois of all of them in ONE head pass; as many batches in flight as lanes
         lock = {}
         lanes = int(getattr(cnet.ctx, "lanes", 1))
-        for bs in (4, 8, 16):
+        for bs in (4, 8, 16, 32):
             groups = [order[i:i + bs] for i in range(0, len(order), bs)]
 
             def run_batches(collect=None):

@@ -43,7 +43,7 @@ typedef enum {
 
 #define AZ_MAX_LEVELS 16
 #define AZ_NUM_SUBREG 11      /* len(cfg.SEAR.SUBREGION), lib/detect/config.py:149-155 */
-#define AZ_BATCH_MAX 16        /* images az_batch_launch searches in lockstep */
+#define AZ_BATCH_MAX 32        /* images az_batch_launch searches in lockstep */
 
 /* Search parameters = the cfg keys lib/detect/test.py reads on this path. */
 typedef struct {

@@ -60,12 +60,12 @@ def _reference(ffi, ref, H, W, scale, Tz, fmaps, **kw):
 TZ_OBJ = 0.6226829886436462        # (tests/golden/g14_stream.npz: the reference's tuned threshold over the object images)
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 8, 16])
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 16, 32])
 def test_batch_equals_every_image_alone(mods, n):
     torch, ffi, synth, HipAZNet, orc = mods
     head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
     H, W, sc = 600, 1000, 1.0
-    fmaps = _object_set(synth, 16)[:n]
+    fmaps = _object_set(synth, 32)[:n]
     ref = HipAZNet(head, name="batch_ref")
     want = _reference(ffi, ref, H, W, sc, TZ_OBJ, fmaps)
     assert len({tuple(int(s.level_regions[l]) for l in range(s.n_levels)) for _, _, s in want}) >= min(n, 4) or n < 4
