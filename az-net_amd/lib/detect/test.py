@@ -191,7 +191,12 @@ def _batch_backbones(net, ims, after=None):
     for im in ims:
         blob = hnet.image_blob_enqueue(_as_uint8(im), cfg.PIXEL_MEANS, scale[0])
         blobs.append(blob)
-        convs.append(hnet.backbone(blob))
+        conv = hnet.backbone(blob)
+        if not conv.is_contiguous(memory_format=torch.channels_last):
+            # (the layout the batch reads the maps in; converted here, on torch's stream, so that the hand-over below stays an
+            #  event wait on the device)
+            conv = conv.contiguous(memory_format=torch.channels_last)
+        convs.append(conv)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     return {"shape": ims[0].shape, "n": len(ims), "convs": convs, "blobs": blobs, "maps_done": ev,
