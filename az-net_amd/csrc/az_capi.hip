@@ -585,7 +585,7 @@ int az_batch_fetch(az_ctx *c, int i, double *boxes_out, float *scores_out, int c
                                fetch_entry(t, 0, boxes_out, scores_out, cap, n_out, st);
     if (rc) c->err = t->err;
     if (++B.next_fetch == B.n_live) {
-        if (B.lockstep) for (int l = 0; l < AZ_MAX_LEVELS; ++l) B.rows_hint[l] = B.rows_acc[l];
+        if (B.lockstep) { for (int l = 0; l < AZ_MAX_LEVELS; ++l) B.rows_hint[l] = B.rows_acc[l]; B.hint_n = B.n_live; }
         B.n_live = 0; B.next_fetch = 0;
         c->batch_order.pop_front();
     }

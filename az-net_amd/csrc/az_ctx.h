@@ -197,6 +197,7 @@ struct az_ctx {
         bool lockstep = false;                // false: the batch's images were launched one after the other on their slots
         int rows_hint[AZ_MAX_LEVELS] = {0};   // rows of the passes of the last fetched batch (which int6 kernel takes a level)
         int rows_acc[AZ_MAX_LEVELS] = {0};
+        int hint_n = 0;                       // images of the batch rows_hint was taken from (0: none yet)
     } batch;
     std::deque<int> batch_order;              // (owner) lanes of the batches in flight, oldest first
     int batch_next = 0;

@@ -1335,12 +1335,12 @@ void head_pass_batch(az_ctx *L, const AzHeadDims &d, const int *Mptr, int im_h, 
 
 }  // namespace
 
-int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken)
+int batch_launch_impl(az_ctx *L, int n_all, az_ctx **slots_all, const az_params *p, const float *const *maps_all, int H, int W, int *not_taken)
 {
     *not_taken = 0;
     int rc = check_ready(L, false, true);          // (join: the passes work in the lane's per-search head buffers)
     if (rc) return rc;
-    if (!p || n < 1 || n > AZ_BATCH_MAX || !slots || !maps || H <= 0 || W <= 0 || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) ||
+    if (!p || n_all < 1 || n_all > AZ_BATCH_MAX || !slots_all || !maps_all || H <= 0 || W <= 0 || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) ||
         p->batch_size <= 0 || !(p->min_side > 0))
         return fail(L, AZ_ERR_INVALID, "az_batch_launch: bad arguments");
     if (!p->fixed_num || (p->reserved & 4)) return fail(L, AZ_ERR_INVALID, "az_batch_launch: fixed proposal count, not the tuner's variant");
@@ -1348,9 +1348,9 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     if (k <= 0) return fail(L, AZ_ERR_INVALID, "az_batch_launch: num_proposals must be positive");
     if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
     const int nlev = num_levels(p->im_h, p->im_w, p->min_side) - 1;
-    for (int b = 0; b < n; ++b) {
-        if (!slots[b] || !maps[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
-        if (!slots[b]->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
+    for (int b = 0; b < n_all; ++b) {
+        if (!slots_all[b] || !maps_all[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
+        if (!slots_all[b]->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
     }
     HIPCHK(L, hipSetDevice(L->device));
     auto &B = L->batch;
@@ -1364,8 +1364,8 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     }
     // this batch's blocks: k proposals each, side by side
     const size_t res_stride = (RES_HDR + (size_t)k * 36 + 255) & ~(size_t)255;
-    for (int b = 0; b < n; ++b) {
-        az_ctx *t = slots[b];
+    for (int b = 0; b < n_all; ++b) {
+        az_ctx *t = slots_all[b];
         if (!t->h_res_own0) t->h_res_own0 = t->h_res[0];
         t->cnt = reinterpret_cast<AzCounts *>(B.res_dev + (size_t)b * res_stride);
         t->h_res[0] = B.res_host + (size_t)b * res_stride;
@@ -1376,8 +1376,8 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
     if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
         return skip();
     for (const auto &e : L->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
-    for (int b = 0; b < n; ++b) {
-        az_ctx *t = slots[b];
+    for (int b = 0; b < n_all; ++b) {
+        az_ctx *t = slots_all[b];
         // (what an image's own reruns have taught its slot about the shape holds for the batch as well)
         if ((p->im_h == t->nofuse_h && p->im_w == t->nofuse_w) || (p->im_h == t->nofuse_lv_h && p->im_w == t->nofuse_lv_w)) return skip();
         for (const auto &e : t->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
@@ -1390,7 +1390,7 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         if (L->spc[0].h != p->im_h || L->spc[0].w != p->im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
     }
     const int P1 = L->spc[0].P1, rows0 = 1 + P1;
-    if ((size_t)rows0 * n > (size_t)L->maxR) return skip();
+    if ((size_t)rows0 * n_all > (size_t)L->maxR) return skip();
     if (!B.off) {
         HIPCHK(L, hipMalloc((void **)&B.off, (AZ_BATCH_MAX + 2) * sizeof(int)));
         HIPCHK(L, hipMalloc((void **)&B.rois_cat, (size_t)L->maxR * 5 * sizeof(float)));
@@ -1406,132 +1406,150 @@ int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, cons
         HIPCHK(L, hipHostMalloc((void **)&B.args_host, need));
         B.args_cap = need;
     }
-    AzHeadDims d = L->d;
-    d.H = H; d.W = W;
-    // ---- the geometry kernels' arguments, all levels, all images: one block, one copy
+    // A batch whose levels would not fit the head's buffers (max_regions rows per pass) -- going by the rows per image of the
+    // last batch fetched on this lane -- is enqueued as several lockstep programs, one after the other, of as many images each
+    // as fit (a pass that overflows all the same marks its images: they are searched again alone by az_batch_fetch).
+    int per = n_all;
+    if (B.hint_n > 0) {
+        long mx = 0;
+        for (int l = 0; l < AZ_MAX_LEVELS; ++l) mx = B.rows_hint[l] > mx ? B.rows_hint[l] : mx;
+        const double per_img = (double)mx / B.hint_n;
+        if (per_img * n_all > 0.9 * L->maxR) per = (int)(0.9 * L->maxR / per_img);
+        if (per < 1) per = 1;
+    }
     size_t off = 0;
-    AzFusedArgs *fa = args_at<AzFusedArgs>(B.args_host, off, n);
-    const size_t off_fa = (size_t)((unsigned char *)fa - B.args_host);
-    std::vector<size_t> off_lv(nlev, 0);
-    std::vector<AzLevelArgs *> la(nlev, nullptr);
-    for (int l = 2; l + 1 < nlev; ++l) { la[l] = args_at<AzLevelArgs>(B.args_host, off, n); off_lv[l] = (size_t)((unsigned char *)la[l] - B.args_host); }
-    AzFinalArgs *fin = args_at<AzFinalArgs>(B.args_host, off, n);
-    const size_t off_fin = (size_t)((unsigned char *)fin - B.args_host);
-    for (int b = 0; b < n; ++b) {
-        az_ctx *t = slots[b];
-        auto INV = [&](int l) { return (l & 1) ? t->inv_odd : t->inv; };
-        {
-            AzFusedArgs a;
-            std::memset(&a, 0, sizeof(a));
-            a.cnt = t->cnt;
-            a.B[0] = t->B[0]; a.B[1] = t->B[1]; a.srcB[0] = t->srcB[0]; a.srcB[1] = t->srcB[1];
-            a.index = t->index; a.inv = INV(2); a.zr = t->zr; a.choff = t->choff; a.csrc = t->csrc;
-            a.choff_all = L->spec_choff[0]; a.specB1 = L->specB1[0];
-            a.reset = 1; a.specP1 = P1; a.specCH = L->spc[0].CH; a.specU = rows0;
-            a.ubox = t->ubox; a.pred_u = t->pred_u; a.Yall = t->Yall; a.Z = t->Z; a.child = t->child;
-            a.zoom_u = t->zoom_u; a.score_u = t->score_u; a.delta_u = t->delta_u; a.Sall = t->Sall;
-            a.zoom_s = L->zoom_s + (size_t)b * rows0; a.score_s = L->score_s + (size_t)b * rows0 * AZ_NSUB;
-            a.delta_s = L->delta_s + (size_t)b * rows0 * 4 * AZ_NSUB;
-            a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
-            a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = 2;
-            a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
-            a.rois = t->rois; a.urois = t->urois; a.next_dedup = 1; a.defer_root = 0; a.cut_next = 0; a.cut_short = 0;
-            a.spec_next = 0; a.choff_next = t->choff_pair; a.crow = t->crow; a.spatial_scale = L->spatial_scale;
-            a.row_map = nullptr; a.root_row = 0; a.stab = nullptr; a.stabT = 0;
-            a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
-            fa[b] = a;
-        }
-        for (int l = 2; l + 1 < nlev; ++l) {
-            AzLevelArgs a;
-            std::memset(&a, 0, sizeof(a));
-            const int cur = l & 1;
-            a.cnt = t->cnt; a.level = l; a.nlev = nlev; a.cut_next = 0;
-            a.B = t->B[cur]; a.Bnext = t->B[cur ^ 1];
-            a.pred_u = t->pred_u; a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.keep_u = t->keep_u; a.Uptr = &t->cnt->U[l];
-            a.urois = t->urois; a.index = t->index; a.inv = INV(l); a.inv_next = INV(l + 1); a.ubox = t->ubox;
-            a.Yall = t->Yall; a.Sall = t->Sall;
-            a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
-            a.batch = p->batch_size; a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
-            a.force_root = 1; a.root_row = 0; a.lookup_next = 0; a.spec_next = 0;
-            a.delta_u = t->delta_u; a.choff_all = t->choff_pair; a.choff_next = t->choff_pair; a.crow = t->crow;
-            a.stab = nullptr; a.stabT = 0; a.root_row_full = 0; a.score_all = t->score_s; a.zoom_all = t->zoom_s;
-            a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
-            a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = L->spatial_scale;
-            la[l][b] = a;
-        }
-        {
-            AzFinalArgs a;
-            std::memset(&a, 0, sizeof(a));
-            const int l = nlev - 1;
-            a.cnt = t->cnt; a.level = l; a.inv = INV(l); a.key_u = t->key_u; a.pred_u = t->pred_u;
-            a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.Yall = t->Yall; a.Sall = t->Sall; a.Tz = p->Tz;
-            a.force_root = 0; a.capCand = t->maxCand; a.k = k;
-            a.Yout = (double *)((unsigned char *)t->cnt + RES_HDR);
-            a.Sout = (float *)((unsigned char *)t->cnt + RES_HDR + (size_t)k * 32);
-            fin[b] = a;
-        }
-    }
-    HIPCHK(L, hipMemcpyAsync(B.args_dev, B.args_host, off, hipMemcpyHostToDevice, s));
-
-    // ---- pass 0: root + B1 of every image
-    AzGatherArgs g;
-    std::memset(&g, 0, sizeof(g));
-    g.n = n; g.capR = L->maxR; g.off_out = B.off; g.rois_cat = B.rois_cat; g.ubox_cat = B.ubox_cat; g.feats_out = B.feats;
-    for (int b = 0; b < n; ++b) {
-        g.rows[b] = L->spec_U[0] + 1;                 // (ensure_spec_cache: the pass without the third level's rows)
-        g.err[b] = nullptr;                           // (the image's counters are cleared by k_spec_levels, behind this pass)
-        g.rois[b] = L->spec_urois[0]; g.ubox[b] = nullptr; g.feat[b] = maps[b];
-    }
-    azk_batch_gather(s, g);
-    const int *Mptr = B.off + AZ_BATCH_MAX + 1;
-    head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
-                    rows0 * n >= B.gemm12_rows);
-    azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
-    // ---- the levels
-    for (int l = 2; l < nlev; ++l) {
-        const bool last = l + 1 == nlev;
+    for (int i0 = 0; i0 < n_all; i0 += per) {
+        const int n = n_all - i0 < per ? n_all - i0 : per;
+        az_ctx **slots = slots_all + i0;
+        const float *const *maps = maps_all + i0;
+        AzHeadDims d = L->d;
+        d.H = H; d.W = W;
+        // ---- the geometry kernels' arguments, all levels, all images of the part: one block, one copy
+        const size_t off_begin = off;
+        AzFusedArgs *fa = args_at<AzFusedArgs>(B.args_host, off, n);
+        const size_t off_fa = (size_t)((unsigned char *)fa - B.args_host);
+        std::vector<size_t> off_lv(nlev, 0);
+        std::vector<AzLevelArgs *> la(nlev, nullptr);
+        for (int l = 2; l + 1 < nlev; ++l) { la[l] = args_at<AzLevelArgs>(B.args_host, off, n); off_lv[l] = (size_t)((unsigned char *)la[l] - B.args_host); }
+        AzFinalArgs *fin = args_at<AzFinalArgs>(B.args_host, off, n);
+        const size_t off_fin = (size_t)((unsigned char *)fin - B.args_host);
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
-            g.rows[b] = &t->cnt->PR[l]; g.err[b] = &t->cnt->err; g.rois[b] = t->urois; g.ubox[b] = t->ubox; g.feat[b] = maps[b];
+            auto INV = [&](int l) { return (l & 1) ? t->inv_odd : t->inv; };
+            {
+                AzFusedArgs a;
+                std::memset(&a, 0, sizeof(a));
+                a.cnt = t->cnt;
+                a.B[0] = t->B[0]; a.B[1] = t->B[1]; a.srcB[0] = t->srcB[0]; a.srcB[1] = t->srcB[1];
+                a.index = t->index; a.inv = INV(2); a.zr = t->zr; a.choff = t->choff; a.csrc = t->csrc;
+                a.choff_all = L->spec_choff[0]; a.specB1 = L->specB1[0];
+                a.reset = 1; a.specP1 = P1; a.specCH = L->spc[0].CH; a.specU = rows0;
+                a.ubox = t->ubox; a.pred_u = t->pred_u; a.Yall = t->Yall; a.Z = t->Z; a.child = t->child;
+                a.zoom_u = t->zoom_u; a.score_u = t->score_u; a.delta_u = t->delta_u; a.Sall = t->Sall;
+                a.zoom_s = L->zoom_s + (size_t)b * rows0; a.score_s = L->score_s + (size_t)b * rows0 * AZ_NSUB;
+                a.delta_s = L->delta_s + (size_t)b * rows0 * 4 * AZ_NSUB;
+                a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
+                a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = 2;
+                a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
+                a.rois = t->rois; a.urois = t->urois; a.next_dedup = 1; a.defer_root = 0; a.cut_next = 0; a.cut_short = 0;
+                a.spec_next = 0; a.choff_next = t->choff_pair; a.crow = t->crow; a.spatial_scale = L->spatial_scale;
+                a.row_map = nullptr; a.root_row = 0; a.stab = nullptr; a.stabT = 0;
+                a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
+                fa[b] = a;
+            }
+            for (int l = 2; l + 1 < nlev; ++l) {
+                AzLevelArgs a;
+                std::memset(&a, 0, sizeof(a));
+                const int cur = l & 1;
+                a.cnt = t->cnt; a.level = l; a.nlev = nlev; a.cut_next = 0;
+                a.B = t->B[cur]; a.Bnext = t->B[cur ^ 1];
+                a.pred_u = t->pred_u; a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.keep_u = t->keep_u; a.Uptr = &t->cnt->U[l];
+                a.urois = t->urois; a.index = t->index; a.inv = INV(l); a.inv_next = INV(l + 1); a.ubox = t->ubox;
+                a.Yall = t->Yall; a.Sall = t->Sall;
+                a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.dedup = (float)p->dedup;
+                a.batch = p->batch_size; a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
+                a.force_root = 1; a.root_row = 0; a.lookup_next = 0; a.spec_next = 0;
+                a.delta_u = t->delta_u; a.choff_all = t->choff_pair; a.choff_next = t->choff_pair; a.crow = t->crow;
+                a.stab = nullptr; a.stabT = 0; a.root_row_full = 0; a.score_all = t->score_s; a.zoom_all = t->zoom_s;
+                a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
+                a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = L->spatial_scale;
+                la[l][b] = a;
+            }
+            {
+                AzFinalArgs a;
+                std::memset(&a, 0, sizeof(a));
+                const int l = nlev - 1;
+                a.cnt = t->cnt; a.level = l; a.inv = INV(l); a.key_u = t->key_u; a.pred_u = t->pred_u;
+                a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.Yall = t->Yall; a.Sall = t->Sall; a.Tz = p->Tz;
+                a.force_root = 0; a.capCand = t->maxCand; a.k = k;
+                a.Yout = (double *)((unsigned char *)t->cnt + RES_HDR);
+                a.Sout = (float *)((unsigned char *)t->cnt + RES_HDR + (size_t)k * 32);
+                fin[b] = a;
+            }
+        }
+        HIPCHK(L, hipMemcpyAsync(B.args_dev + off_begin, B.args_host + off_begin, off - off_begin, hipMemcpyHostToDevice, s));
+
+        // ---- pass 0: root + B1 of every image
+        AzGatherArgs g;
+        std::memset(&g, 0, sizeof(g));
+        g.n = n; g.capR = L->maxR; g.off_out = B.off; g.rois_cat = B.rois_cat; g.ubox_cat = B.ubox_cat; g.feats_out = B.feats;
+        for (int b = 0; b < n; ++b) {
+            g.rows[b] = L->spec_U[0] + 1;                 // (ensure_spec_cache: the pass without the third level's rows)
+            g.err[b] = nullptr;                           // (the image's counters are cleared by k_spec_levels, behind this pass)
+            g.rois[b] = L->spec_urois[0]; g.ubox[b] = nullptr; g.feat[b] = maps[b];
         }
         azk_batch_gather(s, g);
-        head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
-                        B.rows_hint[l] >= B.gemm12_rows);
-        AzScatterArgs sc;
-        std::memset(&sc, 0, sizeof(sc));
-        sc.n = n; sc.off = B.off; sc.zoom = L->zoom_u; sc.score = L->score_u; sc.pred = L->pred_u; sc.keep = L->keep_u;
-        sc.key = last ? L->key_u : nullptr;
+        const int *Mptr = B.off + AZ_BATCH_MAX + 1;
+        head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
+                        rows0 * n >= B.gemm12_rows);
+        azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
+        // ---- the levels
+        for (int l = 2; l < nlev; ++l) {
+            const bool last = l + 1 == nlev;
+            for (int b = 0; b < n; ++b) {
+                az_ctx *t = slots[b];
+                g.rows[b] = &t->cnt->PR[l]; g.err[b] = &t->cnt->err; g.rois[b] = t->urois; g.ubox[b] = t->ubox; g.feat[b] = maps[b];
+            }
+            azk_batch_gather(s, g);
+            head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
+                            (B.hint_n > 0 ? (long)B.rows_hint[l] * n / B.hint_n : 0) >= B.gemm12_rows);
+            AzScatterArgs sc;
+            std::memset(&sc, 0, sizeof(sc));
+            sc.n = n; sc.off = B.off; sc.zoom = L->zoom_u; sc.score = L->score_u; sc.pred = L->pred_u; sc.keep = L->keep_u;
+            sc.key = last ? L->key_u : nullptr;
+            for (int b = 0; b < n; ++b) {
+                az_ctx *t = slots[b];
+                sc.zoom_d[b] = t->zoom_u; sc.score_d[b] = t->score_u; sc.pred_d[b] = t->pred_u; sc.keep_d[b] = t->keep_u; sc.key_d[b] = t->key_u;
+            }
+            azk_batch_scatter(s, sc);
+            if (!last) azk_level_geom_batch(s, reinterpret_cast<const AzLevelArgs *>(B.args_dev + off_lv[l]), n);
+            else azk_final_select_batch(s, reinterpret_cast<const AzFinalArgs *>(B.args_dev + off_fin), n);
+        }
+        HIPCHK(L, hipGetLastError());
+        // ---- every image's record on its way to the host; the searches enter the slots' queues
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
-            sc.zoom_d[b] = t->zoom_u; sc.score_d[b] = t->score_u; sc.pred_d[b] = t->pred_u; sc.keep_d[b] = t->keep_u; sc.key_d[b] = t->key_u;
+            az_ctx::PendingSearch q;
+            q.p = *p; q.nlev = nlev; q.batch = 1;
+            q.npass = 0;
+            q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -rows0 - 1;
+            for (int l = 2; l < nlev; ++l) {
+                q.pass_lv[q.npass] = l;
+                q.pass_src[q.npass++] = (int)(&t->cnt->PR[l] - reinterpret_cast<int *>(t->cnt));
+            }
+            t->feat = maps[b]; t->d.H = H; t->d.W = W;
+            q.feat = maps[b]; q.fH = H; q.fW = W; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
+            q.slot = 0;                                   // (the slot's queue is empty: its first result slot, a slice of the arena)
+            if (b == 0) HIPCHK(L, hipMemcpyAsync(B.res_host + (size_t)i0 * res_stride, B.res_dev + (size_t)i0 * res_stride, res_stride * n, hipMemcpyDeviceToHost, s));
+            HIPCHK(L, hipEventRecord(t->ev_res[q.slot], s));
+            q.copied = true;
+            q.last_s = s;
+            t->last_s = s;
+            t->cand_n = -1;
+            t->slot_busy[q.slot] = true;
+            t->pend.push_back(q);
         }
-        azk_batch_scatter(s, sc);
-        if (!last) azk_level_geom_batch(s, reinterpret_cast<const AzLevelArgs *>(B.args_dev + off_lv[l]), n);
-        else azk_final_select_batch(s, reinterpret_cast<const AzFinalArgs *>(B.args_dev + off_fin), n);
-    }
-    HIPCHK(L, hipGetLastError());
-    // ---- every image's record on its way to the host; the searches enter the slots' queues
-    for (int b = 0; b < n; ++b) {
-        az_ctx *t = slots[b];
-        az_ctx::PendingSearch q;
-        q.p = *p; q.nlev = nlev; q.batch = 1;
-        q.npass = 0;
-        q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -rows0 - 1;
-        for (int l = 2; l < nlev; ++l) {
-            q.pass_lv[q.npass] = l;
-            q.pass_src[q.npass++] = (int)(&t->cnt->PR[l] - reinterpret_cast<int *>(t->cnt));
-        }
-        t->feat = maps[b]; t->d.H = H; t->d.W = W;
-        q.feat = maps[b]; q.fH = H; q.fW = W; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
-        q.slot = 0;                                   // (the slot's queue is empty: its first result slot, a slice of the arena)
-        if (b == 0) HIPCHK(L, hipMemcpyAsync(B.res_host, B.res_dev, res_stride * n, hipMemcpyDeviceToHost, s));
-        HIPCHK(L, hipEventRecord(t->ev_res[q.slot], s));
-        q.copied = true;
-        q.last_s = s;
-        t->last_s = s;
-        t->cand_n = -1;
-        t->slot_busy[q.slot] = true;
-        t->pend.push_back(q);
+
     }
     L->last_s = s;
     return AZ_OK;
