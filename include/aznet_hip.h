@@ -214,7 +214,8 @@ void *az_last_stream(az_ctx *ctx);
  *   maps: n device pointers to channel-last maps [H][W][C] (az_set_feature_map_dev_nhwc's layout), valid and unmodified
  *   until the batch's last az_batch_fetch; p: fixed proposal count, not the tuner's variant; 1 <= n <= AZ_BATCH_MAX.
  * The search is level by level for every image (root + its children in the first pass); an image whose tree outgrows a
- * fused kernel's tables, or a batch whose level outgrows max_regions rows, is run again on its own by az_batch_fetch.
+ * fused kernel's tables, or a batch whose level outgrows max_regions rows, is run again on its own by az_batch_fetch (a
+ * batch that would not fit, going by the rows per image of the context's last batch, is enqueued in parts that do).
  * Shapes / settings the lockstep form does not take (fewer than three levels, params.reserved bits 0 / 1 / 4, int6 on the
  * 16-bit matrix cores) are searched one image after the other, same results.  az_batch_fetch returns the images of the
  * OLDEST unfetched batch, i = 0 .. n-1 in order.  With two lanes (az_set_lanes) two batches may be in flight, else one.
