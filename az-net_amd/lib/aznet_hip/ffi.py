@@ -256,13 +256,14 @@ class AzContext(object):
         self._chk(self.L.az_load_head(self.h, C, n6, n71, n72, *[_p(a, ctypes.c_float) for a in arrs]))
         self.dims = dict(C=C, n6=n6, n71=n71, n72=n72, K6=K6)
 
-    def set_feature_map(self, fmap, wait=True):
+    def set_feature_map(self, fmap, wait=True, producer_done=False):
         """fmap: [1,C,H,W] or [C,H,W]; a NumPy array (copied to HBM) or a CUDA torch tensor
         (borrowed: its data_ptr is handed to the library, the tensor is kept alive here).
         The ctx stream is not torch's: torch's current stream is synchronised first, so a map the
         backbone is still writing is never read early.  wait=False (torch tensors only) skips the
         closing synchronisation of the ctx stream (az_set_feature_map_dev_async): the tensor then
-        has to stay untouched until the next propose/propose_fetch returns."""
+        has to stay untouched until the next propose/propose_fetch returns.  producer_done=True (torch tensors): the caller
+        knows the map is complete (e.g. a search that read it has been fetched): torch's stream is not synchronised."""
         if isinstance(fmap, np.ndarray):
             a = _f32(fmap)
             if a.ndim == 4:
@@ -275,7 +276,8 @@ class AzContext(object):
             t, cl = self._torch_map(fmap)
             C, H, W = (int(x) for x in t.shape)
             import torch
-            torch.cuda.current_stream(t.device).synchronize()     # producer (backbone) done
+            if not producer_done:
+                torch.cuda.current_stream(t.device).synchronize()     # producer (backbone) done
             fn = self.L.az_set_feature_map_dev_nhwc if cl else (
                 self.L.az_set_feature_map_dev if wait else self.L.az_set_feature_map_dev_async)
             self._chk(fn(self.h, ctypes.c_void_p(t.data_ptr()), C, H, W))

@@ -199,7 +199,7 @@ def _batch_backbones(net, ims, after=None):
         convs.append(conv)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return {"shape": ims[0].shape, "n": len(ims), "convs": convs, "blobs": blobs, "maps_done": ev,
+    return {"shape": ims[0].shape, "n": len(ims), "ims": ims, "convs": convs, "blobs": blobs, "maps_done": ev,
             "params": _params(ims[0].shape, scale[0], None)}
 
 
@@ -226,6 +226,32 @@ def _batch_finish(net, h, i):
     print('{0} proposals, evaluate {1} regions, reaches depth {2}.'
           .format(Y.shape[0], st.num_eval, st.depth))
     return Y
+
+
+def _batched_proposals(net, images, num_images, nb):
+    """(image, proposals, conv maps) for every image of the stream `images`, in order, the proposals made in lockstep batches
+    of up to nb consecutive images of one shape; the next batch's front-ends and backbones are enqueued before the current
+    batch's images are handed out, its search after the last of them has been taken."""
+    import itertools
+
+    def groups():
+        cur = []
+        for _ in range(num_images):
+            im = next(images)
+            if cur and (im.shape != cur[0].shape or len(cur) == nb):
+                yield cur
+                cur = []
+            cur.append(im)
+        if cur:
+            yield cur
+    pend = None
+    for grp in itertools.chain(groups(), [None]):
+        nxt = _batch_backbones(net, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
+        if pend is not None:
+            for i in range(pend["n"]):
+                Y = _batch_finish(net, pend, i)
+                yield pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}
+        pend = _batch_launch(net, nxt) if nxt is not None else None
 
 
 def _prefetched(imdb, indices, depth=2):
@@ -343,29 +369,14 @@ def test_proposals(net, imdb):
         # shape walk their zoom trees in lockstep (az_batch_launch).  Every image's boxes are what im_propose gives for it
         # alone, the printed lines and their order are the reference's; while one batch is searched the host enqueues the
         # next batch's front-ends and backbones behind it.
-        def groups():
-            cur = []
-            for i in range(num_images):
-                im = next(images)
-                if cur and (im.shape != cur[0].shape or len(cur) == nb):
-                    yield cur
-                    cur = []
-                cur.append(im)
-            if cur:
-                yield cur
-        pend, done_i = None, 0
+        done_i = 0
         _t['im_prop'].tic()
-        import itertools
-        for grp in itertools.chain(groups(), [None]):
-            nxt = _batch_backbones(net, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
-            if pend is not None:
-                for i in range(pend["n"]):
-                    prop_boxes[done_i] = _batch_finish(net, pend, i)
-                    done_i += 1
-                    _t['im_prop'].toc()
-                    print('im_prop: {:d}/{:d} {:.3f}s'.format(done_i, num_images, _t['im_prop'].average_time))
-                    _t['im_prop'].tic()
-            pend = _batch_launch(net, nxt) if nxt is not None else None
+        for _im, Y, _conv in _batched_proposals(net, images, num_images, nb):
+            prop_boxes[done_i] = Y
+            done_i += 1
+            _t['im_prop'].toc()
+            print('im_prop: {:d}/{:d} {:.3f}s'.format(done_i, num_images, _t['im_prop'].average_time))
+            _t['im_prop'].tic()
     elif _can_queue(hnet):
         # One image ahead: while the GPU works on image i the host reads image i+1 and enqueues its whole pipeline behind
         # it.  Same boxes, same printed lines in the same order; the timer counts from one finished image to the next
@@ -427,13 +438,26 @@ def test_net_shared(sc_net, frcnn_net, imdb):
     # order; the reference's loop (test.py:690-737) waits for each image before it reads the next.
     images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
     queued = _can_queue(hnet) and num_images > 0
+    # cfg.TEST.BATCH_IMAGES > 1 (an extension): the proposals of consecutive images of one shape in lockstep batches
+    # (az_batch_launch), the detection head image by image as before; same detections, same printed lines
+    nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
+    batched = nb > 1 and queued and bool(cfg.SEAR.FIXED_PROPOSAL_NUM)
+    gen = _batched_proposals(sc_net, images, num_images, nb) if batched else None
     pend, im = None, None
-    if queued:
+    if queued and not batched:
         im = next(images)
         pend = _propose_start(sc_net, im)
     for i in range(num_images):
         _t['im_detect'].tic()
-        if queued:
+        if batched:
+            im, prop, conv = next(gen)
+            # (the image's map is complete -- its search has been fetched --: bound to the context without waiting for torch's
+            #  stream, on which the NEXT batch's backbones are already queued)
+            c0 = conv[cfg.SEAR.FRCNN_CONV[0]]
+            hnet.ctx.set_feature_map(c0, producer_done=True)
+            hnet._conv = c0
+            scores, boxes, _ = _frcnn_forward(frcnn_net, im, prop, num_classes, conv)
+        elif queued:
             prop, conv = _propose_finish(sc_net, pend, return_conv=True)
             scores, boxes, _ = _frcnn_forward(frcnn_net, im, prop, num_classes, conv)
             if i + 1 < num_images:

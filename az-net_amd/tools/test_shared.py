@@ -19,6 +19,8 @@ FLAGS = [
     ("--net_az", "caffemodel_az", "AZ-Net weights (.caffemodel / .npz) or synthetic[:seed]", "synthetic", str),
     ("--imdb", "imdb_name", "dataset to test", "synthetic_600x1000_4", str),
     ("--comp", "comp_mode", "competition mode", None, None),
+    # (extension) cfg.TEST.BATCH_IMAGES: the PROPOSALS of consecutive images of one shape in lockstep batches (same detections)
+    ("--batch-images", "batch_images", "make the proposals of up to N consecutive images of one shape in lockstep (default 1)", 1, int),
 ]
 
 
@@ -39,7 +41,8 @@ def load_det_head(spec):
 def main():
     args = _cli.parse("Detect objects with AZ-Net proposals and Fast R-CNN on shared conv layers",
                       [_cli.COMMON, _cli.THRESH, FLAGS])
-    _cli.setup_cfg(args, "Test")
+    cfg = _cli.setup_cfg(args, "Test")
+    cfg.TEST.BATCH_IMAGES = max(1, int(getattr(args, "batch_images", 1) or 1))
     for f in (args.caffemodel_az, args.caffemodel_frcnn):
         if not f.startswith("synthetic"):
             _cli.wait_for(f, args.wait)

@@ -215,6 +215,35 @@ def test_test_net_shared_matches_the_reference_run(rig, mods):
             assert abs(all_boxes[j][i].shape[0] - ref.shape[0]) <= 5
 
 
+@pytest.mark.parametrize("nb", [2, 16])
+def test_test_net_shared_with_lockstep_proposals(rig, mods, nb):
+    """cfg.TEST.BATCH_IMAGES in the detection loop: the proposals of consecutive images in lockstep batches, the Fast R-CNN
+    head image by image -- the reference run's printed lines (g13), detections.pkl and NMS lists of the one-by-one loop."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    g, net, dnet, imdb, C = rig
+    from detect import test as T
+
+    def run():
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            nms = T.test_net_shared({"full": net, "fc": net}, {"fc": dnet}, imdb)
+        with open(os.path.join(C.get_output_dir(imdb, net), "detections.pkl"), "rb") as f:
+            return buf.getvalue(), nms, pickle.load(f)
+    out1, nms1, det1 = run()
+    C.cfg.TEST.BATCH_IMAGES = nb
+    try:
+        out2, nms2, det2 = run()
+    finally:
+        C.cfg.TEST.BATCH_IMAGES = 1
+    assert scrub(out2) == scrub(out1) == str(g["det_stdout"])
+    n = int(g["n_img"])
+    for j in range(1, 21):
+        for i in range(n):
+            assert np.array_equal(det1[j][i], det2[j][i])
+            a, b = nms1[j][i], nms2[j][i]
+            assert (isinstance(a, list) and isinstance(b, list) and a == b == []) or np.array_equal(a, b)
+
+
 def _run_tool(args, timeout=900, extra_env=None):
     env = dict(os.environ)
     env.update(extra_env or {})
