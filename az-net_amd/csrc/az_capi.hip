@@ -335,18 +335,20 @@ static void destroy_twin(az_ctx *c)
 static void destroy_batch(az_ctx *c)
 {
     if (!c) return;
-    auto &B = c->batch;
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (az_ctx *t : B.slots) {
-        if (t->stream) hipStreamSynchronize(t->stream);
-        if (t->h_res_own0) { t->h_res[0] = t->h_res_own0; t->h_res_own0 = nullptr; }     // (its own block again: az_destroy frees that)
-        az_destroy(t);
+    for (auto &B : c->bsets) {
+        for (az_ctx *t : B.slots) {
+            if (t->stream) hipStreamSynchronize(t->stream);
+            if (t->h_res_own0) { t->h_res[0] = t->h_res_own0; t->h_res_own0 = nullptr; }     // (its own block again: az_destroy frees that)
+            az_destroy(t);
+        }
+        B.slots.clear();
+        for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev, (void *)B.res_dev}) if (q) hipFree(q);
+        if (B.args_host) hipHostFree(B.args_host);
+        if (B.res_host) hipHostFree(B.res_host);
+        B = az_ctx::Batch();
     }
-    B.slots.clear();
-    for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev, (void *)B.res_dev}) if (q) hipFree(q);
-    if (B.args_host) hipHostFree(B.args_host);
-    if (B.res_host) hipHostFree(B.res_host);
-    B = az_ctx::Batch();
+    c->bset_turn = 0;
     c->batch_order.clear();
     c->batch_next = 0;
 }
@@ -522,13 +524,14 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
     int lane, rc;
     az_ctx *L = batch_lane(c, &lane, &rc);
     if (!L) return rc;
-    auto &B = L->batch;
-    if (B.n_live) return fail(c, AZ_ERR_STATE, "az_batch_launch: the lane's previous batch has not been fetched");
+    const int set = L->bset_turn;
+    auto &B = L->bsets[set];
+    if (B.n_live) return fail(c, AZ_ERR_STATE, "az_batch_launch: two batches per lane are already in flight, fetch one first");
     HIPCHK(c, hipSetDevice(c->device));
     while ((int)B.slots.size() < n) {
         az_ctx *t = nullptr;
         if ((rc = make_lane(c, &t, false, "az_batch_launch")) != AZ_OK) return rc;
-        t->batch_lane = L;
+        t->batch_set = &B;
         B.slots.push_back(t);
     }
     for (int b = 0; b < n; ++b) {
@@ -538,7 +541,7 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
     }
     if (L != c) { if (L->cal.state == 0 && c->cal.state != 0) L->cal = c->cal; }
     int not_taken = 0;
-    rc = batch_launch_impl(L, n, B.slots.data(), p, maps, H, W, &not_taken);
+    rc = batch_launch_impl(L, B, n, B.slots.data(), p, maps, H, W, &not_taken);
     if (rc && !not_taken) { if (L != c) c->err = L->err; return rc; }
     B.lockstep = !not_taken;
     if (not_taken) {
@@ -566,7 +569,8 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
     }
     B.n_live = n; B.next_fetch = 0;
     for (int &r : B.rows_acc) r = 0;
-    c->batch_order.push_back(lane);
+    c->batch_order.push_back(lane | (set << 1));
+    L->bset_turn ^= 1;
     if (c->lanes == 2) c->batch_next ^= 1;
     return AZ_OK;
 }
@@ -575,17 +579,18 @@ int az_batch_fetch(az_ctx *c, int i, double *boxes_out, float *scores_out, int c
 {
     if (!c || c->owner || c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_batch_fetch without az_batch_launch");
     if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_batch_fetch: bad arguments");
-    const int lane = c->batch_order.front();
+    const int lane = c->batch_order.front() & 1, set = c->batch_order.front() >> 1;
     az_ctx *L = lane ? c->twin : c;
     if (!L) return fail(c, AZ_ERR_STATE, "az_batch_fetch: the lane is gone");
-    auto &B = L->batch;
+    auto &B = L->bsets[set];
     if (i != B.next_fetch || i >= B.n_live) return fail(c, AZ_ERR_INVALID, "az_batch_fetch: the images of a batch are fetched in order, each once");
     az_ctx *t = B.slots[i];
     int rc = t->pend.empty() ? fail(t, AZ_ERR_STATE, "az_batch_fetch: the image's search is not queued") :
                                fetch_entry(t, 0, boxes_out, scores_out, cap, n_out, st);
     if (rc) c->err = t->err;
     if (++B.next_fetch == B.n_live) {
-        if (B.lockstep) { for (int l = 0; l < AZ_MAX_LEVELS; ++l) B.rows_hint[l] = B.rows_acc[l]; B.hint_n = B.n_live; }
+        if (B.lockstep)       // (what the lane's next batches go by: both sets)
+            for (auto &S : L->bsets) { for (int l = 0; l < AZ_MAX_LEVELS; ++l) S.rows_hint[l] = B.rows_acc[l]; S.hint_n = B.n_live; }
         B.n_live = 0; B.next_fetch = 0;
         c->batch_order.pop_front();
     }
@@ -722,9 +727,9 @@ int az_propose_stage_result_dev(az_ctx *c, void *dst_dev, size_t cap_bytes)
 int az_batch_stage_results_dev(az_ctx *c, void *dst_dev, size_t pitch_bytes, size_t cap_bytes)
 {
     if (!c || c->owner || c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev without az_batch_launch");
-    az_ctx *L = c->batch_order.back() ? c->twin : c;
-    if (!L || !L->batch.n_live) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: no batch in flight");
-    auto &B = L->batch;
+    az_ctx *L = (c->batch_order.back() & 1) ? c->twin : c;
+    if (!L || !L->bsets[c->batch_order.back() >> 1].n_live) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: no batch in flight");
+    auto &B = L->bsets[c->batch_order.back() >> 1];
     const int n = B.n_live;
     if (B.next_fetch) return fail(c, AZ_ERR_STATE, "az_batch_stage_results_dev: call it right behind az_batch_launch");
     az_ctx *t0 = B.slots[0];

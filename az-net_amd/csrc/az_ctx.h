@@ -198,11 +198,13 @@ struct az_ctx {
         int rows_hint[AZ_MAX_LEVELS] = {0};   // rows of the passes of the last fetched batch (which int6 kernel takes a level)
         int rows_acc[AZ_MAX_LEVELS] = {0};
         int hint_n = 0;                       // images of the batch rows_hint was taken from (0: none yet)
-    } batch;
-    std::deque<int> batch_order;              // (owner) lanes of the batches in flight, oldest first
+    } bsets[2];                               // two sets per lane, used in turn: the host enqueues a lane's next batch while its
+                                              // current one runs (same stream: the two do not interleave on the GPU)
+    int bset_turn = 0;
+    std::deque<int> batch_order;              // (owner) lane | set << 1 of the batches in flight, oldest first
     int batch_next = 0;
     bool head_bufs = true;                    // false: a batch slot that has not needed pool5 / slabs / h6 / h7 yet
-    az_ctx *batch_lane = nullptr;             // (a batch slot) the lane whose passes its rois ride in
+    Batch *batch_set = nullptr;               // (a batch slot) the batch set it belongs to
     // (a batch slot) its counters / result block and its first host result slot are slices of the lane's arenas
     // (Batch::res_dev / res_host); the slot's own allocations stay in its lists and are freed with it
     unsigned char *h_res_own0 = nullptr;
@@ -686,7 +688,7 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
 int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes);
 // n images of one shape in lockstep on lane L (whose head buffers the passes use), image b on slots[b] with map maps[b];
 // AZ_ERR_STATE + *not_taken = 1: this shape / these settings do not take the lockstep form (nothing enqueued)
-int batch_launch_impl(az_ctx *L, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken);
+int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken);
 // ---- az_capi.hip --------------------------------------------------------------------------------------------------------
 int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W, bool wait = true);
 int ensure_lane_head(az_ctx *t);          // the head buffers of a lane / batch slot created without them

@@ -1160,8 +1160,8 @@ int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int
         if (q.stage_dst && (rc2 = stage_impl(c, q.stage_dst, q.stage_cap)) != AZ_OK) return rc2;
         return fetch_entry(c, c->pend.size() - 1, boxes_out, scores_out, cap, n_out, st);
     };
-    if (q.batch && c->batch_lane)
-        for (int l = 0; l < nlev; ++l) c->batch_lane->batch.rows_acc[l] += (l < 2) ? (l == 0 ? h.specU : 0) : h.PR[l];
+    if (q.batch && c->batch_set)
+        for (int l = 0; l < nlev; ++l) c->batch_set->rows_acc[l] += (l < 2) ? (l == 0 ? h.specU : 0) : h.PR[l];
     if ((h.err & 2048) && q.batch) {
         // a level of the batch held more rois than the head's buffers take rows: every image of it runs again on its own
         az_params p2 = q.p;
@@ -1307,14 +1307,14 @@ template <typename T> T *args_at(unsigned char *base, size_t &off, int n)
     return p;
 }
 
-void head_pass_batch(az_ctx *L, const AzHeadDims &d, const int *Mptr, int im_h, int im_w, double eps, float *zoom, float *score,
+void head_pass_batch(az_ctx *L, az_ctx::Batch &B, const AzHeadDims &d, const int *Mptr, int im_h, int im_w, double eps, float *zoom, float *score,
                      float *delta, double min_side, bool keep_flags, bool keys, bool many_rows)
 {
     hipStream_t s = L->stream;
     // (gemm mode 3 -- int6 on the 16-bit matrix cores, every fp32 operand as three bf16 terms: the planes carry no per-map
     //  scale, so the images of a batch share a pass there as well; mode 2's fp16 terms are scaled per map: not taken)
-    azk_roi_pool(s, nullptr, d, L->spatial_scale, L->batch.rois_cat, Mptr, L->maxR, L->pool5, L->pool5p,
-                 azk_act_plane_elems(L->maxR, d.K6), L->gemm_parts, 0, 0, nullptr, L->batch.feats);
+    azk_roi_pool(s, nullptr, d, L->spatial_scale, B.rois_cat, Mptr, L->maxR, L->pool5, L->pool5p,
+                 azk_act_plane_elems(L->maxR, d.K6), L->gemm_parts, 0, 0, nullptr, B.feats);
     const bool can12 = (d.n6 / 128) * L->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
                        azk_fc_chunk(d.K6, L->S6) * L->S6 == d.K6 && azk_fc_chunk(d.K6, L->S6) >= 64 &&
                        L->gemm12_min_rows < 0x7fffffff;
@@ -1329,13 +1329,13 @@ void head_pass_batch(az_ctx *L, const AzHeadDims &d, const int *Mptr, int im_h, 
     azk_fc_reduce(s, L->part, L->b6, Mptr, L->maxR, d.n6, L->S6, L->h6, d.n6, 1);
     float *p7 = L->part7 ? L->part7 : L->part;
     azk_fc_gemm(s, L->h6, d.n6, L->W7, d.n6, Mptr, L->maxR, d.n7, d.n6, L->S7, p7, 1 << 30, nullptr);
-    azk_tail(s, p7, L->S7, L->b7, d.n7, L->Wt, L->bt, L->batch.ubox_cat, Mptr, L->maxR, im_h, im_w, eps, zoom, score, delta,
+    azk_tail(s, p7, L->S7, L->b7, d.n7, L->Wt, L->bt, B.ubox_cat, Mptr, L->maxR, im_h, im_w, eps, zoom, score, delta,
              L->pred_u, keep_flags ? L->keep_u : nullptr, min_side, (keep_flags && keys) ? L->key_u : nullptr);
 }
 
 }  // namespace
 
-int batch_launch_impl(az_ctx *L, int n_all, az_ctx **slots_all, const az_params *p, const float *const *maps_all, int H, int W, int *not_taken)
+int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all, const az_params *p, const float *const *maps_all, int H, int W, int *not_taken)
 {
     *not_taken = 0;
     int rc = check_ready(L, false, true);          // (join: the passes work in the lane's per-search head buffers)
@@ -1353,7 +1353,6 @@ int batch_launch_impl(az_ctx *L, int n_all, az_ctx **slots_all, const az_params 
         if (!slots_all[b]->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
     }
     HIPCHK(L, hipSetDevice(L->device));
-    auto &B = L->batch;
     hipStream_t s = L->stream;
     // (before anything can decide that the images are searched one by one: those searches use the slices, too)
     const size_t res_slot = RES_HDR + (size_t)AZ_TOPK_MAX * 36;
@@ -1500,7 +1499,7 @@ int batch_launch_impl(az_ctx *L, int n_all, az_ctx **slots_all, const az_params 
         }
         azk_batch_gather(s, g);
         const int *Mptr = B.off + AZ_BATCH_MAX + 1;
-        head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
+        head_pass_batch(L, B, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
                         rows0 * n >= B.gemm12_rows);
         azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
         // ---- the levels
@@ -1511,7 +1510,7 @@ int batch_launch_impl(az_ctx *L, int n_all, az_ctx **slots_all, const az_params 
                 g.rows[b] = &t->cnt->PR[l]; g.err[b] = &t->cnt->err; g.rois[b] = t->urois; g.ubox[b] = t->ubox; g.feat[b] = maps[b];
             }
             azk_batch_gather(s, g);
-            head_pass_batch(L, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
+            head_pass_batch(L, B, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_u, L->score_u, L->delta_u, p->min_side, true, last,
                             (B.hint_n > 0 ? (long)B.rows_hint[l] * n / B.hint_n : 0) >= B.gemm12_rows);
             AzScatterArgs sc;
             std::memset(&sc, 0, sizeof(sc));

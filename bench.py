@@ -1210,7 +1210,7 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
             rep.append(r_ms)
             fracs.append(floors(st_i[-1][1], fm, 1.0)["merged_pass_t_min_us"])
         # the same set in lockstep batches (az_batch_launch): the images of B consecutive iterations of the dataset loop walk
-        # their trees together, every level's rois of all of them in ONE head pass; as many batches in flight as lanes
+        # their trees together, every level's rois of all of them in ONE head pass; two batches in flight per lane
         lock = {}
         lanes = int(getattr(cnet.ctx, "lanes", 1))
         for bs in (4, 8, 16, 32):
@@ -1219,7 +1219,7 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
             def run_batches(collect=None):
                 launched = 0
                 for gi in range(len(groups)):
-                    while launched < min(len(groups), gi + lanes):
+                    while launched < min(len(groups), gi + 2 * lanes):
                         cnet.ctx.batch_launch(prm, [maps[j] for j in groups[launched]], producer_done=True)
                         launched += 1
                     for i in range(len(groups[gi])):
@@ -1283,7 +1283,7 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
                    "history-primed replay (what calibrated_tz / tz_sweep measure for ONE image); merged_pass_floor.frac = mean "
                    "of the images' merged-pass floors (of their replay's passes) over ms_per_image; lockstep_batches = the same "
                    "set, B consecutive images per az_batch_launch (each image's result identical to its search alone: "
-                   "tests/test_gpu_batch.py), as many batches in flight as lanes; its floor charges one weight stream per pass of "
+                   "tests/test_gpu_batch.py), two batches in flight per lane; its floor charges one weight stream per pass of "
                    "a BATCH")
     return res
 

@@ -218,7 +218,8 @@ void *az_last_stream(az_ctx *ctx);
  * batch that would not fit, going by the rows per image of the context's last batch, is enqueued in parts that do).
  * Shapes / settings the lockstep form does not take (fewer than three levels, params.reserved bits 0 / 1 / 4, int6 on the
  * 16-bit matrix cores) are searched one image after the other, same results.  az_batch_fetch returns the images of the
- * OLDEST unfetched batch, i = 0 .. n-1 in order.  With two lanes (az_set_lanes) two batches may be in flight, else one.
+ * OLDEST unfetched batch, i = 0 .. n-1 in order.  Two batches per lane may be in flight (a lane's two run one after the other
+ * on its stream: the host enqueues the next while the GPU works on the current one; with az_set_lanes(ctx, 2) four).
  * Uses max_regions-sized geometry buffers per image slot (~25 KB per region), allocated at the first batch. */
 int az_batch_launch(az_ctx *ctx, int n, const az_params *p, const float *const *maps_nhwc_dev, int C, int H, int W);
 int az_batch_fetch(az_ctx *ctx, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);

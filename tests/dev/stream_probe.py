@@ -99,7 +99,7 @@ def main():
         print("== anchors/img %d Tz %.5f: %.4f ms/image over %d images, reruns %d, forms %s" % (a, tz, dt / n * 1e3, n, reruns, forms))
         for bs in [int(x) for x in args.batch.split(",") if x]:
             groups = [order[i:i + bs] for i in range(0, len(order), bs)]
-            inflight = args.lanes
+            inflight = 2 * args.lanes
 
             def run_batches(collect=None):
                 launched = 0

@@ -165,7 +165,10 @@ def test_shapes_the_lockstep_form_does_not_take(mods):
         assert st.search_form != 5
 
 
-def test_two_batches_in_flight_and_single_searches_in_between(mods):
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_batches_in_flight_and_single_searches_in_between(mods, lanes):
+    """Two batches per lane may be launched before the first is fetched (a lane's two run one after the other on its stream,
+    those of two lanes interleave on the GPU); results come back oldest first."""
     torch, ffi, synth, HipAZNet, orc = mods
     head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
     H, W, sc = 600, 1000, 1.0
@@ -173,20 +176,21 @@ def test_two_batches_in_flight_and_single_searches_in_between(mods):
     ref = HipAZNet(head, name="two_ref")
     want = _reference(ffi, ref, H, W, sc, TZ_OBJ, fmaps)
     net = HipAZNet(head, name="two")
-    net.ctx.set_lanes(2)
+    net.ctx.set_lanes(lanes)
+    inflight = 2 * lanes
     prm = ffi.AzContext.make_params(H, W, sc, TZ_OBJ)
     tm = [_cl(torch, f) for f in fmaps]
     with pytest.raises(ffi.AzError):
         net.ctx.batch_fetch(0)                                         # nothing launched
-    groups = [list(range(0, 8)), list(range(8, 16)), list(range(16, 24)), [3, 4, 5], [23]]
+    groups = [list(range(0, 8)), list(range(8, 16)), list(range(16, 24)), [3, 4, 5], [23], [1, 0], list(range(4, 20)), [7]]
     launched = 0
     for gi in range(len(groups)):
-        while launched < min(len(groups), gi + 2):
+        while launched < min(len(groups), gi + inflight):
             net.ctx.batch_launch(prm, [tm[j] for j in groups[launched]], producer_done=True)
             launched += 1
         if gi == 0:
             with pytest.raises(ffi.AzError):
-                net.ctx.batch_launch(prm, [tm[0]], producer_done=True)     # both lanes hold a batch
+                net.ctx.batch_launch(prm, [tm[0]], producer_done=True)     # every lane holds two batches
             with pytest.raises(ffi.AzError):
                 net.ctx._chk(net.ctx.L.az_batch_fetch(net.ctx.h, 1, None, None, 0, None, None))
         for i, j in enumerate(groups[gi]):
