@@ -228,10 +228,12 @@ def _batch_finish(net, h, i):
     return Y
 
 
-def _batched_proposals(net, images, num_images, nb):
+def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
     """(image, proposals, conv maps) for every image of the stream `images`, in order, the proposals made in lockstep batches
-    of up to nb consecutive images of one shape; the next batch's front-ends and backbones are enqueued before the current
-    batch's images are handed out, its search after the last of them has been taken."""
+    of up to nb consecutive images of one shape; the next batch's front-ends, backbones and (launch_ahead: a context takes
+    two batches per lane) search are enqueued before the current batch's images are handed out.  launch_ahead=False: the
+    next search only after the last image of the current batch has been taken (a caller that runs other kernels of its own
+    on the context between two images -- the detection head -- would find them queued behind that search)."""
     import itertools
 
     def groups():
@@ -247,11 +249,13 @@ def _batched_proposals(net, images, num_images, nb):
     pend = None
     for grp in itertools.chain(groups(), [None]):
         nxt = _batch_backbones(net, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
+        if nxt is not None and launch_ahead:
+            nxt = _batch_launch(net, nxt)
         if pend is not None:
             for i in range(pend["n"]):
                 Y = _batch_finish(net, pend, i)
                 yield pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}
-        pend = _batch_launch(net, nxt) if nxt is not None else None
+        pend = (nxt if launch_ahead else _batch_launch(net, nxt)) if nxt is not None else None
 
 
 def _prefetched(imdb, indices, depth=2):
@@ -442,7 +446,7 @@ def test_net_shared(sc_net, frcnn_net, imdb):
     # (az_batch_launch), the detection head image by image as before; same detections, same printed lines
     nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
     batched = nb > 1 and queued and bool(cfg.SEAR.FIXED_PROPOSAL_NUM)
-    gen = _batched_proposals(sc_net, images, num_images, nb) if batched else None
+    gen = _batched_proposals(sc_net, images, num_images, nb, launch_ahead=False) if batched else None
     pend, im = None, None
     if queued and not batched:
         im = next(images)
