@@ -258,6 +258,14 @@ def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
         pend = (nxt if launch_ahead else _batch_launch(net, nxt)) if nxt is not None else None
 
 
+def _prefetch_depth():
+    """Images read ahead by the worker thread: cfg.TEST.PREFETCH, and with lockstep batches (cfg.TEST.BATCH_IMAGES) at least
+    two batches' worth -- the host must be able to collect the next batch while the GPU works on the current one."""
+    d = int(cfg.TEST.get("PREFETCH", 2))
+    nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
+    return max(d, 2 * nb) if (nb > 1 and d > 0) else d
+
+
 def _prefetched(imdb, indices, depth=2):
     """imdb.image_at(i) for i in indices, in order, read up to `depth` images ahead by a worker thread (decoding a JPEG or
     reading an .npy takes as long as the GPU needs for an image).  depth <= 0: read in the caller's thread."""
@@ -366,7 +374,7 @@ def test_proposals(net, imdb):
         os.makedirs(output_dir)
     _t = {'im_prop': Timer()}
     num_boxes = 0.0
-    images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
+    images = _prefetched(imdb, list(range(num_images)), depth=_prefetch_depth())
     nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
     if nb > 1 and _can_queue(hnet) and cfg.SEAR.FIXED_PROPOSAL_NUM:
         # cfg.TEST.BATCH_IMAGES (an extension: the reference has no such key): up to that many CONSECUTIVE images of one
@@ -440,7 +448,7 @@ def test_net_shared(sc_net, frcnn_net, imdb):
     # front-end + backbone + search are enqueued as soon as image i's detections are on the host: the GPU works on image
     # i+1 while Python does image i's per-class bookkeeping below.  Same calls per image, same printed lines in the same
     # order; the reference's loop (test.py:690-737) waits for each image before it reads the next.
-    images = _prefetched(imdb, list(range(num_images)), depth=int(cfg.TEST.get("PREFETCH", 2)))
+    images = _prefetched(imdb, list(range(num_images)), depth=_prefetch_depth())
     queued = _can_queue(hnet) and num_images > 0
     # cfg.TEST.BATCH_IMAGES > 1 (an extension): the proposals of consecutive images of one shape in lockstep batches
     # (az_batch_launch), the detection head image by image as before; same detections, same printed lines

@@ -93,7 +93,7 @@ def main():
     torch.cuda.set_device(device)
     from datasets.factory import get_imdb
     from detect.config import get_output_dir
-    from detect.test import test_proposals, im_propose, _propose_start, _propose_finish, _prefetched, _can_queue
+    from detect.test import test_proposals, im_propose, _propose_start, _propose_finish, _prefetched, _prefetch_depth, _can_queue
     cfg.TEST.BATCH_IMAGES = max(1, int(getattr(args, "batch_images", 1) or 1))
     net = load_net(args.caffemodel, device, tuned=bool(getattr(args, "tune_backbone", False)))
     nets = {"full": net, "fc": net}
@@ -135,7 +135,7 @@ def main():
     gat = azdist.DeviceGather(net.ctx, int(cfg.SEAR.NUM_PROPOSALS), rows, dev) if fixed else None
     t = Timer()
     local = []
-    images = _prefetched(imdb, mine, depth=int(cfg.TEST.get("PREFETCH", 2)))
+    images = _prefetched(imdb, mine, depth=_prefetch_depth())
     nb = int(cfg.TEST.get("BATCH_IMAGES", 1))
     if fixed and _can_queue(net) and nb > 1:
         # --batch-images: the rank's consecutive images of one shape in lockstep batches (detect.test.test_proposals does the
