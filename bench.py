@@ -1226,7 +1226,9 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
                         r = cnet.ctx.batch_fetch(i, want_stats=collect is not None)
                         if collect is not None:
                             collect.append(r[1])
-            for _ in range(4 if bs == 4 else 2):          # (untimed: slots, row hints; the first size also takes the idle gap)
+            # (untimed: every lane's two slot sets are created and have a batch's row counts behind them; the first size also
+            #  takes the idle gap)
+            for _ in range(max(4 if bs == 4 else 2, -(-4 * lanes // len(groups)) + 1)):
                 run_batches()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

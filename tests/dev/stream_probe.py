@@ -111,8 +111,8 @@ def main():
                         r = net.ctx.batch_fetch(i, want_stats=collect is not None)
                         if collect is not None:
                             collect.append(r[1])
-            run_batches()
-            run_batches()
+            for _ in range(max(2, -(-2 * inflight // len(groups)) + 1)):      # (every lane's two slot sets created, hints set)
+                run_batches()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.passes):
