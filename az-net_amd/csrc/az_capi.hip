@@ -597,6 +597,28 @@ int az_batch_fetch(az_ctx *c, int i, double *boxes_out, float *scores_out, int c
     return rc;
 }
 
+// Every image of the oldest unfetched batch in one call: image i's boxes at boxes_out + i * cap * 4, its scores at
+// scores_out + i * cap (may be NULL), its count in n_out[i], its statistics in st[i] (may be NULL).  Returns the first error
+// (the remaining images are still collected, their n_out = -1 on error).
+int az_batch_fetch_all(az_ctx *c, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st)
+{
+    if (!c || c->owner || c->batch_order.empty()) return fail(c, AZ_ERR_STATE, "az_batch_fetch_all without az_batch_launch");
+    if (!boxes_out || !n_out || cap < 0) return fail(c, AZ_ERR_INVALID, "az_batch_fetch_all: bad arguments");
+    const int lane = c->batch_order.front() & 1, set = c->batch_order.front() >> 1;
+    az_ctx *L = lane ? c->twin : c;
+    if (!L) return fail(c, AZ_ERR_STATE, "az_batch_fetch_all: the lane is gone");
+    const int n = L->bsets[set].n_live, i0 = L->bsets[set].next_fetch;
+    int first = AZ_OK;
+    std::string msg;
+    for (int i = i0; i < n; ++i) {
+        const int rc = az_batch_fetch(c, i, boxes_out + (size_t)i * cap * 4, scores_out ? scores_out + (size_t)i * cap : nullptr, cap,
+                                      &n_out[i], st ? &st[i] : nullptr);
+        if (rc) { n_out[i] = -1; if (!first) { first = rc; msg = c->err; } }
+    }
+    if (first) c->err = msg;
+    return first;
+}
+
 int az_propose(az_ctx *c, const az_params *p, double *boxes_out, float *scores_out, int cap, int *n_out,
                az_stats *st)
 {

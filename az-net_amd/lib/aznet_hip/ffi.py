@@ -36,7 +36,7 @@ SYMBOLS = [
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
     "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
     "az_bias_relu", "az_bias_relu_pool", "az_batch_launch", "az_batch_fetch", "az_batch_next_stream",
-    "az_batch_stage_results_dev",
+    "az_batch_stage_results_dev", "az_batch_fetch_all",
 ]
 
 
@@ -156,6 +156,7 @@ def load_library(path=None):
     L.az_batch_launch.argtypes = [vp, ci, ctypes.POINTER(AzParams), ctypes.POINTER(vp), ci, ci, ci]
     L.az_batch_fetch.argtypes = [vp, ci, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     L.az_batch_stage_results_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t]
+    L.az_batch_fetch_all.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
     u8p = ctypes.POINTER(ctypes.c_uint8)
     L.az_last_anchors.argtypes = [vp, dp, fp, ci, cip]
@@ -430,15 +431,29 @@ class AzContext(object):
         import torch
         maps, ptrs, shape = [], [], None
         converted = False
+        # (the layout checks of a tensor are remembered per tensor object, as propose_launch does: a batch of 32 maps is
+        #  otherwise ~0.3 ms of Python)
+        ck = self.__dict__.setdefault("_bmap_cache", {})
         for f in fmaps:
-            t = f if f.dim() == 4 else f[None]
-            assert t.is_cuda and t.dtype == torch.float32 and t.device.index == self.device and t.shape[0] == 1
-            if not t.is_contiguous(memory_format=torch.channels_last):
-                t = t.contiguous(memory_format=torch.channels_last)
-                converted = True
-            C, H, W = (int(x) for x in t.shape[1:])
-            assert shape in (None, (C, H, W)), "the maps of a batch have one shape"
-            shape = (C, H, W)
+            ent = ck.get(id(f))
+            ptr = f.data_ptr()
+            if ent is None or ent[0] != ptr or ent[2]() is not f:
+                import weakref
+                t = f if f.dim() == 4 else f[None]
+                assert t.is_cuda and t.dtype == torch.float32 and t.device.index == self.device and t.shape[0] == 1
+                if not t.is_contiguous(memory_format=torch.channels_last):
+                    t = t.contiguous(memory_format=torch.channels_last)
+                    converted = True
+                    ent = None                       # (a converted copy is made again every time: the source may have changed)
+                else:
+                    if len(ck) > 256:
+                        ck.clear()
+                    ent = ck[id(f)] = (ptr, tuple(int(x) for x in t.shape[1:]), weakref.ref(f), t)
+                chw = tuple(int(x) for x in t.shape[1:])
+            else:
+                t, chw = ent[3], ent[1]
+            assert shape in (None, chw), "the maps of a batch have one shape"
+            shape = chw
             maps.append(t)
             ptrs.append(t.data_ptr())
         C, H, W = shape
@@ -459,6 +474,30 @@ class AzContext(object):
         """Right behind batch_launch: the batch's result records to dst_ptr + i * pitch_bytes (a raw device pointer, e.g. rows
         of the RCCL send buffer), device to device; image i's is complete when batch_fetch(i) returns."""
         self._chk(self.L.az_batch_stage_results_dev(self.h, ctypes.c_void_p(int(dst_ptr)), int(pitch_bytes), int(cap_bytes)))
+
+    def batch_fetch_all(self, want_scores=False, want_stats=False):
+        """Every image of the oldest unfetched batch in one call (az_batch_fetch_all): a list of what batch_fetch(i) returns."""
+        if not getattr(self, "_batches", None):
+            raise AzError(-4, "batch_fetch_all without batch_launch")
+        params, maps = self._batches[0]
+        n, cap = len(maps), params.num_proposals
+        boxes = np.empty((n, cap, 4), dtype=np.float64)
+        scores = np.empty((n, cap), dtype=np.float32)
+        cnt = (ctypes.c_int * n)()
+        st = (AzStats * n)()
+        try:
+            self._chk(self.L.az_batch_fetch_all(self.h, _p(boxes, ctypes.c_double), _p(scores, ctypes.c_float), cap, cnt, st))
+        finally:
+            self._batches.popleft()
+        out = []
+        for i in range(n):
+            r = [boxes[i, :cnt[i]].copy()]
+            if want_scores:
+                r.append(scores[i, :cnt[i]].copy())
+            if want_stats:
+                r.append(st[i])
+            out.append(r[0] if len(r) == 1 else tuple(r))
+        return out
 
     def batch_record_event(self):
         """A torch.cuda.Event recorded now on the stream of the batch launched last: behind that batch."""

@@ -215,7 +215,9 @@ def _batch_launch(net, h):
 def _batch_finish(net, h, i):
     """Image i of the batch, formatted as im_propose formats it."""
     hnet = net["full"] if isinstance(net, dict) else net
-    Y, st = hnet.ctx.batch_fetch(i, want_stats=True)
+    if "results" not in h:
+        h["results"] = hnet.ctx.batch_fetch_all(want_stats=True)      # (the whole batch in one call)
+    Y, st = h["results"][i]
     shape = h["shape"]
     if cfg.SEAR.APPEND_BOXES:
         Y = _append_boxes(Y)

@@ -1222,10 +1222,9 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
                     while launched < min(len(groups), gi + 2 * lanes):
                         cnet.ctx.batch_launch(prm, [maps[j] for j in groups[launched]], producer_done=True)
                         launched += 1
-                    for i in range(len(groups[gi])):
-                        r = cnet.ctx.batch_fetch(i, want_stats=collect is not None)
-                        if collect is not None:
-                            collect.append(r[1])
+                    rs = cnet.ctx.batch_fetch_all(want_stats=collect is not None)
+                    if collect is not None:
+                        collect.extend(r[1] for r in rs)
             # (untimed: every lane's two slot sets are created and have a batch's row counts behind them; the first size also
             #  takes the idle gap)
             for _ in range(max(4 if bs == 4 else 2, -(-4 * lanes // len(groups)) + 1)):

@@ -223,6 +223,10 @@ void *az_last_stream(az_ctx *ctx);
  * Uses max_regions-sized geometry buffers per image slot (~25 KB per region), allocated at the first batch. */
 int az_batch_launch(az_ctx *ctx, int n, const az_params *p, const float *const *maps_nhwc_dev, int C, int H, int W);
 int az_batch_fetch(az_ctx *ctx, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);
+/* All images of the oldest unfetched batch (those not yet fetched one by one) in ONE call: image i's boxes at
+ * boxes_out + i * cap * 4, scores at scores_out + i * cap (may be NULL), count in n_out[i] (-1: that image failed), statistics
+ * in stats[i] (may be NULL); returns the first error, the other images are collected all the same. */
+int az_batch_fetch_all(az_ctx *ctx, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);
 /* the hipStream_t the NEXT az_batch_launch runs on: make it wait for the maps' producers there */
 void *az_batch_next_stream(az_ctx *ctx);
 /* az_propose_stage_result_dev for the batch launched last (call it right behind az_batch_launch): image i's record to

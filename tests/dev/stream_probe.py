@@ -107,10 +107,9 @@ def main():
                     while launched < min(len(groups), gi + inflight):
                         net.ctx.batch_launch(prm, [convs[j] for j in groups[launched]], producer_done=True)
                         launched += 1
-                    for i in range(len(groups[gi])):
-                        r = net.ctx.batch_fetch(i, want_stats=collect is not None)
-                        if collect is not None:
-                            collect.append(r[1])
+                    rs = net.ctx.batch_fetch_all(want_stats=collect is not None)
+                    if collect is not None:
+                        collect.extend(r[1] for r in rs)
             for _ in range(max(2, -(-2 * inflight // len(groups)) + 1)):      # (every lane's two slot sets created, hints set)
                 run_batches()
             torch.cuda.synchronize()

@@ -86,6 +86,30 @@ def test_batch_equals_every_image_alone(mods, n):
             _covered(st)
 
 
+def test_fetch_all_equals_fetch_one_by_one(mods):
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    tm = [_cl(torch, f) for f in _object_set(synth, 9)]
+    net = HipAZNet(head, name="fetch_all")
+    prm = ffi.AzContext.make_params(H, W, sc, TZ_OBJ)
+    net.ctx.batch_launch(prm, tm, producer_done=True)
+    one = [net.ctx.batch_fetch(i, want_scores=True, want_stats=True) for i in range(9)]
+    net.ctx.batch_launch(prm, tm, producer_done=True)
+    net.ctx.batch_launch(prm, tm[:4], producer_done=True)
+    every = net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
+    part = net.ctx.batch_fetch_all(want_scores=True)
+    assert len(every) == 9 and len(part) == 4
+    for (Y, S, st), (Y1, S1, st1) in zip(every, one):
+        assert np.array_equal(Y, Y1) and np.array_equal(S, S1)
+        _same(st, st1)
+        assert st.search_form == 5
+    for (Y, S), (Y1, S1, _) in zip(part, one):
+        assert np.array_equal(Y, Y1) and np.array_equal(S, S1)
+    with pytest.raises(ffi.AzError):
+        net.ctx.batch_fetch_all()
+
+
 def test_batch_against_the_cpu_oracle(mods):
     torch, ffi, synth, HipAZNet, orc = mods
     head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
