@@ -212,8 +212,8 @@ def _batch_launch(net, h):
     return h
 
 
-def _batch_finish(net, h, i):
-    """Image i of the batch, formatted as im_propose formats it."""
+def _batch_finish(net, h, i, quiet=False):
+    """Image i of the batch, formatted as im_propose formats it (quiet: the line im_propose prints is returned, not printed)."""
     hnet = net["full"] if isinstance(net, dict) else net
     if "results" not in h:
         h["results"] = hnet.ctx.batch_fetch_all(want_stats=True)      # (the whole batch in one call)
@@ -225,39 +225,59 @@ def _batch_finish(net, h, i):
         Y[:, 1::4] = np.maximum(Y[:, 1::4], 0)
         Y[:, 2::4] = np.minimum(Y[:, 2::4], shape[1] - 1)
         Y[:, 3::4] = np.minimum(Y[:, 3::4], shape[0] - 1)
-    print('{0} proposals, evaluate {1} regions, reaches depth {2}.'
-          .format(Y.shape[0], st.num_eval, st.depth))
+    line = '{0} proposals, evaluate {1} regions, reaches depth {2}.'.format(Y.shape[0], st.num_eval, st.depth)
+    if quiet:
+        return Y, line
+    print(line)
     return Y
 
 
 def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
-    """(image, proposals, conv maps) for every image of the stream `images`, in order, the proposals made in lockstep batches
-    of up to nb consecutive images of one shape; the next batch's front-ends, backbones and (launch_ahead: a context takes
-    two batches per lane) search are enqueued before the current batch's images are handed out.  launch_ahead=False: the
-    next search only after the last image of the current batch has been taken (a caller that runs other kernels of its own
-    on the context between two images -- the detection head -- would find them queued behind that search)."""
-    import itertools
+    """(image, proposals, conv maps) for every image of the stream `images`, IN ORDER, the proposals made in lockstep batches
+    of up to nb images of one shape.  A dataset mixes shapes (VOC: 500x375, 375x500, 500x333, ...): a batch is the next
+    unprocessed image plus the images of ITS shape among the following ones, within a window of four batches' worth that is
+    read ahead; results (and the per-image line im_propose prints) are handed out in dataset order whatever order the
+    batches ran in.  The next batch's front-ends, backbones and (launch_ahead: a context takes two batches per lane) search
+    are enqueued before the current batch's images are handed out; launch_ahead=False: the next search only after the last
+    image of the current batch has been taken (a caller that runs other kernels of its own on the context between two images
+    -- the detection head -- would find them queued behind that search)."""
+    win = max(4 * nb, nb)
+    buf, done = {}, {}
+    state = {"read": 0, "out": 0}
 
-    def groups():
-        cur = []
-        for _ in range(num_images):
-            im = next(images)
-            if cur and (im.shape != cur[0].shape or len(cur) == nb):
-                yield cur
-                cur = []
-            cur.append(im)
-        if cur:
-            yield cur
+    def next_group():
+        while state["read"] < num_images and len(buf) < win:
+            buf[state["read"]] = next(images)
+            state["read"] += 1
+        if not buf:
+            return None
+        i0 = min(buf)
+        shape = buf[i0].shape
+        idx = [i for i in sorted(buf) if buf[i].shape == shape][:nb]
+        return idx, [buf.pop(i) for i in idx]
+
     pend = None
-    for grp in itertools.chain(groups(), [None]):
-        nxt = _batch_backbones(net, grp, after=(pend["done"] if pend is not None else None)) if grp is not None else None
-        if nxt is not None and launch_ahead:
-            nxt = _batch_launch(net, nxt)
+    while True:
+        g = next_group()
+        nxt = None
+        if g is not None:
+            nxt = _batch_backbones(net, g[1], after=(pend["done"] if pend is not None else None))
+            nxt["idx"] = g[0]
+            if launch_ahead:
+                nxt = _batch_launch(net, nxt)
         if pend is not None:
             for i in range(pend["n"]):
-                Y = _batch_finish(net, pend, i)
-                yield pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}
-        pend = (nxt if launch_ahead else _batch_launch(net, nxt)) if nxt is not None else None
+                Y, line = _batch_finish(net, pend, i, quiet=True)
+                done[pend["idx"][i]] = (pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}, line)
+            while state["out"] in done:
+                im, Y, conv, line = done.pop(state["out"])
+                state["out"] += 1
+                print(line)
+                yield im, Y, conv
+        if nxt is None:
+            break
+        pend = nxt if launch_ahead else _batch_launch(net, nxt)
+    assert not done and state["out"] == num_images
 
 
 def _prefetch_depth():

@@ -244,6 +244,64 @@ def test_test_net_shared_with_lockstep_proposals(rig, mods, nb):
             assert (isinstance(a, list) and isinstance(b, list) and a == b == []) or np.array_equal(a, b)
 
 
+def test_lockstep_batches_over_a_dataset_of_mixed_shapes(mods):
+    """A dataset mixes image shapes: test_proposals with cfg.TEST.BATCH_IMAGES batches every image with the images of ITS shape
+    among the following ones (a read-ahead window) and still prints and stores everything in dataset order -- the lines and
+    boxes of the one-by-one loop.  A narrow VGG16 reads the blobs (every map is its own image's)."""
+    torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
+    from aznet_hip.backbone import VGG16Conv5
+    from datasets.imdb import imdb as imdb_base
+    from detect import config as C
+    from detect import test as T
+    shapes = [(375, 500), (600, 1000), (375, 500), (375, 500), (500, 375), (600, 1000), (375, 500), (333, 500), (500, 375),
+              (375, 500), (600, 1000), (375, 500), (375, 500), (500, 375)]
+    ims = [synth.make_scene_image(700 + j, h, w) for j, (h, w) in enumerate(shapes)]
+
+    class Mixed(imdb_base):
+        def __init__(self):
+            imdb_base.__init__(self, "mixed_shapes")
+            self._image_index = list(range(len(ims)))
+            self._classes = ["c%d" % i for i in range(21)]
+
+        def image_at(self, i):
+            return ims[i]
+
+        def image_path_at(self, i):
+            return "synthetic:/%d" % i
+    old = (C.cfg.SEAR.get("Tz", 0.0), C.cfg.EXP_DIR, C.cfg.TEST.NUM_PROPOSALS)
+    C.cfg_set_path("harness_mixed")
+    C.cfg_set_mode("Test", 0.3)
+    C.cfg.TEST.NUM_PROPOSALS = 100
+    try:
+        bb = VGG16Conv5(device="cuda:0", seed=11, width_div=32)
+        net = HipAZNet(synth.make_head(seed=77, **synth.SMALL_DIMS), backbone=bb, name="mixed")
+        bb.normalize_output(T._get_image_blob(ims[1], net)[0])
+        imdb = Mixed()
+
+        def run():
+            buf = io.StringIO()
+            with redirect_stdout(buf):
+                pf = T.test_proposals({"full": net, "fc": net}, imdb)
+            with open(pf, "rb") as f:
+                return scrub(buf.getvalue()), pickle.load(f)["boxes"]
+        out1, boxes1 = run()
+        assert len({b.shape[0] for b in boxes1}) >= 1 and len(boxes1) == len(ims)
+        for nb in (2, 4, 16):
+            C.cfg.TEST.BATCH_IMAGES = nb
+            try:
+                out2, boxes2 = run()
+            finally:
+                C.cfg.TEST.BATCH_IMAGES = 1
+            assert out2 == out1, nb
+            for i, (a, b) in enumerate(zip(boxes1, boxes2)):
+                assert np.array_equal(a, b), (nb, i)
+    finally:
+        C.cfg_set_mode("Test", old[0])
+        C.cfg.EXP_DIR = old[1]
+        C.cfg.TEST.NUM_PROPOSALS = old[2]
+        shutil.rmtree(os.path.join(C.cfg.ROOT_DIR, "output", "harness_mixed"), ignore_errors=True)
+
+
 def _run_tool(args, timeout=900, extra_env=None):
     env = dict(os.environ)
     env.update(extra_env or {})
