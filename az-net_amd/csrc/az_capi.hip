@@ -610,6 +610,7 @@ int az_batch_fetch_all(az_ctx *c, double *boxes_out, float *scores_out, int cap,
     const int n = L->bsets[set].n_live, i0 = L->bsets[set].next_fetch;
     int first = AZ_OK;
     std::string msg;
+    for (int i = 0; i < i0; ++i) n_out[i] = 0;          // (already fetched one by one)
     for (int i = i0; i < n; ++i) {
         const int rc = az_batch_fetch(c, i, boxes_out + (size_t)i * cap * 4, scores_out ? scores_out + (size_t)i * cap : nullptr, cap,
                                       &n_out[i], st ? &st[i] : nullptr);
