@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libaznet_hip.so")
 AZ_MAX_LEVELS = 16
 AZ_NUM_SUBREG = 11
 AZ_OK = 0
+AZ_BATCH_MAX = 32          # include/aznet_hip.h
 AZ_ERR_INVALID, AZ_ERR_HIP, AZ_ERR_CAPACITY, AZ_ERR_STATE, AZ_ERR_NO_DEVICE = -1, -2, -3, -4, -5
 _ERR_NAMES = {-1: "AZ_ERR_INVALID", -2: "AZ_ERR_HIP", -3: "AZ_ERR_CAPACITY", -4: "AZ_ERR_STATE",
               -5: "AZ_ERR_NO_DEVICE"}

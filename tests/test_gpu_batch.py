@@ -269,3 +269,52 @@ def test_two_fp16_terms_keep_their_images_apart(mods):
         Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
         assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
         assert st.search_form != 5
+
+
+def test_batch_entry_points_refuse_what_they_cannot_do(mods):
+    """Argument and state errors come back as AZ_ERR_* with a message, nothing is left half-launched."""
+    import ctypes
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    H, W, sc = 600, 1000, 1.0
+    tm = [_cl(torch, f) for f in _object_set(synth, 3)]
+    net = HipAZNet(head, name="errs")
+    ctx, L = net.ctx, net.ctx.L
+    prm = ffi.AzContext.make_params(H, W, sc, TZ_OBJ)
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tm])
+    C = synth.SMALL_DIMS["C"]
+
+    def rc(*a):
+        return L.az_batch_launch(ctx.h, *a)
+    assert rc(0, ctypes.byref(prm), ptrs, C, 38, 63) == ffi.AZ_ERR_INVALID                      # no image
+    assert rc(ffi.AZ_BATCH_MAX + 1, ctypes.byref(prm), ptrs, C, 38, 63) == ffi.AZ_ERR_INVALID   # too many
+    assert rc(3, ctypes.byref(prm), ptrs, C + 4, 38, 63) == ffi.AZ_ERR_INVALID                  # another head's channel count
+    assert rc(3, None, ptrs, C, 38, 63) == ffi.AZ_ERR_INVALID
+    bad = (ctypes.c_void_p * 3)(tm[0].data_ptr(), None, tm[2].data_ptr())
+    assert rc(3, ctypes.byref(prm), bad, C, 38, 63) == ffi.AZ_ERR_INVALID                       # a null map
+    var = ffi.AzContext.make_params(H, W, sc, TZ_OBJ, fixed_num=False)
+    assert rc(3, ctypes.byref(var), ptrs, C, 38, 63) == ffi.AZ_ERR_INVALID                      # data-dependent proposal count
+    tune = ffi.AzContext.make_params(H, W, sc, 0.0, tune=True)
+    assert rc(3, ctypes.byref(tune), ptrs, C, 38, 63) == ffi.AZ_ERR_INVALID                     # the tuner's variant
+    with pytest.raises(ffi.AzError):
+        ctx.batch_fetch(0)                                                                      # nothing was launched by any of these
+    # a good batch; fetching out of order or twice is refused, the batch itself stays whole
+    want = _reference(ffi, HipAZNet(head, name="errs_ref"), H, W, sc, TZ_OBJ, _object_set(synth, 3))
+    ctx.batch_launch(prm, tm, producer_done=True)
+    boxes = np.empty((300, 4)); n = ctypes.c_int(0)
+    bp = boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    assert L.az_batch_fetch(ctx.h, 1, bp, None, 300, ctypes.byref(n), None) == ffi.AZ_ERR_INVALID
+    assert L.az_batch_fetch(ctx.h, 0, bp, None, 10, ctypes.byref(n), None) == ffi.AZ_ERR_CAPACITY   # cap too small: image 0 is gone ...
+    with pytest.raises(ffi.AzError):
+        ctx.set_lanes(2)                                                                        # ... but the batch is still in flight
+    Y1 = ctx.batch_fetch(1)
+    Y2 = ctx.batch_fetch(2)
+    assert np.array_equal(Y1, want[1][0]) and np.array_equal(Y2, want[2][0])
+    with pytest.raises(ffi.AzError):
+        ctx.batch_fetch(2)
+    ctx.set_lanes(2)
+    ctx.set_lanes(1)
+    # and the context is as good as new
+    ctx.batch_launch(prm, tm, producer_done=True)
+    for i, (Y, S) in enumerate(ctx.batch_fetch_all(want_scores=True)):
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
