@@ -28,6 +28,13 @@ def test_header_symbols_are_exported():
     assert b"gfx950" in L.az_version()
 
 
+def test_constants_the_binding_restates():
+    from aznet_hip import ffi
+    src = open(os.path.join(REPO, "include", "aznet_hip.h")).read()
+    assert int(re.search(r"#define\s+AZ_BATCH_MAX\s+(\d+)", src).group(1)) == ffi.AZ_BATCH_MAX
+    assert sorted(ffi.SEARCH_FORMS) == [0, 1, 2, 3, 4, 5]
+
+
 def test_no_gpu_means_loud_failure():
     """Without a gfx950 device az_create must fail (AZ_ERR_NO_DEVICE) -- never fall back."""
     import torch
