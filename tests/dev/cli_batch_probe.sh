@@ -8,4 +8,4 @@ for nb in 1 8 16; do
   done
   echo "batch-images $nb: $(grep 'average proposal generation time' /tmp/cli_$nb.log)"
 done
-rm -rf ../../output/cli_nb_* output/cli_nb_*
+rm -rf ../output/cli_nb_*
