@@ -195,3 +195,56 @@ def test_bench_self_launch_relays_rank_failures():
         assert r.returncode != 0
         assert '"metric"' not in r.stdout
         assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr or "Error" in r.stderr
+
+
+def test_batched_proposals_groups_by_shape_and_keeps_dataset_order(monkeypatch, capsys):
+    """detect.test._batched_proposals (cfg.TEST.BATCH_IMAGES): every image exactly once and in dataset order, a batch = images
+    of ONE shape (at most nb, taken from a read-ahead window), the per-image line printed in order -- with the GPU halves
+    replaced by recorders."""
+    from detect import test as T
+    shapes = [(375, 500, 3), (600, 1000, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3), (600, 1000, 3), (375, 500, 3),
+              (333, 500, 3), (500, 375, 3), (375, 500, 3), (600, 1000, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3),
+              (375, 500, 3), (375, 500, 3), (375, 500, 3)]
+    ims = [np.full(s, i, dtype=np.uint8) for i, s in enumerate(shapes)]
+    batches, log = [], []
+
+    def backbones(net, group, after=None):
+        assert len({im.shape for im in group}) == 1
+        h = {"shape": group[0].shape, "n": len(group), "ims": group, "convs": [("conv", int(im.flat[0])) for im in group],
+             "after": after}
+        log.append(("backbones", [int(im.flat[0]) for im in group]))
+        return h
+
+    def launch(net, h):
+        h["done"] = ("done", tuple(int(im.flat[0]) for im in h["ims"]))
+        batches.append([int(im.flat[0]) for im in h["ims"]])
+        log.append(("launch", batches[-1]))
+        return h
+
+    def finish(net, h, i, quiet=False):
+        k = int(h["ims"][i].flat[0])
+        return np.full((2, 4), float(k)), "line %d" % k
+    monkeypatch.setattr(T, "_batch_backbones", backbones)
+    monkeypatch.setattr(T, "_batch_launch", launch)
+    monkeypatch.setattr(T, "_batch_finish", finish)
+    for nb, ahead in ((4, True), (4, False), (2, True), (16, True), (1, True)):
+        del batches[:], log[:]
+        out = list(T._batched_proposals(None, iter(ims), len(ims), nb, launch_ahead=ahead))
+        printed = capsys.readouterr().out.split("\n")[:-1]
+        assert [int(im.flat[0]) for im, _, _ in out] == list(range(len(ims)))           # dataset order, each once
+        assert printed == ["line %d" % i for i in range(len(ims))]
+        assert all(float(Y[0, 0]) == i for i, (_, Y, _) in enumerate(out))
+        assert all(conv[T.cfg.SEAR.FRCNN_CONV[0]] == ("conv", i) for i, (_, _, conv) in enumerate(out))
+        assert sorted(i for b in batches for i in b) == list(range(len(ims)))
+        assert all(1 <= len(b) <= nb and len({shapes[i] for i in b}) == 1 and b == sorted(b) for b in batches)
+        # a batch starts with the oldest unprocessed image and reaches at most a window of 4 nb images ahead
+        seen = set()
+        for b in batches:
+            assert b[0] == min(set(range(len(ims))) - seen)
+            assert max(b) < b[0] + 4 * nb + len(b)
+            seen.update(b)
+        if nb >= 4:
+            assert any(len(b) > 1 and b != list(range(b[0], b[0] + len(b))) for b in batches)   # images were pulled forward
+        # launch_ahead: the next batch's search is enqueued before the current batch's images are handed out
+        launches = [i for i, e in enumerate(log) if e[0] == "launch"]
+        assert len(launches) == len(batches)
