@@ -179,3 +179,33 @@ def test_stream_against_the_reference_run_g14(mods, lanes, depth):
         # every proposal of the reference within reach of one of ours (a tie at the cut may swap the last ones)
         hit = [np.abs(Y - r).max(axis=1).min() <= 1e-3 for r in ref]
         assert np.mean(hit) >= 0.97, (k, float(np.mean(hit)))
+
+
+@pytest.mark.parametrize("nb", [12, 5])
+def test_lockstep_batches_against_the_reference_run_g14(mods, nb):
+    """g14 again, the 12 images in lockstep batches (az_batch_launch: every level's rois of a batch in ONE head pass): every
+    image forwards the reference's number of unique rois at every level and returns its proposals."""
+    import torch
+    from helpers import load
+    ffi, synth, HipAZNet, orc = mods
+    g = load("g14_stream.npz")
+    n, H, W, Tz = int(g["n_img"]), int(g["H"]), int(g["W"]), float(g["Tz"])
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    maps = [torch.from_numpy(synth.make_object_map(j, synth.SMALL_DIMS["C"], 38, 63)).cuda().contiguous(memory_format=torch.channels_last)
+            for j in range(n)]
+    net = HipAZNet(head, name="g14_batch")
+    prm = ffi.AzContext.make_params(H, W, 1.0, Tz)
+    got = []
+    for rep in range(2):
+        got = []
+        for i0 in range(0, n, nb):
+            net.ctx.batch_launch(prm, maps[i0:i0 + nb], producer_done=True)
+            got += net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
+    for k, (Y, S, st) in enumerate(got):
+        calls = [int(x) for x in g["calls%d" % k]]
+        assert st.search_form == 5 and st.n_reruns == 0
+        assert [int(st.level_unique[l]) for l in range(st.n_levels) if st.level_unique[l] > 0] == calls, (k, calls)
+        ref = g["Y%d" % k]
+        assert Y.shape == ref.shape, (k, Y.shape, ref.shape)
+        hit = [np.abs(Y - r).max(axis=1).min() <= 1e-3 for r in ref]
+        assert np.mean(hit) >= 0.97, (k, float(np.mean(hit)))
