@@ -49,7 +49,11 @@ __global__ void __launch_bounds__(256) k_batch_gather(AzGatherArgs a)
     if (blockIdx.x == 0) {
         if (threadIdx.x <= a.n) a.off_out[threadIdx.x] = off[threadIdx.x];
         if (threadIdx.x == 0) a.off_out[AZ_BATCH_MAX + 1] = total;          // the pass's row count (the head kernels' Mptr)
-        if (threadIdx.x < a.n) a.feats_out[threadIdx.x] = a.feat[threadIdx.x];
+        if (threadIdx.x < a.n) {
+            a.feats_out[threadIdx.x] = a.feat[threadIdx.x];
+            a.feat_hw_out[2 * threadIdx.x] = a.fh[threadIdx.x];
+            a.feat_hw_out[2 * threadIdx.x + 1] = a.fw[threadIdx.x];
+        }
     }
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < total; r += gridDim.x * blockDim.x) {
         int b = 0;
@@ -59,6 +63,8 @@ __global__ void __launch_bounds__(256) k_batch_gather(AzGatherArgs a)
         float *dst = a.rois_cat + 5 * (size_t)r;
         dst[0] = (float)b;                                                   // Caffe's roi_batch_ind
         dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+        a.row_hw_out[2 * (size_t)r] = a.im_h[b];
+        a.row_hw_out[2 * (size_t)r + 1] = a.im_w[b];
         if (a.ubox[b]) {
             const double *ub = a.ubox[b] + 4 * (size_t)i;
             double *ud = a.ubox_cat + 4 * (size_t)r;

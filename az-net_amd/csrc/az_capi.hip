@@ -343,7 +343,7 @@ static void destroy_batch(az_ctx *c)
             az_destroy(t);
         }
         B.slots.clear();
-        for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.args_dev, (void *)B.res_dev}) if (q) hipFree(q);
+        for (void *q : {(void *)B.off, (void *)B.rois_cat, (void *)B.ubox_cat, (void *)B.feats, (void *)B.feat_hw, (void *)B.row_hw, (void *)B.args_dev, (void *)B.res_dev}) if (q) hipFree(q);
         if (B.args_host) hipHostFree(B.args_host);
         if (B.res_host) hipHostFree(B.res_host);
         B = az_ctx::Batch();
@@ -517,10 +517,21 @@ void *az_batch_next_stream(az_ctx *c)
 
 int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *maps, int C, int H, int W)
 {
+    if (!p || n < 1 || n > AZ_BATCH_MAX) return fail(c, AZ_ERR_INVALID, "az_batch_launch: 1 .. AZ_BATCH_MAX maps of the loaded head's channel count");
+    az_params pa[AZ_BATCH_MAX];
+    int Hs[AZ_BATCH_MAX], Ws[AZ_BATCH_MAX];
+    for (int b = 0; b < n; ++b) { pa[b] = *p; Hs[b] = H; Ws[b] = W; }
+    return az_batch_launch_shapes(c, n, pa, maps, C, Hs, Ws);
+}
+
+int az_batch_launch_shapes(az_ctx *c, int n, const az_params *pa, const float *const *maps, int C, const int *Hs, const int *Ws)
+{
     if (!c || c->owner) return fail(c, AZ_ERR_INVALID, "az_batch_launch: the context itself, not a lane");
     if (!c->head_loaded) return fail(c, AZ_ERR_STATE, "az_load_head has not been called");
-    if (!p || !maps || n < 1 || n > AZ_BATCH_MAX || C != c->d.C || H <= 0 || W <= 0)
+    if (!pa || !maps || !Hs || !Ws || n < 1 || n > AZ_BATCH_MAX || C != c->d.C)
         return fail(c, AZ_ERR_INVALID, "az_batch_launch: 1 .. AZ_BATCH_MAX maps of the loaded head's channel count");
+    for (int b = 0; b < n; ++b)
+        if (Hs[b] <= 0 || Ws[b] <= 0) return fail(c, AZ_ERR_INVALID, "az_batch_launch: 1 .. AZ_BATCH_MAX maps of the loaded head's channel count");
     int lane, rc;
     az_ctx *L = batch_lane(c, &lane, &rc);
     if (!L) return rc;
@@ -541,7 +552,7 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
     }
     if (L != c) { if (L->cal.state == 0 && c->cal.state != 0) L->cal = c->cal; }
     int not_taken = 0;
-    rc = batch_launch_impl(L, B, n, B.slots.data(), p, maps, H, W, &not_taken);
+    rc = batch_launch_impl(L, B, n, B.slots.data(), pa, maps, Hs, Ws, &not_taken);
     if (rc && !not_taken) { if (L != c) c->err = L->err; return rc; }
     B.lockstep = !not_taken;
     if (not_taken) {
@@ -553,8 +564,8 @@ int az_batch_launch(az_ctx *c, int n, const az_params *p, const float *const *ma
             az_ctx *t = B.slots[b];
             if (!maps[b]) return fail(c, AZ_ERR_INVALID, "az_batch_launch: null map");
             HIPCHK(c, hipStreamWaitEvent(t->stream, L->ev_hand, 0));
-            t->feat = maps[b]; t->d.H = H; t->d.W = W;
-            if ((rc = launch_impl(t, p)) != AZ_OK) {
+            t->feat = maps[b]; t->d.H = Hs[b]; t->d.W = Ws[b];
+            if ((rc = launch_impl(t, &pa[b])) != AZ_OK) {
                 c->err = t->err;
                 // (the images launched so far are dropped: nothing of this batch can be fetched)
                 for (int q = 0; q < b; ++q) {

@@ -187,6 +187,7 @@ struct az_ctx {
         float *rois_cat = nullptr;            // the pass's rois / anchors / map table
         double *ubox_cat = nullptr;
         const float **feats = nullptr;
+        int *feat_hw = nullptr, *row_hw = nullptr;   // every image's map size [AZ_BATCH_MAX][2]; every row's image size [maxR][2]
         unsigned char *args_dev = nullptr, *args_host = nullptr;   // the geometry kernels' arguments, one block per image and launch
         size_t args_cap = 0;
         // the images' result blocks (counters + selected boxes and scores) lie side by side, on the device and in pinned host
@@ -686,9 +687,11 @@ bool nms_keep_tagged(const long long *hk, int n, unsigned tag, long spins)
 int launch_impl(az_ctx *c, const az_params *p);
 int fetch_entry(az_ctx *c, size_t idx, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *st);
 int stage_impl(az_ctx *c, void *dst_dev, size_t cap_bytes);
-// n images of one shape in lockstep on lane L (whose head buffers the passes use), image b on slots[b] with map maps[b];
+// n images (one shape or several, the same number of levels) in lockstep on lane L (whose head buffers the passes use), image b
+// on slots[b] with parameters params[b] and map maps[b] of Hs[b] x Ws[b] cells;
 // AZ_ERR_STATE + *not_taken = 1: this shape / these settings do not take the lockstep form (nothing enqueued)
-int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n, az_ctx **slots, const az_params *p, const float *const *maps, int H, int W, int *not_taken);
+int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n, az_ctx **slots, const az_params *params /* [n] */, const float *const *maps,
+                      const int *Hs, const int *Ws, int *not_taken);
 // ---- az_capi.hip --------------------------------------------------------------------------------------------------------
 int set_feature_map_common(az_ctx *c, const float *src, bool src_is_host, int C, int H, int W, bool wait = true);
 int ensure_lane_head(az_ctx *t);          // the head buffers of a lane / batch slot created without them

@@ -278,6 +278,9 @@ struct AzGatherArgs {
     const float *rois[AZ_BATCH_MAX];          // its rois [rows][5]
     const double *ubox[AZ_BATCH_MAX];         // its anchor boxes [rows][4] (NULL: the pass decodes nothing)
     const float *feat[AZ_BATCH_MAX];          // its channel-last map
+    int fh[AZ_BATCH_MAX], fw[AZ_BATCH_MAX];   // ... of fh x fw cells
+    int im_h[AZ_BATCH_MAX], im_w[AZ_BATCH_MAX];   // the image's size (what its decoded boxes are clipped to)
+    int *feat_hw_out, *row_hw_out;            // device tables: [n][2] map sizes for RoIPool, [rows][2] image sizes for the heads
     int *off_out;                             // [AZ_BATCH_MAX + 2]: first row of every image, off_out[n] = off_out[AZ_BATCH_MAX + 1] = rows of the pass
     float *rois_cat; double *ubox_cat;        // the pass's rois (column 0 = image index: Caffe's roi_batch_ind) and anchors
     const float **feats_out;                  // device table RoIPool reads the maps from
@@ -301,7 +304,8 @@ void azk_batch_scatter(hipStream_t s, const AzScatterArgs &a);
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale,
                   const float *urois, const int *Uptr, int capU, float *pool5, unsigned short *planes,
                   size_t plane_stride, int parts, int min_strips, int coop_tail = 0, const float *xscale = nullptr,
-                  const float *const *feats = nullptr);     // feats (device table): the map of roi row r is feats[(int)roi[0]]
+                  const float *const *feats = nullptr,      // feats (device table): the map of roi row r is feats[(int)roi[0]]
+                  const int *feat_hw = nullptr);            // ... of feat_hw[2 b] x feat_hw[2 b + 1] cells (NULL: d.H x d.W all)
 void azk_nchw_to_nhwc(hipStream_t s, const float *in, float *out, int C, int HW);
 // rows [R][C*49]: Caffe order (c*49+p) <-> the bin-major order (p*C+c) pool5 / W6 use in HBM
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major);
@@ -361,7 +365,7 @@ void azk_fc_reduce(hipStream_t s, const float *part, const float *bias, const in
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
               float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u = nullptr, double min_side = 0.0,
-              unsigned *key_u = nullptr);
+              unsigned *key_u = nullptr, const int *row_hw = nullptr);   // row_hw [row][2]: the image every row clips against
 size_t azk_tail_lds_bytes(int n7);
 size_t azk_tail_weight_rows(int n7);
 int azk_fc_split(int K);

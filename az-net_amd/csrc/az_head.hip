@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                                                   const int *Uptr, float *__restrict__ pool5,
                                                   unsigned short *__restrict__ planes, size_t plane_stride,
                                                   int parts, int min_strips, int coop_tail,
-                                                  const float *__restrict__ xscale, const float *const *feats)
+                                                  const float *__restrict__ xscale, const float *const *feats,
+                                                  const int *__restrict__ feat_hw)
 {
     constexpr int P = 7, PP = 49;                 // pooled_h = pooled_w = 7 (test_fc.prototxt:20-21)
     __shared__ __attribute__((aligned(16))) float spart[4][512];
@@ -135,6 +136,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
             const float *roi = urois + 5 * (size_t)u;
             // (a batch of images, az_batch.hip: roi[0] is the image's index in the batch -- Caffe's roi_batch_ind)
             const float *fm = feats ? feats[(int)roi[0]] : feat;
+            // (... and, with maps of several sizes in the batch, the size of ITS map)
+            const int fH = (feats && feat_hw) ? feat_hw[2 * (int)roi[0]] : d.H, fW = (feats && feat_hw) ? feat_hw[2 * (int)roi[0] + 1] : d.W;
             const int rsw = (int)roundf(roi[1] * spatial_scale);
             const int rsh = (int)roundf(roi[2] * spatial_scale);
             const int rew = (int)roundf(roi[3] * spatial_scale);
@@ -147,8 +150,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
             int he = (int)ceilf((float)(ph + 1) * bh) + rsh;
             int ws = (int)floorf((float)pw * bw) + rsw;
             int we = (int)ceilf((float)(pw + 1) * bw) + rsw;
-            hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
-            ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
+            hs = min(max(hs, 0), fH); he = min(max(he, 0), fH);
+            ws = min(max(ws, 0), fW); we = min(max(we, 0), fW);
             const bool empty = (he <= hs) || (we <= ws);
             float *out = pool5 + (size_t)u * d.K6 + (size_t)p * d.C;
             // up to 8 channel chunks (512 channels) per pass, so 8 independent loads are in flight
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
     #pragma unroll
                 for (int j = 0; j < 8; ++j) m[j] = empty ? 0.0f : -FLT_MAX;
                 for (int h = hs; h < he; ++h) {
-                    const float *row = fm + ((size_t)h * d.W + ws) * d.C + cb + lane;
+                    const float *row = fm + ((size_t)h * fW + ws) * d.C + cb + lane;
                     for (int w = ws; w < we; ++w, row += d.C) {
                         float v[8];
     #pragma unroll
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         const int ph = p / P, pw = p - ph * P;
         const float *roi = urois + 5 * (size_t)u;
         const float *fm = feats ? feats[(int)roi[0]] : feat;
+        const int fH = (feats && feat_hw) ? feat_hw[2 * (int)roi[0]] : d.H, fW = (feats && feat_hw) ? feat_hw[2 * (int)roi[0] + 1] : d.W;
         const int rsw = (int)roundf(roi[1] * spatial_scale);
         const int rsh = (int)roundf(roi[2] * spatial_scale);
         const int rew = (int)roundf(roi[3] * spatial_scale);
@@ -197,8 +201,8 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
         int he = (int)ceilf((float)(ph + 1) * bh) + rsh;
         int ws = (int)floorf((float)pw * bw) + rsw;
         int we = (int)ceilf((float)(pw + 1) * bw) + rsw;
-        hs = min(max(hs, 0), d.H); he = min(max(he, 0), d.H);
-        ws = min(max(ws, 0), d.W); we = min(max(we, 0), d.W);
+        hs = min(max(hs, 0), fH); he = min(max(he, 0), fH);
+        ws = min(max(ws, 0), fW); we = min(max(we, 0), fW);
         const bool empty = (he <= hs) || (we <= ws);
         const int nw = we - ws;
         const int ncell = empty ? 0 : (he - hs) * nw;
@@ -213,7 +217,7 @@ __global__ void __launch_bounds__(256) k_roi_pool(const float *__restrict__ feat
                 for (int q = 0; q < 4; ++q) {
                     const int ii = min(i + 4 * q, ncell - 1);      // a repeated cell cannot change a max
                     const int hh = ii / nw;
-                    const float *cell = fm + ((size_t)(hs + hh) * d.W + (ws + ii - hh * nw)) * d.C;
+                    const float *cell = fm + ((size_t)(hs + hh) * fW + (ws + ii - hh * nw)) * d.C;
                     v0[q] = *reinterpret_cast<const float4 *>(cell + c0);
                     v1[q] = *reinterpret_cast<const float4 *>(cell + c1);
                 }
@@ -834,7 +838,7 @@ __global__ void __launch_bounds__(TAIL_WAVES * 64)
 k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float *__restrict__ b7, int n7, int kq,
              const float *__restrict__ WtT, const float *__restrict__ bt, const double *__restrict__ ubox,
              const int *Uptr, int im_h, int im_w, double eps, float *zoom_u, float *score_u, float *delta_u,
-             double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u)
+             double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u, const int *__restrict__ row_hw)
 {
     extern __shared__ __attribute__((aligned(16))) float tail_lds[];
     const int KP = TAIL_WAVES * kq;
@@ -932,7 +936,9 @@ k_tail_fused(const float *__restrict__ part7, int S7, size_t slab7, const float 
                         delta_u[(size_t)u * 4 * AZ_NSUB + 4 * t + q] = d4[q];
                     }
                     double *pb = pred_u + ((size_t)u * AZ_NSUB + t) * 4;
-                    az_decode_box(ubox + 4 * (size_t)u, d4, im_h, im_w, eps, pb);
+                    // (a batch of images of several shapes, az_batch.hip: every row clips against ITS image)
+                    az_decode_box(ubox + 4 * (size_t)u, d4, row_hw ? row_hw[2 * (size_t)u] : im_h,
+                                  row_hw ? row_hw[2 * (size_t)u + 1] : im_w, eps, pb);
                     if (keep_u) {
                         const bool kp = cand_keep(pb, min_side);
                         keep_u[(size_t)u * AZ_NSUB + t] = kp ? 1 : 0;
@@ -1032,11 +1038,11 @@ __global__ void k_det_gather(const int *Pptr, const int *__restrict__ inv, int n
 // --------------------------------------------------------------------------------------
 void azk_roi_pool(hipStream_t s, const float *feat_nhwc, AzHeadDims d, float spatial_scale, const float *urois,
                   const int *Uptr, int capU, float *pool5, unsigned short *planes, size_t plane_stride, int parts,
-                  int min_strips, int coop_tail, const float *xscale, const float *const *feats)
+                  int min_strips, int coop_tail, const float *xscale, const float *const *feats, const int *feat_hw)
 {
     (void)capU;
     hipLaunchKernelGGL(k_roi_pool, dim3(4096), dim3(256), 0, s, feat_nhwc, d, spatial_scale, urois, Uptr, pool5,
-                       planes, plane_stride, parts, min_strips, coop_tail, xscale, feats);
+                       planes, plane_stride, parts, min_strips, coop_tail, xscale, feats, feat_hw);
 }
 
 void azk_permute_k(hipStream_t s, const float *in, float *out, long long rows, int C, int to_bin_major)
@@ -1110,13 +1116,14 @@ size_t azk_tail_weight_rows(int n7) { return (size_t)TAIL_WAVES * tail_kq(n7) + 
 
 void azk_tail(hipStream_t s, const float *part7, int S7, const float *b7, int n7, const float *WtT, const float *bt,
               const double *ubox, const int *Uptr, int capU, int im_h, int im_w, double eps, float *zoom_u,
-              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u)
+              float *score_u, float *delta_u, double *pred_u, unsigned char *keep_u, double min_side, unsigned *key_u,
+              const int *row_hw)
 {
     int grid = (capU + TAIL_ROWS - 1) / TAIL_ROWS;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(k_tail_fused, dim3(grid), dim3(TAIL_WAVES * 64), azk_tail_lds_bytes(n7), s, part7, S7,
                        (size_t)capU * n7, b7, n7, tail_kq(n7), WtT, bt, ubox, Uptr, im_h, im_w, eps, zoom_u, score_u,
-                       delta_u, pred_u, keep_u, min_side, key_u);
+                       delta_u, pred_u, keep_u, min_side, key_u, row_hw);
 }
 
 void azk_det_epilogue(hipStream_t s, const float *part, int S, int ncls, const float *bt, const double *ubox,

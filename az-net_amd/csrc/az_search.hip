@@ -1314,7 +1314,7 @@ void head_pass_batch(az_ctx *L, az_ctx::Batch &B, const AzHeadDims &d, const int
     // (gemm mode 3 -- int6 on the 16-bit matrix cores, every fp32 operand as three bf16 terms: the planes carry no per-map
     //  scale, so the images of a batch share a pass there as well; mode 2's fp16 terms are scaled per map: not taken)
     azk_roi_pool(s, nullptr, d, L->spatial_scale, B.rois_cat, Mptr, L->maxR, L->pool5, L->pool5p,
-                 azk_act_plane_elems(L->maxR, d.K6), L->gemm_parts, 0, 0, nullptr, B.feats);
+                 azk_act_plane_elems(L->maxR, d.K6), L->gemm_parts, 0, 0, nullptr, B.feats, B.feat_hw);
     const bool can12 = (d.n6 / 128) * L->S6 >= 256 && d.n6 % 128 == 0 && d.K6 % 32 == 0 &&
                        azk_fc_chunk(d.K6, L->S6) * L->S6 == d.K6 && azk_fc_chunk(d.K6, L->S6) >= 64 &&
                        L->gemm12_min_rows < 0x7fffffff;
@@ -1330,20 +1330,28 @@ void head_pass_batch(az_ctx *L, az_ctx::Batch &B, const AzHeadDims &d, const int
     float *p7 = L->part7 ? L->part7 : L->part;
     azk_fc_gemm(s, L->h6, d.n6, L->W7, d.n6, Mptr, L->maxR, d.n7, d.n6, L->S7, p7, 1 << 30, nullptr);
     azk_tail(s, p7, L->S7, L->b7, d.n7, L->Wt, L->bt, B.ubox_cat, Mptr, L->maxR, im_h, im_w, eps, zoom, score, delta,
-             L->pred_u, keep_flags ? L->keep_u : nullptr, min_side, (keep_flags && keys) ? L->key_u : nullptr);
+             L->pred_u, keep_flags ? L->keep_u : nullptr, min_side, (keep_flags && keys) ? L->key_u : nullptr, B.row_hw);
 }
 
 }  // namespace
 
-int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all, const az_params *p, const float *const *maps_all, int H, int W, int *not_taken)
+int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all, const az_params *pa_all, const float *const *maps_all,
+                      const int *Hs_all, const int *Ws_all, int *not_taken)
 {
     *not_taken = 0;
     int rc = check_ready(L, false, true);          // (join: the passes work in the lane's per-search head buffers)
     if (rc) return rc;
-    if (!p || n_all < 1 || n_all > AZ_BATCH_MAX || !slots_all || !maps_all || H <= 0 || W <= 0 || p->im_h <= 0 || p->im_w <= 0 || !(p->scale > 0) ||
-        p->batch_size <= 0 || !(p->min_side > 0))
+    if (!pa_all || n_all < 1 || n_all > AZ_BATCH_MAX || !slots_all || !maps_all || !Hs_all || !Ws_all)
         return fail(L, AZ_ERR_INVALID, "az_batch_launch: bad arguments");
-    if (!p->fixed_num || (p->reserved & 4)) return fail(L, AZ_ERR_INVALID, "az_batch_launch: fixed proposal count, not the tuner's variant");
+    const az_params *p = &pa_all[0];                // (what the images of a batch must share is checked against the first)
+    for (int b = 0; b < n_all; ++b) {
+        const az_params &q = pa_all[b];
+        if (Hs_all[b] <= 0 || Ws_all[b] <= 0 || q.im_h <= 0 || q.im_w <= 0 || !(q.scale > 0) || q.batch_size <= 0 || !(q.min_side > 0))
+            return fail(L, AZ_ERR_INVALID, "az_batch_launch: bad arguments");
+        if (!q.fixed_num || (q.reserved & 4)) return fail(L, AZ_ERR_INVALID, "az_batch_launch: fixed proposal count, not the tuner's variant");
+        if (q.num_proposals != p->num_proposals || q.reserved != p->reserved || q.eps != p->eps || q.min_side != p->min_side)
+            return fail(L, AZ_ERR_INVALID, "az_batch_launch: the images of a batch share num_proposals, eps, min_side and the flags");
+    }
     const int k = p->num_proposals;
     if (k <= 0) return fail(L, AZ_ERR_INVALID, "az_batch_launch: num_proposals must be positive");
     if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
@@ -1372,29 +1380,36 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
     auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
     if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
     if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
-    if (!L->level_fused_env || (p->im_h == L->nofuse_h && p->im_w == L->nofuse_w) || (p->im_h == L->nofuse_lv_h && p->im_w == L->nofuse_lv_w))
-        return skip();
-    for (const auto &e : L->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+    if (!L->level_fused_env) return skip();
+    // the images may differ in shape (each has its own pre-pass, its own map size, its own clipping box) but walk the same
+    // number of levels; a shape one of the contexts has learnt not to take on the fused kernels keeps the batch off them
+    struct Pre { const float *urois; const double *B1; const int *choff, *Udev; int P1, CH; };
+    std::vector<Pre> pre_all(n_all);
+    long rows0_all = 0;
     for (int b = 0; b < n_all; ++b) {
+        const az_params &q = pa_all[b];
         az_ctx *t = slots_all[b];
-        // (what an image's own reruns have taught its slot about the shape holds for the batch as well)
-        if ((p->im_h == t->nofuse_h && p->im_w == t->nofuse_w) || (p->im_h == t->nofuse_lv_h && p->im_w == t->nofuse_lv_w)) return skip();
-        for (const auto &e : t->lv_limits) if (e.h == p->im_h && e.w == p->im_w) return skip();
+        if (num_levels(q.im_h, q.im_w, q.min_side) - 1 != nlev) return skip();
+        for (const az_ctx *x : {(const az_ctx *)L, (const az_ctx *)t}) {
+            if ((q.im_h == x->nofuse_h && q.im_w == x->nofuse_w) || (q.im_h == x->nofuse_lv_h && q.im_w == x->nofuse_lv_w)) return skip();
+            for (const auto &e : x->lv_limits) if (e.h == q.im_h && e.w == q.im_w) return skip();
+        }
+        // the shape's pre-pass (B1, the rois of root + B1, counters): cached per shape on the lane
+        SearchPlan sp{};
+        sp.fused = true; sp.defer_root = false;
+        if ((rc = ensure_spec_cache(L, &q, sp)) != AZ_OK) return rc;
+        if (L->spc[0].h != q.im_h || L->spc[0].w != q.im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
+        pre_all[b] = {L->spec_urois[0], L->specB1[0], L->spec_choff[0], L->spec_U[0], L->spc[0].P1, L->spc[0].CH};
+        rows0_all += 1 + L->spc[0].P1;
     }
-    // the shape's pre-pass (B1, the rois of root + B1, counters): cached per shape on the lane
-    {
-        SearchPlan q{};
-        q.fused = true; q.defer_root = false;
-        if ((rc = ensure_spec_cache(L, p, q)) != AZ_OK) return rc;
-        if (L->spc[0].h != p->im_h || L->spc[0].w != p->im_w) return skip();     // (the pre-pass outgrew the context: nofuse_*)
-    }
-    const int P1 = L->spc[0].P1, rows0 = 1 + P1;
-    if ((size_t)rows0 * n_all > (size_t)L->maxR) return skip();
+    if ((size_t)rows0_all > (size_t)L->maxR) return skip();
     if (!B.off) {
         HIPCHK(L, hipMalloc((void **)&B.off, (AZ_BATCH_MAX + 2) * sizeof(int)));
         HIPCHK(L, hipMalloc((void **)&B.rois_cat, (size_t)L->maxR * 5 * sizeof(float)));
         HIPCHK(L, hipMalloc((void **)&B.ubox_cat, (size_t)L->maxR * 4 * sizeof(double)));
         HIPCHK(L, hipMalloc((void **)&B.feats, AZ_BATCH_MAX * sizeof(float *)));
+        HIPCHK(L, hipMalloc((void **)&B.feat_hw, AZ_BATCH_MAX * 2 * sizeof(int)));
+        HIPCHK(L, hipMalloc((void **)&B.row_hw, (size_t)L->maxR * 2 * sizeof(int)));
         HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
     }
     if (B.gemm12_rows < 0) { const char *e = getenv("AZ_BATCH_GEMM12_ROWS"); B.gemm12_rows = e ? atoi(e) : L->gemm12_dual_rows; }
@@ -1421,8 +1436,14 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         const int n = n_all - i0 < per ? n_all - i0 : per;
         az_ctx **slots = slots_all + i0;
         const float *const *maps = maps_all + i0;
+        const az_params *pa = pa_all + i0;
+        const int *Hs = Hs_all + i0, *Ws = Ws_all + i0;
+        const Pre *pre = pre_all.data() + i0;
+        int off0[AZ_BATCH_MAX + 1];                   // first row of every image in pass 0 (root + its children: host-known)
+        off0[0] = 0;
+        for (int b = 0; b < n; ++b) off0[b + 1] = off0[b] + 1 + pre[b].P1;
         AzHeadDims d = L->d;
-        d.H = H; d.W = W;
+        d.H = Hs[0]; d.W = Ws[0];                     // (RoIPool takes every image's own size from the batch's table)
         // ---- the geometry kernels' arguments, all levels, all images of the part: one block, one copy
         const size_t off_begin = off;
         AzFusedArgs *fa = args_at<AzFusedArgs>(B.args_host, off, n);
@@ -1434,6 +1455,8 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         const size_t off_fin = (size_t)((unsigned char *)fin - B.args_host);
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
+            const az_params *p = &pa[b];
+            const int P1 = pre[b].P1, rows0 = 1 + P1;
             auto INV = [&](int l) { return (l & 1) ? t->inv_odd : t->inv; };
             {
                 AzFusedArgs a;
@@ -1441,12 +1464,12 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
                 a.cnt = t->cnt;
                 a.B[0] = t->B[0]; a.B[1] = t->B[1]; a.srcB[0] = t->srcB[0]; a.srcB[1] = t->srcB[1];
                 a.index = t->index; a.inv = INV(2); a.zr = t->zr; a.choff = t->choff; a.csrc = t->csrc;
-                a.choff_all = L->spec_choff[0]; a.specB1 = L->specB1[0];
-                a.reset = 1; a.specP1 = P1; a.specCH = L->spc[0].CH; a.specU = rows0;
+                a.choff_all = pre[b].choff; a.specB1 = pre[b].B1;
+                a.reset = 1; a.specP1 = P1; a.specCH = pre[b].CH; a.specU = rows0;
                 a.ubox = t->ubox; a.pred_u = t->pred_u; a.Yall = t->Yall; a.Z = t->Z; a.child = t->child;
                 a.zoom_u = t->zoom_u; a.score_u = t->score_u; a.delta_u = t->delta_u; a.Sall = t->Sall;
-                a.zoom_s = L->zoom_s + (size_t)b * rows0; a.score_s = L->score_s + (size_t)b * rows0 * AZ_NSUB;
-                a.delta_s = L->delta_s + (size_t)b * rows0 * 4 * AZ_NSUB;
+                a.zoom_s = L->zoom_s + (size_t)off0[b]; a.score_s = L->score_s + (size_t)off0[b] * AZ_NSUB;
+                a.delta_s = L->delta_s + (size_t)off0[b] * 4 * AZ_NSUB;
                 a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
                 a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = 2;
                 a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
@@ -1492,15 +1515,17 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         AzGatherArgs g;
         std::memset(&g, 0, sizeof(g));
         g.n = n; g.capR = L->maxR; g.off_out = B.off; g.rois_cat = B.rois_cat; g.ubox_cat = B.ubox_cat; g.feats_out = B.feats;
+        g.feat_hw_out = B.feat_hw; g.row_hw_out = B.row_hw;
         for (int b = 0; b < n; ++b) {
-            g.rows[b] = L->spec_U[0] + 1;                 // (ensure_spec_cache: the pass without the third level's rows)
+            g.rows[b] = pre[b].Udev + 1;                  // (ensure_spec_cache: the pass without the third level's rows)
             g.err[b] = nullptr;                           // (the image's counters are cleared by k_spec_levels, behind this pass)
-            g.rois[b] = L->spec_urois[0]; g.ubox[b] = nullptr; g.feat[b] = maps[b];
+            g.rois[b] = pre[b].urois; g.ubox[b] = nullptr; g.feat[b] = maps[b];
+            g.fh[b] = Hs[b]; g.fw[b] = Ws[b]; g.im_h[b] = pa[b].im_h; g.im_w[b] = pa[b].im_w;
         }
         azk_batch_gather(s, g);
         const int *Mptr = B.off + AZ_BATCH_MAX + 1;
         head_pass_batch(L, B, d, Mptr, p->im_h, p->im_w, p->eps, L->zoom_s, L->score_s, L->delta_s, 0.0, false, false,
-                        rows0 * n >= B.gemm12_rows);
+                        off0[n] >= B.gemm12_rows);
         azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
         // ---- the levels
         for (int l = 2; l < nlev; ++l) {
@@ -1529,15 +1554,15 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
             az_ctx::PendingSearch q;
-            q.p = *p; q.nlev = nlev; q.batch = 1;
+            q.p = pa[b]; q.nlev = nlev; q.batch = 1;
             q.npass = 0;
-            q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -rows0 - 1;
+            q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -(1 + pre[b].P1) - 1;
             for (int l = 2; l < nlev; ++l) {
                 q.pass_lv[q.npass] = l;
                 q.pass_src[q.npass++] = (int)(&t->cnt->PR[l] - reinterpret_cast<int *>(t->cnt));
             }
-            t->feat = maps[b]; t->d.H = H; t->d.W = W;
-            q.feat = maps[b]; q.fH = H; q.fW = W; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
+            t->feat = maps[b]; t->d.H = Hs[b]; t->d.W = Ws[b];
+            q.feat = maps[b]; q.fH = Hs[b]; q.fW = Ws[b]; q.feat_gen = t->feat_gen; q.feat_is_copy = false;
             q.slot = 0;                                   // (the slot's queue is empty: its first result slot, a slice of the arena)
             if (b == 0) HIPCHK(L, hipMemcpyAsync(B.res_host + (size_t)i0 * res_stride, B.res_dev + (size_t)i0 * res_stride, res_stride * n, hipMemcpyDeviceToHost, s));
             HIPCHK(L, hipEventRecord(t->ev_res[q.slot], s));

@@ -37,7 +37,7 @@ SYMBOLS = [
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
     "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
     "az_bias_relu", "az_bias_relu_pool", "az_batch_launch", "az_batch_fetch", "az_batch_next_stream",
-    "az_batch_stage_results_dev", "az_batch_fetch_all",
+    "az_batch_stage_results_dev", "az_batch_fetch_all", "az_batch_launch_shapes",
 ]
 
 
@@ -156,6 +156,7 @@ def load_library(path=None):
     L.az_batch_next_stream.argtypes = [vp]
     L.az_batch_launch.argtypes = [vp, ci, ctypes.POINTER(AzParams), ctypes.POINTER(vp), ci, ci, ci]
     L.az_batch_fetch.argtypes = [vp, ci, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
+    L.az_batch_launch_shapes.argtypes = [vp, ci, ctypes.POINTER(AzParams), ctypes.POINTER(vp), ci, cip, cip]
     L.az_batch_stage_results_dev.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_size_t]
     L.az_batch_fetch_all.argtypes = [vp, dp, fp, ci, cip, ctypes.POINTER(AzStats)]
     ll, llp = ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)
@@ -428,9 +429,11 @@ class AzContext(object):
         together: every level's rois of all of them in one head pass (az_batch_launch).  fmaps: CUDA tensors [1,C,H,W] /
         [C,H,W] on this GPU, one per image (torch.channels_last ones are read where they lie, others are converted by torch);
         they must stay untouched until the batch's last batch_fetch.  producer_done / producer_event as propose_launch.
-        Results: batch_fetch(i), i = 0 .. len(fmaps)-1 in order; each is what propose gives for that image alone."""
+        Results: batch_fetch(i), i = 0 .. len(fmaps)-1 in order; each is what propose gives for that image alone.
+        params may also be a LIST of AzParams, one per image: the images of the batch then have shapes of their own
+        (az_batch_launch_shapes; they must walk the same number of levels and share num_proposals, eps, min_side, flags)."""
         import torch
-        maps, ptrs, shape = [], [], None
+        maps, ptrs, shape, hw = [], [], None, []
         converted = False
         # (the layout checks of a tensor are remembered per tensor object, as propose_launch does: a batch of 32 maps is
         #  otherwise ~0.3 ms of Python)
@@ -453,10 +456,13 @@ class AzContext(object):
                 chw = tuple(int(x) for x in t.shape[1:])
             else:
                 t, chw = ent[3], ent[1]
-            assert shape in (None, chw), "the maps of a batch have one shape"
+            per_image = isinstance(params, (list, tuple))
+            assert per_image or shape in (None, chw), "the maps of a batch have one shape (or pass one AzParams per image)"
+            assert shape is None or shape[0] == chw[0]
             shape = chw
             maps.append(t)
             ptrs.append(t.data_ptr())
+            hw.append(chw[1:])
         C, H, W = shape
         dev = maps[0].device
         if producer_event is not None and not converted:
@@ -465,7 +471,15 @@ class AzContext(object):
             torch.cuda.current_stream(dev).synchronize()
         arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
         self._batch_stream = self._ext(self.L.az_batch_next_stream(self.h))       # (the stream this batch runs on)
-        self._chk(self.L.az_batch_launch(self.h, len(ptrs), ctypes.byref(params), arr, C, H, W))
+        if isinstance(params, (list, tuple)):
+            assert len(params) == len(ptrs)
+            pa = (AzParams * len(ptrs))(*params)
+            Hs = (ctypes.c_int * len(ptrs))(*[h for h, _ in hw])
+            Ws = (ctypes.c_int * len(ptrs))(*[w for _, w in hw])
+            self._chk(self.L.az_batch_launch_shapes(self.h, len(ptrs), pa, arr, C, Hs, Ws))
+            params = params[0]
+        else:
+            self._chk(self.L.az_batch_launch(self.h, len(ptrs), ctypes.byref(params), arr, C, H, W))
         import collections
         q = self.__dict__.setdefault("_batches", collections.deque())
         q.append((params, maps))

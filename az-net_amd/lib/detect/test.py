@@ -184,11 +184,11 @@ def _batch_backbones(net, ims, after=None):
     dev = hnet.backbone.device
     if after is not None:
         torch.cuda.current_stream(dev).wait_event(after)
-    scale = _im_scale(ims[0].shape)
-    if len(scale) != 1:
-        raise NotImplementedError("one test scale (cfg.TEST.SCALES), as in every config of the reference")
     convs, blobs = [], []
     for im in ims:
+        scale = _im_scale(im.shape)
+        if len(scale) != 1:
+            raise NotImplementedError("one test scale (cfg.TEST.SCALES), as in every config of the reference")
         blob = hnet.image_blob_enqueue(_as_uint8(im), cfg.PIXEL_MEANS, scale[0])
         blobs.append(blob)
         conv = hnet.backbone(blob)
@@ -199,8 +199,10 @@ def _batch_backbones(net, ims, after=None):
         convs.append(conv)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return {"shape": ims[0].shape, "n": len(ims), "ims": ims, "convs": convs, "blobs": blobs, "maps_done": ev,
-            "params": _params(ims[0].shape, scale[0], None)}
+    # (one AzParams per image: the images of a batch may differ in shape)
+    params = [_params(im.shape, _im_scale(im.shape)[0], None) for im in ims]
+    return {"shapes": [im.shape for im in ims], "n": len(ims), "ims": ims, "convs": convs, "blobs": blobs, "maps_done": ev,
+            "params": params}
 
 
 def _batch_launch(net, h):
@@ -218,7 +220,7 @@ def _batch_finish(net, h, i, quiet=False):
     if "results" not in h:
         h["results"] = hnet.ctx.batch_fetch_all(want_stats=True)      # (the whole batch in one call)
     Y, st = h["results"][i]
-    shape = h["shape"]
+    shape = h["shapes"][i]
     if cfg.SEAR.APPEND_BOXES:
         Y = _append_boxes(Y)
         Y[:, 0::4] = np.maximum(Y[:, 0::4], 0)
@@ -232,12 +234,22 @@ def _batch_finish(net, h, i, quiet=False):
     return Y
 
 
+def _num_levels(im_shape):
+    """K of im_propose (lib/detect/test.py:365-368; Python-2 integer division when MIN_SIDE is integral): the images of a
+    lockstep batch must agree on it."""
+    side = min(im_shape[0], im_shape[1])
+    ms = cfg.SEAR.MIN_SIDE
+    q = side // int(ms) if float(ms) == int(ms) and ms >= 1 else side / float(ms)
+    return int(np.log2(q) + 1.0) if q >= 1 else 0
+
+
 def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
     """(image, proposals, conv maps) for every image of the stream `images`, IN ORDER, the proposals made in lockstep batches
-    of up to nb images of one shape.  A dataset mixes shapes (VOC: 500x375, 375x500, 500x333, ...): a batch is the next
-    unprocessed image plus the images of ITS shape among the following ones, within a window of four batches' worth that is
-    read ahead; results (and the per-image line im_propose prints) are handed out in dataset order whatever order the
-    batches ran in.  The next batch's front-ends, backbones and (launch_ahead: a context takes two batches per lane) search
+    of up to nb images.  A dataset mixes shapes (VOC: 500x375, 375x500, 500x333, ...): the images of a batch may differ in
+    shape (az_batch_launch_shapes) as long as their searches have the same number of levels (K of test.py:365-368) -- a
+    batch is the next unprocessed image plus the images with ITS level count among the following ones, within a window of
+    four batches' worth that is read ahead; results (and the per-image line im_propose prints) are handed out in dataset
+    order whatever order the batches ran in.  The next batch's front-ends, backbones and (launch_ahead: a context takes two batches per lane) search
     are enqueued before the current batch's images are handed out; launch_ahead=False: the next search only after the last
     image of the current batch has been taken (a caller that runs other kernels of its own on the context between two images
     -- the detection head -- would find them queued behind that search)."""
@@ -252,8 +264,8 @@ def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
         if not buf:
             return None
         i0 = min(buf)
-        shape = buf[i0].shape
-        idx = [i for i in sorted(buf) if buf[i].shape == shape][:nb]
+        key = _num_levels(buf[i0].shape)
+        idx = [i for i in sorted(buf) if _num_levels(buf[i].shape) == key][:nb]
         return idx, [buf.pop(i) for i in idx]
 
     pend = None

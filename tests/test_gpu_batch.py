@@ -318,3 +318,47 @@ def test_batch_entry_points_refuse_what_they_cannot_do(mods):
     ctx.batch_launch(prm, tm, producer_done=True)
     for i, (Y, S) in enumerate(ctx.batch_fetch_all(want_scores=True)):
         assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
+
+
+@pytest.mark.parametrize("tz", [0.0, 0.3, 0.5])
+def test_images_of_several_shapes_in_one_batch(mods, tz):
+    """az_batch_launch_shapes: 600x1000, 375x500 (scale 1.6), 500x375, 333x500 and 480x640 images -- five map sizes, five
+    pre-passes, five clipping boxes -- share their head passes; every image as its plain search alone gives it."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_head(seed=77, **synth.SMALL_DIMS)
+    shapes = [(600, 1000), (375, 500), (500, 375), (333, 500), (480, 640), (375, 500), (600, 1000), (500, 375), (375, 500)]
+    items = []
+    for j, (H, W) in enumerate(shapes):
+        sc = 600.0 / min(H, W)
+        if round(sc * max(H, W)) > 1000:
+            sc = 1000.0 / max(H, W)
+        fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+        items.append((H, W, sc, synth.make_scene_map(300 + j, synth.SMALL_DIMS["C"], fh, fw)))
+    ref = HipAZNet(head, name="shapes_ref")
+    want = []
+    for (H, W, sc, f) in items:
+        ref.set_conv(f)
+        want.append(ref.propose(_plain(ffi, H, W, sc, tz), want_scores=True, want_stats=True))
+    net = HipAZNet(head, name="shapes")
+    prm = [ffi.AzContext.make_params(H, W, sc, tz, static_tree=False) for (H, W, sc, _) in items]
+    tm = [_cl(torch, f) for (_, _, _, f) in items]
+    for rep in range(2):
+        order = list(range(len(items))) if rep == 0 else list(range(len(items)))[::-1]
+        net.ctx.batch_launch([prm[i] for i in order], [tm[i] for i in order], producer_done=True)
+        for i, (Y, S, st) in zip(order, net.ctx.batch_fetch_all(want_scores=True, want_stats=True)):
+            assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), (rep, i, shapes[i])
+            _same(st, want[i][2])
+            assert st.search_form == 5 and st.n_reruns == 0
+    # an image with another number of levels in the batch: searched one by one, same results
+    H, W, sc = 160, 240, 600.0 / 160
+    fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+    small = synth.make_scene_map(400, synth.SMALL_DIMS["C"], fh, fw)
+    ref.set_conv(small)
+    w_small = ref.propose(_plain(ffi, H, W, sc, tz), want_scores=True, want_stats=True)
+    assert w_small[2].n_levels != want[0][2].n_levels
+    net.ctx.batch_launch([prm[0], ffi.AzContext.make_params(H, W, sc, tz, static_tree=False), prm[1]],
+                         [tm[0], _cl(torch, small), tm[1]], producer_done=True)
+    got = net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
+    for (Y, S, st), w in zip(got, (want[0], w_small, want[1])):
+        assert np.array_equal(Y, w[0]) and np.array_equal(S, w[1])
+        assert st.search_form != 5

@@ -245,16 +245,17 @@ def test_test_net_shared_with_lockstep_proposals(rig, mods, nb):
 
 
 def test_lockstep_batches_over_a_dataset_of_mixed_shapes(mods):
-    """A dataset mixes image shapes: test_proposals with cfg.TEST.BATCH_IMAGES batches every image with the images of ITS shape
-    among the following ones (a read-ahead window) and still prints and stores everything in dataset order -- the lines and
-    boxes of the one-by-one loop.  A narrow VGG16 reads the blobs (every map is its own image's)."""
+    """A dataset mixes image shapes: test_proposals with cfg.TEST.BATCH_IMAGES puts images of DIFFERENT shapes into one lockstep
+    batch (az_batch_launch_shapes: every image its own pre-pass, map size and clipping box), regroups only where the number
+    of levels differs (the two small images), and still prints and stores everything in dataset order -- the lines and boxes
+    of the one-by-one loop.  A narrow VGG16 reads the blobs (every map is its own image's)."""
     torch, ffi, synth, HipAZNet, HipDetNet, orc = mods
     from aznet_hip.backbone import VGG16Conv5
     from datasets.imdb import imdb as imdb_base
     from detect import config as C
     from detect import test as T
-    shapes = [(375, 500), (600, 1000), (375, 500), (375, 500), (500, 375), (600, 1000), (375, 500), (333, 500), (500, 375),
-              (375, 500), (600, 1000), (375, 500), (375, 500), (500, 375)]
+    shapes = [(375, 500), (600, 1000), (375, 500), (160, 240), (500, 375), (600, 1000), (375, 500), (333, 500), (500, 375),
+              (375, 500), (150, 200), (375, 500), (375, 500), (500, 375)]
     ims = [synth.make_scene_image(700 + j, h, w) for j, (h, w) in enumerate(shapes)]
 
     class Mixed(imdb_base):

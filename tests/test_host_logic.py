@@ -199,18 +199,20 @@ def test_bench_self_launch_relays_rank_failures():
 
 def test_batched_proposals_groups_by_shape_and_keeps_dataset_order(monkeypatch, capsys):
     """detect.test._batched_proposals (cfg.TEST.BATCH_IMAGES): every image exactly once and in dataset order, a batch = images
-    of ONE shape (at most nb, taken from a read-ahead window), the per-image line printed in order -- with the GPU halves
-    replaced by recorders."""
+    whose searches have ONE number of levels (at most nb, taken from a read-ahead window; their shapes may differ), the
+    per-image line printed in order -- with the GPU halves replaced by recorders."""
     from detect import test as T
-    shapes = [(375, 500, 3), (600, 1000, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3), (600, 1000, 3), (375, 500, 3),
-              (333, 500, 3), (500, 375, 3), (375, 500, 3), (600, 1000, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3),
-              (375, 500, 3), (375, 500, 3), (375, 500, 3)]
+    shapes = [(375, 500, 3), (150, 200, 3), (375, 500, 3), (600, 1000, 3), (500, 375, 3), (150, 200, 3), (375, 500, 3),
+              (333, 500, 3), (90, 120, 3), (375, 500, 3), (160, 200, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3),
+              (375, 500, 3), (150, 220, 3), (375, 500, 3)]
+    levels = [T._num_levels(sh) for sh in shapes]
+    assert sorted(set(levels)) == [4, 5, 6] and T._num_levels((600, 1000, 3)) == 6 and T._num_levels((333, 500, 3)) == 6
     ims = [np.full(s, i, dtype=np.uint8) for i, s in enumerate(shapes)]
     batches, log = [], []
 
     def backbones(net, group, after=None):
-        assert len({im.shape for im in group}) == 1
-        h = {"shape": group[0].shape, "n": len(group), "ims": group, "convs": [("conv", int(im.flat[0])) for im in group],
+        assert len({T._num_levels(im.shape) for im in group}) == 1
+        h = {"shapes": [im.shape for im in group], "n": len(group), "ims": group, "convs": [("conv", int(im.flat[0])) for im in group],
              "after": after}
         log.append(("backbones", [int(im.flat[0]) for im in group]))
         return h
@@ -236,7 +238,9 @@ def test_batched_proposals_groups_by_shape_and_keeps_dataset_order(monkeypatch, 
         assert all(float(Y[0, 0]) == i for i, (_, Y, _) in enumerate(out))
         assert all(conv[T.cfg.SEAR.FRCNN_CONV[0]] == ("conv", i) for i, (_, _, conv) in enumerate(out))
         assert sorted(i for b in batches for i in b) == list(range(len(ims)))
-        assert all(1 <= len(b) <= nb and len({shapes[i] for i in b}) == 1 and b == sorted(b) for b in batches)
+        assert all(1 <= len(b) <= nb and len({levels[i] for i in b}) == 1 and b == sorted(b) for b in batches)
+        if nb >= 4:
+            assert any(len({shapes[i] for i in b}) > 1 for b in batches)                 # shapes mix inside a batch
         # a batch starts with the oldest unprocessed image and reaches at most a window of 4 nb images ahead
         seen = set()
         for b in batches:
