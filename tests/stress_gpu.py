@@ -127,14 +127,28 @@ def run_case(net, case):
         import torch
         nb = int(rng.randint(1, 6))
         C = (synth.FULL_DIMS if FULL else synth.SMALL_DIMS)["C"]
-        maps = [fmap] + [synth.make_feature_map(50000 + 7 * case + j, C, fh, fw) for j in range(nb - 1)]
+        # (half of the extra images have a shape of their own, a few pixels off, with the same number of levels:
+        #  az_batch_launch_shapes)
+        geo = [(H, W, scale, fh, fw)]
+        for j in range(nb - 1):
+            H2, W2 = H, W
+            if rng.rand() < 0.5:
+                H2 = max(40, H + int(rng.randint(-24, 25))); W2 = max(40, W + int(rng.randint(-24, 25)))
+            s2 = 600.0 / min(H2, W2)
+            if np.round(s2 * max(H2, W2)) > max_size:
+                s2 = float(max_size) / max(H2, W2)
+            if orc.num_levels(H2, W2) != orc.num_levels(H, W):
+                H2, W2, s2 = H, W, scale
+            geo.append((H2, W2, s2, synth.conv_out_size(int(round(H2 * s2))), synth.conv_out_size(int(round(W2 * s2)))))
+        maps = [fmap] + [synth.make_feature_map(50000 + 7 * case + j, C, geo[j + 1][3], geo[j + 1][4]) for j in range(nb - 1)]
         want = [b]
-        for m in maps[1:]:
+        for m, (H2, W2, s2, _, _) in zip(maps[1:], geo[1:]):
             net.set_conv(m)
-            want.append(net.propose(ffi.AzContext.make_params(H, W, scale, Tz, speculate=False, fused=False, radix_select=True, **kw),
+            want.append(net.propose(ffi.AzContext.make_params(H2, W2, s2, Tz, speculate=False, fused=False, radix_select=True, **kw),
                                     want_scores=True, want_stats=True))
         order = [int(x) for x in rng.permutation(nb)]
-        net.ctx.batch_launch(forms[0], [torch.from_numpy(maps[j]).cuda() for j in order])
+        net.ctx.batch_launch([ffi.AzContext.make_params(geo[j][0], geo[j][1], geo[j][2], Tz, **kw) for j in order],
+                             [torch.from_numpy(maps[j]).cuda() for j in order])
         for i, j in enumerate(order):
             g = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
             if not (np.array_equal(g[0], want[j][0]) and np.array_equal(g[1], want[j][1]) and g[2].num_eval == want[j][2].num_eval and
