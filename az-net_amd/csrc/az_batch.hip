@@ -5,12 +5,14 @@
 // test.py:373-391); its roi blob nevertheless carries Caffe's batch index in column 0 (test.py:93-97, always 0 there).
 // At a tuned threshold a level of one image is a few dozen rois -- far too few for a pass over the 411 MB of int6 weights
 // to be anything but a weight stream -- and what one image does at a level does not depend on any other image.  So B
-// images of one shape are searched together: every image keeps its own tree (an az_ctx of its own: regions, counters,
+// images (of one shape or of several, as long as their searches have the same number of levels) are searched together: every image keeps its own tree (an az_ctx of its own: regions, counters,
 // candidates, geometry kernels as workgroups (., b) of one launch, az_fused.hip / az_level.hip / az_static.hip), and per
 // level
 //   k_batch_gather    concatenates the images' unique rois -- column 0 = the image's index in the batch, which RoIPool
 //                     reads as Caffe's roi_batch_ind (az_head.hip) -- and their anchor boxes, and leaves the row offsets
-//                     and the pass's row count on the device (no host synchronisation anywhere);
+//                     and the pass's row count on the device (no host synchronisation anywhere); also every image's
+//                     map size (RoIPool clamps a window to ITS map) and every row's image size (the heads clip a decoded
+//                     box to ITS image): the images of a batch may differ in shape;
 //   the head          RoIPool, int6, slab sum, int7, heads: the unchanged kernels on the concatenated rows (a row's bits do
 //                     not depend on which rows share its launch: tests/test_gpu_parity.py);
 //   k_batch_scatter   hands every image its rows of the head's outputs, where its geometry kernel expects them.
@@ -95,6 +97,8 @@ __global__ void __launch_bounds__(256) k_batch_scatter(AzScatterArgs a)
         if (lane < 4 * AZ_NSUB) a.pred_d[b][i * 4 * AZ_NSUB + lane] = a.pred[(size_t)r * 4 * AZ_NSUB + lane];
     }
 }
+
+static_assert(sizeof(AzGatherArgs) <= 4000 && sizeof(AzScatterArgs) <= 4000, "kernel arguments are limited to 4 KB");
 
 }  // namespace
 
