@@ -1261,6 +1261,80 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
                 "levels_reached_histogram": {str(k): int(v) for k, v in
                                              zip(*np.unique([sum(1 for x in t if x > 0) for t in trees], return_counts=True))}}
 
+    def mixed_shapes_point(cnet, n):
+        shapes = [(375, 500), (500, 375), (333, 500), (375, 500), (500, 333), (375, 500), (500, 375), (600, 1000)]
+        items = []
+        for j in range(n):
+            h, w = shapes[j % len(shapes)]
+            sc = 600.0 / min(h, w)
+            if round(sc * max(h, w)) > 1000:
+                sc = 1000.0 / max(h, w)
+            fh, fw = synth.conv_out_size(int(round(h * sc))), synth.conv_out_size(int(round(w * sc)))
+            m = torch.from_numpy(synth.make_object_map(500 + j, 512, fh, fw)).to("cuda:%d" % device).contiguous(memory_format=torch.channels_last)
+            items.append((h, w, sc, m))
+        cnet.ctx.tune_begin(n * 2 * cnet.ctx.max_regions)
+        for (h, w, sc, m) in items:
+            cnet.set_conv(m)
+            cnet.propose(ffi.AzContext.make_params(h, w, sc, 0.0, num_proposals=NUM_PROPOSALS, tune=True))
+        tz = cnet.ctx.tune_kth_largest(n * 20)[0]
+        cnet.ctx.tune_end()
+        prm = [ffi.AzContext.make_params(h, w, sc, tz, num_proposals=NUM_PROPOSALS) for (h, w, sc, _) in items]
+        maps = [m for (_, _, _, m) in items]
+        order = list(range(n))
+
+        def one_by_one(stats=None):
+            launched = 0
+            for i in range(n):
+                while launched < min(n, i + depth):
+                    cnet.ctx.propose_launch(prm[launched], fmap=maps[launched], producer_done=True)
+                    launched += 1
+                Y, st = cnet.ctx.propose_fetch(want_stats=True)
+                if stats is not None:
+                    stats.append(st)
+        gc.collect()
+        gc.disable()
+        one_by_one()
+        one_by_one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_by_one()
+        torch.cuda.synchronize()
+        ms1 = (time.perf_counter() - t0) / (passes * n) * 1e3
+        lanes = int(getattr(cnet.ctx, "lanes", 1))
+        lock = {}
+        for bs in (8, 16):
+            groups = [order[i:i + bs] for i in range(0, n, bs)]
+
+            def run_batches(collect=None):
+                launched = 0
+                for gi in range(len(groups)):
+                    while launched < min(len(groups), gi + 2 * lanes):
+                        cnet.ctx.batch_launch([prm[j] for j in groups[launched]], [maps[j] for j in groups[launched]], producer_done=True)
+                        launched += 1
+                    rs = cnet.ctx.batch_fetch_all(want_stats=collect is not None)
+                    if collect is not None:
+                        collect.extend(r[1] for r in rs)
+            for _ in range(max(2, -(-4 * lanes // len(groups)) + 1)):
+                run_batches()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                run_batches()
+            torch.cuda.synchronize()
+            b_ms = (time.perf_counter() - t0) / (passes * n) * 1e3
+            sts = []
+            run_batches(sts)
+            lock[str(bs)] = {"ms_per_image": b_ms, "value": NUM_PROPOSALS * 1e3 / b_ms, "vs_one_image_at_a_time": ms1 / b_ms,
+                             "searches_run_twice": sum(int(st.n_reruns) for st in sts),
+                             "search_forms": sorted({ffi.SEARCH_FORMS.get(int(st.search_form), "?") for st in sts})}
+        gc.enable()
+        return {"set": "objects, images of %d shapes in dataset order (%s)" % (len(set(shapes)), ", ".join("%dx%d" % sh for sh in sorted(set(shapes)))),
+                "anchors_per_img": 20, "Tz": tz, "images": n, "one_image_at_a_time_ms": ms1, "value": NUM_PROPOSALS * 1e3 / ms1,
+                "unit": "proposals/s", "lockstep_batches": lock,
+                "note": "every batch holds images of several shapes (az_batch_launch_shapes: per-image map size, pre-pass, clipping "
+                        "box; shared head passes)"}
+
     # ---- objects: planted-object maps + a head whose zoom unit reads them ---------------------------------------------
     ohead = synth.make_object_head(seed=1234, **synth.FULL_DIMS)
     onet = HipAZNet(ohead, backbone=None, device=device, name="stream_objects", max_regions=4096)
@@ -1269,6 +1343,12 @@ def stream_tz(net, head, backbone, convs0, ffi, synth, HipAZNet, torch, get_imag
              for j in range(n_img)]
     tz_o = tune(onet, omaps, [20])
     res["points"].append(point("objects", onet, omaps, tz_o[0], 20))
+    # ---- the same head over images of SEVERAL shapes (what a dataset is: VOC's 500x375, 375x500, 500x333 ... at the reference's
+    #      scale rule), one image per search and in lockstep batches whose images differ in shape (az_batch_launch_shapes)
+    try:
+        res["mixed_shapes"] = mixed_shapes_point(onet, n_img)
+    except Exception as e:                                   # noqa: BLE001 -- an extra, never the bench line's failure
+        res["mixed_shapes"] = {"error": repr(e)}
     del onet, omaps, ohead
     # ---- untrained: scene images through `value`'s backbone and head --------------------------------------------------------
     smaps = []
