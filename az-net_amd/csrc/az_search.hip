@@ -1355,7 +1355,12 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
     const int k = p->num_proposals;
     if (k <= 0) return fail(L, AZ_ERR_INVALID, "az_batch_launch: num_proposals must be positive");
     if (k > AZ_TOPK_MAX) return fail(L, AZ_ERR_CAPACITY, "az_batch_launch: num_proposals > 4096");
-    const int nlev = num_levels(p->im_h, p->im_w, p->min_side) - 1;
+    int nlev = 0;                                   // the batch's deepest tree; image b walks nl_all[b] levels
+    int nl_all[AZ_BATCH_MAX];
+    for (int b = 0; b < n_all; ++b) {
+        nl_all[b] = num_levels(pa_all[b].im_h, pa_all[b].im_w, pa_all[b].min_side) - 1;
+        nlev = nl_all[b] > nlev ? nl_all[b] : nlev;
+    }
     for (int b = 0; b < n_all; ++b) {
         if (!slots_all[b] || !maps_all[b]) return fail(L, AZ_ERR_INVALID, "az_batch_launch: null slot / map");
         if (!slots_all[b]->pend.empty()) return fail(L, AZ_ERR_STATE, "az_batch_launch: an image slot still holds an unfetched search");
@@ -1377,19 +1382,26 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         t->cnt = reinterpret_cast<AzCounts *>(B.res_dev + (size_t)b * res_stride);
         t->h_res[0] = B.res_host + (size_t)b * res_stride;
     }
-    auto skip = [&]() { *not_taken = 1; return AZ_ERR_STATE; };
-    if (nlev < 3 || nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
+    auto skip_at = [&](int line) {
+        if (getenv("AZ_BATCH_DEBUG")) fprintf(stderr, "az: batch not taken in lockstep (az_search.hip:%d)\n", line);
+        *not_taken = 1;
+        return AZ_ERR_STATE;
+    };
+#define skip() skip_at(__LINE__)
+    if (nlev > AZ_MAX_LEVELS || (p->reserved & (1 | 2 | 8 | 16)) || L->gemm_parts == 2) return skip();
+    for (int b = 0; b < n_all; ++b) if (nl_all[b] < 3) return skip();        // (an image too small for two fused levels + one more)
     if (L->level_fused_env < 0) { const char *e = getenv("AZ_LEVEL_FUSED"); L->level_fused_env = (e && !atoi(e)) ? 0 : 1; }
     if (!L->level_fused_env) return skip();
-    // the images may differ in shape (each has its own pre-pass, its own map size, its own clipping box) but walk the same
-    // number of levels; a shape one of the contexts has learnt not to take on the fused kernels keeps the batch off them
+    // the images may differ in shape (each has its own pre-pass, its own map size, its own clipping box) and in the number of
+    // levels (an image's last level gets its final selection where the others get their mid-tree geometry kernel; it has no
+    // rows in the passes after that); a shape one of the contexts has learnt not to take on the fused kernels keeps the batch
+    // off them
     struct Pre { const float *urois; const double *B1; const int *choff, *Udev; int P1, CH; };
     std::vector<Pre> pre_all(n_all);
     long rows0_all = 0;
     for (int b = 0; b < n_all; ++b) {
         const az_params &q = pa_all[b];
         az_ctx *t = slots_all[b];
-        if (num_levels(q.im_h, q.im_w, q.min_side) - 1 != nlev) return skip();
         for (const az_ctx *x : {(const az_ctx *)L, (const az_ctx *)t}) {
             if ((q.im_h == x->nofuse_h && q.im_w == x->nofuse_w) || (q.im_h == x->nofuse_lv_h && q.im_w == x->nofuse_lv_w)) return skip();
             for (const auto &e : x->lv_limits) if (e.h == q.im_h && e.w == q.im_w) return skip();
@@ -1413,7 +1425,7 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         HIPCHK(L, hipMemsetAsync(B.ubox_cat, 0, (size_t)L->maxR * 4 * sizeof(double), s));
     }
     if (B.gemm12_rows < 0) { const char *e = getenv("AZ_BATCH_GEMM12_ROWS"); B.gemm12_rows = e ? atoi(e) : L->gemm12_dual_rows; }
-    const size_t need = 64 + ((sizeof(AzFusedArgs) + 16) + (sizeof(AzLevelArgs) + 16) * (size_t)nlev + (sizeof(AzFinalArgs) + 16)) * AZ_BATCH_MAX;
+    const size_t need = 64 + ((sizeof(AzFusedArgs) + 16) + (sizeof(AzLevelArgs) + sizeof(AzFinalArgs) + 32) * (size_t)nlev) * AZ_BATCH_MAX;
     if (B.args_cap < need) {
         if (B.args_dev) { HIPCHK(L, hipStreamSynchronize(s)); hipFree(B.args_dev); hipHostFree(B.args_host); B.args_dev = nullptr; B.args_host = nullptr; B.args_cap = 0; }
         HIPCHK(L, hipMalloc((void **)&B.args_dev, need));
@@ -1439,6 +1451,7 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         const az_params *pa = pa_all + i0;
         const int *Hs = Hs_all + i0, *Ws = Ws_all + i0;
         const Pre *pre = pre_all.data() + i0;
+        const int *nl = nl_all + i0;
         int off0[AZ_BATCH_MAX + 1];                   // first row of every image in pass 0 (root + its children: host-known)
         off0[0] = 0;
         for (int b = 0; b < n; ++b) off0[b + 1] = off0[b] + 1 + pre[b].P1;
@@ -1448,11 +1461,15 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         const size_t off_begin = off;
         AzFusedArgs *fa = args_at<AzFusedArgs>(B.args_host, off, n);
         const size_t off_fa = (size_t)((unsigned char *)fa - B.args_host);
-        std::vector<size_t> off_lv(nlev, 0);
+        // (per level: the images that go on -- k_level_geom -- and the images whose last level it is -- k_final_select)
+        std::vector<size_t> off_lv(nlev, 0), off_fin(nlev, 0);
         std::vector<AzLevelArgs *> la(nlev, nullptr);
-        for (int l = 2; l + 1 < nlev; ++l) { la[l] = args_at<AzLevelArgs>(B.args_host, off, n); off_lv[l] = (size_t)((unsigned char *)la[l] - B.args_host); }
-        AzFinalArgs *fin = args_at<AzFinalArgs>(B.args_host, off, n);
-        const size_t off_fin = (size_t)((unsigned char *)fin - B.args_host);
+        std::vector<AzFinalArgs *> fin(nlev, nullptr);
+        std::vector<int> n_mid(nlev, 0), n_fin(nlev, 0);
+        for (int l = 2; l < nlev; ++l) {
+            la[l] = args_at<AzLevelArgs>(B.args_host, off, n); off_lv[l] = (size_t)((unsigned char *)la[l] - B.args_host);
+            fin[l] = args_at<AzFinalArgs>(B.args_host, off, n); off_fin[l] = (size_t)((unsigned char *)fin[l] - B.args_host);
+        }
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
             const az_params *p = &pa[b];
@@ -1471,7 +1488,7 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
                 a.zoom_s = L->zoom_s + (size_t)off0[b]; a.score_s = L->score_s + (size_t)off0[b] * AZ_NSUB;
                 a.delta_s = L->delta_s + (size_t)off0[b] * 4 * AZ_NSUB;
                 a.scale = p->scale; a.Tz = p->Tz; a.min_side = p->min_side; a.eps = p->eps; a.dedup = (float)p->dedup;
-                a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nlev; a.n_fused = 2;
+                a.batch = p->batch_size; a.im_h = p->im_h; a.im_w = p->im_w; a.nlev = nl[b]; a.n_fused = 2;
                 a.capR = t->maxR; a.capCh = t->maxCh; a.capCand = t->maxCand;
                 a.rois = t->rois; a.urois = t->urois; a.next_dedup = 1; a.defer_root = 0; a.cut_next = 0; a.cut_short = 0;
                 a.spec_next = 0; a.choff_next = t->choff_pair; a.crow = t->crow; a.spatial_scale = L->spatial_scale;
@@ -1479,11 +1496,11 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
                 a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
                 fa[b] = a;
             }
-            for (int l = 2; l + 1 < nlev; ++l) {
+            for (int l = 2; l + 1 < nl[b]; ++l) {
                 AzLevelArgs a;
                 std::memset(&a, 0, sizeof(a));
                 const int cur = l & 1;
-                a.cnt = t->cnt; a.level = l; a.nlev = nlev; a.cut_next = 0;
+                a.cnt = t->cnt; a.level = l; a.nlev = nl[b]; a.cut_next = 0;
                 a.B = t->B[cur]; a.Bnext = t->B[cur ^ 1];
                 a.pred_u = t->pred_u; a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.keep_u = t->keep_u; a.Uptr = &t->cnt->U[l];
                 a.urois = t->urois; a.index = t->index; a.inv = INV(l); a.inv_next = INV(l + 1); a.ubox = t->ubox;
@@ -1495,18 +1512,18 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
                 a.stab = nullptr; a.stabT = 0; a.root_row_full = 0; a.score_all = t->score_s; a.zoom_all = t->zoom_s;
                 a.pred_v = t->pred_v; a.score_v = t->score_v; a.zoom_v = t->zoom_v; a.keep_v = t->keep_v; a.key_v = t->key_v;
                 a.im_h = p->im_h; a.im_w = p->im_w; a.eps = p->eps; a.spatial_scale = L->spatial_scale;
-                la[l][b] = a;
+                la[l][n_mid[l]++] = a;
             }
             {
                 AzFinalArgs a;
                 std::memset(&a, 0, sizeof(a));
-                const int l = nlev - 1;
+                const int l = nl[b] - 1;
                 a.cnt = t->cnt; a.level = l; a.inv = INV(l); a.key_u = t->key_u; a.pred_u = t->pred_u;
                 a.score_u = t->score_u; a.zoom_u = t->zoom_u; a.Yall = t->Yall; a.Sall = t->Sall; a.Tz = p->Tz;
                 a.force_root = 0; a.capCand = t->maxCand; a.k = k;
                 a.Yout = (double *)((unsigned char *)t->cnt + RES_HDR);
                 a.Sout = (float *)((unsigned char *)t->cnt + RES_HDR + (size_t)k * 32);
-                fin[b] = a;
+                fin[l][n_fin[l]++] = a;
             }
         }
         HIPCHK(L, hipMemcpyAsync(B.args_dev + off_begin, B.args_host + off_begin, off - off_begin, hipMemcpyHostToDevice, s));
@@ -1529,7 +1546,7 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
         azk_spec_levels_batch(s, reinterpret_cast<const AzFusedArgs *>(B.args_dev + off_fa), n);
         // ---- the levels
         for (int l = 2; l < nlev; ++l) {
-            const bool last = l + 1 == nlev;
+            const bool last = n_fin[l] > 0;               // (some image's last level: the heads also emit the selection keys)
             for (int b = 0; b < n; ++b) {
                 az_ctx *t = slots[b];
                 g.rows[b] = &t->cnt->PR[l]; g.err[b] = &t->cnt->err; g.rois[b] = t->urois; g.ubox[b] = t->ubox; g.feat[b] = maps[b];
@@ -1546,18 +1563,18 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
                 sc.zoom_d[b] = t->zoom_u; sc.score_d[b] = t->score_u; sc.pred_d[b] = t->pred_u; sc.keep_d[b] = t->keep_u; sc.key_d[b] = t->key_u;
             }
             azk_batch_scatter(s, sc);
-            if (!last) azk_level_geom_batch(s, reinterpret_cast<const AzLevelArgs *>(B.args_dev + off_lv[l]), n);
-            else azk_final_select_batch(s, reinterpret_cast<const AzFinalArgs *>(B.args_dev + off_fin), n);
+            if (n_mid[l]) azk_level_geom_batch(s, reinterpret_cast<const AzLevelArgs *>(B.args_dev + off_lv[l]), n_mid[l]);
+            if (n_fin[l]) azk_final_select_batch(s, reinterpret_cast<const AzFinalArgs *>(B.args_dev + off_fin[l]), n_fin[l]);
         }
         HIPCHK(L, hipGetLastError());
         // ---- every image's record on its way to the host; the searches enter the slots' queues
         for (int b = 0; b < n; ++b) {
             az_ctx *t = slots[b];
             az_ctx::PendingSearch q;
-            q.p = pa[b]; q.nlev = nlev; q.batch = 1;
+            q.p = pa[b]; q.nlev = nl[b]; q.batch = 1;
             q.npass = 0;
             q.pass_lv[q.npass] = -1; q.pass_src[q.npass++] = -(1 + pre[b].P1) - 1;
-            for (int l = 2; l < nlev; ++l) {
+            for (int l = 2; l < nl[b]; ++l) {
                 q.pass_lv[q.npass] = l;
                 q.pass_src[q.npass++] = (int)(&t->cnt->PR[l] - reinterpret_cast<int *>(t->cnt));
             }
@@ -1577,4 +1594,5 @@ int batch_launch_impl(az_ctx *L, az_ctx::Batch &B, int n_all, az_ctx **slots_all
     }
     L->last_s = s;
     return AZ_OK;
+#undef skip
 }

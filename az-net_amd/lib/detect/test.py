@@ -243,13 +243,19 @@ def _num_levels(im_shape):
     return int(np.log2(q) + 1.0) if q >= 1 else 0
 
 
+def _lockstep_ok(im_shape):
+    """Whether an image's search can share the head passes of a lockstep batch: at least three levels (K - 1 >= 3: an image of
+    >= 80 px on its short side at MIN_SIDE 10); smaller ones are batched among themselves and searched one by one."""
+    return _num_levels(im_shape) - 1 >= 3
+
+
 def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
     """(image, proposals, conv maps) for every image of the stream `images`, IN ORDER, the proposals made in lockstep batches
     of up to nb images.  A dataset mixes shapes (VOC: 500x375, 375x500, 500x333, ...): the images of a batch may differ in
-    shape (az_batch_launch_shapes) as long as their searches have the same number of levels (K of test.py:365-368) -- a
-    batch is the next unprocessed image plus the images with ITS level count among the following ones, within a window of
-    four batches' worth that is read ahead; results (and the per-image line im_propose prints) are handed out in dataset
-    order whatever order the batches ran in.  The next batch's front-ends, backbones and (launch_ahead: a context takes two batches per lane) search
+    shape and in the number of levels of their trees (az_batch_launch_shapes); only images too small for the lockstep form
+    (fewer than three levels) are kept apart -- a batch is the next unprocessed image plus the following images of ITS kind,
+    within a window of four batches' worth that is read ahead; results (and the per-image line im_propose prints) are handed
+    out in dataset order whatever order the batches ran in.  The next batch's front-ends, backbones and (launch_ahead: a context takes two batches per lane) search
     are enqueued before the current batch's images are handed out; launch_ahead=False: the next search only after the last
     image of the current batch has been taken (a caller that runs other kernels of its own on the context between two images
     -- the detection head -- would find them queued behind that search)."""
@@ -264,8 +270,8 @@ def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
         if not buf:
             return None
         i0 = min(buf)
-        key = _num_levels(buf[i0].shape)
-        idx = [i for i in sorted(buf) if _num_levels(buf[i].shape) == key][:nb]
+        key = _lockstep_ok(buf[i0].shape)
+        idx = [i for i in sorted(buf) if _lockstep_ok(buf[i].shape) == key][:nb]
         return idx, [buf.pop(i) for i in idx]
 
     pend = None

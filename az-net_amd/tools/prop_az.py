@@ -141,13 +141,13 @@ def main():
         # --batch-images: the rank's consecutive images of one shape in lockstep batches (detect.test.test_proposals does the
         # same in a one-process run); a batch's records go to the send buffer in one strided device-to-device copy
         import itertools
-        from detect.test import _batch_backbones, _batch_launch, _batch_finish, _num_levels
+        from detect.test import _batch_backbones, _batch_launch, _batch_finish, _lockstep_ok
 
         def groups():
             cur = []
             for _ in range(len(mine)):
                 im = next(images)
-                if cur and (_num_levels(im.shape) != _num_levels(cur[0].shape) or len(cur) == nb):
+                if cur and (_lockstep_ok(im.shape) != _lockstep_ok(cur[0].shape) or len(cur) == nb):
                     yield cur
                     cur = []
                 cur.append(im)

@@ -127,17 +127,22 @@ def run_case(net, case):
         import torch
         nb = int(rng.randint(1, 6))
         C = (synth.FULL_DIMS if FULL else synth.SMALL_DIMS)["C"]
-        # (half of the extra images have a shape of their own, a few pixels off, with the same number of levels:
-        #  az_batch_launch_shapes)
+        # (most of the extra images have a shape of their own -- a few pixels off, or half / double the size, so that the
+        #  numbers of levels differ as well: az_batch_launch_shapes)
         geo = [(H, W, scale, fh, fw)]
         for j in range(nb - 1):
             H2, W2 = H, W
-            if rng.rand() < 0.5:
+            u = rng.rand()
+            if u < 0.45:
                 H2 = max(40, H + int(rng.randint(-24, 25))); W2 = max(40, W + int(rng.randint(-24, 25)))
+            elif u < 0.6:
+                H2 = max(40, H // 2); W2 = max(40, W // 2)
+            elif u < 0.7:
+                H2 = min(900, H * 2); W2 = min(1300, W * 2)
             s2 = 600.0 / min(H2, W2)
             if np.round(s2 * max(H2, W2)) > max_size:
                 s2 = float(max_size) / max(H2, W2)
-            if orc.num_levels(H2, W2) != orc.num_levels(H, W):
+            if orc.num_levels(H2, W2) - 1 < 1:
                 H2, W2, s2 = H, W, scale
             geo.append((H2, W2, s2, synth.conv_out_size(int(round(H2 * s2))), synth.conv_out_size(int(round(W2 * s2)))))
         maps = [fmap] + [synth.make_feature_map(50000 + 7 * case + j, C, geo[j + 1][3], geo[j + 1][4]) for j in range(nb - 1)]

@@ -349,16 +349,40 @@ def test_images_of_several_shapes_in_one_batch(mods, tz):
             assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), (rep, i, shapes[i])
             _same(st, want[i][2])
             assert st.search_form == 5 and st.n_reruns == 0
-    # an image with another number of levels in the batch: searched one by one, same results
-    H, W, sc = 160, 240, 600.0 / 160
+    # images with other numbers of levels in the batch (160x240: four, 90x130: three, against five): an image's last level
+    # gets its final selection while the others go on
+    extra = []
+    for j, (H, W) in enumerate(((160, 240), (90, 130), (1000, 700))):
+        sc = 600.0 / min(H, W)
+        if round(sc * max(H, W)) > 1000:
+            sc = 1000.0 / max(H, W)
+        fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+        m = synth.make_scene_map(400 + j, synth.SMALL_DIMS["C"], fh, fw)
+        ref.set_conv(m)
+        extra.append((ffi.AzContext.make_params(H, W, sc, tz, static_tree=False), _cl(torch, m),
+                      ref.propose(_plain(ffi, H, W, sc, tz), want_scores=True, want_stats=True)))
+    assert sorted({e[2][2].n_levels for e in extra} | {want[0][2].n_levels}) == [3, 4, 5, 6]
+    net.ctx.batch_launch([prm[0], extra[0][0], prm[1], extra[1][0], extra[2][0], prm[2]],
+                         [tm[0], extra[0][1], tm[1], extra[1][1], extra[2][1], tm[2]], producer_done=True)
+    got = net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
+    for (Y, S, st), w in zip(got, (want[0], extra[0][2], want[1], extra[1][2], extra[2][2], want[2])):
+        assert np.array_equal(Y, w[0]) and np.array_equal(S, w[1])
+        _same(st, w[2])
+        if max(int(st.level_regions[l]) for l in range(st.n_levels)) <= 1024:
+            assert st.search_form == 5 and st.n_reruns == 0
+        else:
+            # (the 1000x700 image's tree has up to 1447 regions at its sixth level: more than the fused level kernel's tables
+            #  hold -- that image is searched again alone, the others are not)
+            assert st.n_reruns == 1
+    # an image too small for the lockstep form (40x60: two levels): the batch is searched one by one, same results
+    H, W, sc = 40, 60, 15.0
     fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
-    small = synth.make_scene_map(400, synth.SMALL_DIMS["C"], fh, fw)
+    small = synth.make_scene_map(410, synth.SMALL_DIMS["C"], fh, fw)
     ref.set_conv(small)
     w_small = ref.propose(_plain(ffi, H, W, sc, tz), want_scores=True, want_stats=True)
-    assert w_small[2].n_levels != want[0][2].n_levels
+    assert w_small[2].n_levels == 2
     net.ctx.batch_launch([prm[0], ffi.AzContext.make_params(H, W, sc, tz, static_tree=False), prm[1]],
                          [tm[0], _cl(torch, small), tm[1]], producer_done=True)
-    got = net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
-    for (Y, S, st), w in zip(got, (want[0], w_small, want[1])):
+    for (Y, S, st), w in zip(net.ctx.batch_fetch_all(want_scores=True, want_stats=True), (want[0], w_small, want[1])):
         assert np.array_equal(Y, w[0]) and np.array_equal(S, w[1])
         assert st.search_form != 5

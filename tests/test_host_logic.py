@@ -198,20 +198,22 @@ def test_bench_self_launch_relays_rank_failures():
 
 
 def test_batched_proposals_groups_by_shape_and_keeps_dataset_order(monkeypatch, capsys):
-    """detect.test._batched_proposals (cfg.TEST.BATCH_IMAGES): every image exactly once and in dataset order, a batch = images
-    whose searches have ONE number of levels (at most nb, taken from a read-ahead window; their shapes may differ), the
-    per-image line printed in order -- with the GPU halves replaced by recorders."""
+    """detect.test._batched_proposals (cfg.TEST.BATCH_IMAGES): every image exactly once and in dataset order, a batch = at most
+    nb images of any shapes and level counts, taken from a read-ahead window -- only images too small for the lockstep form
+    (fewer than three levels) are kept among themselves --, the per-image line printed in order; with the GPU halves replaced
+    by recorders."""
     from detect import test as T
-    shapes = [(375, 500, 3), (150, 200, 3), (375, 500, 3), (600, 1000, 3), (500, 375, 3), (150, 200, 3), (375, 500, 3),
+    shapes = [(375, 500, 3), (50, 70, 3), (375, 500, 3), (600, 1000, 3), (500, 375, 3), (60, 60, 3), (375, 500, 3),
               (333, 500, 3), (90, 120, 3), (375, 500, 3), (160, 200, 3), (375, 500, 3), (375, 500, 3), (500, 375, 3),
-              (375, 500, 3), (150, 220, 3), (375, 500, 3)]
-    levels = [T._num_levels(sh) for sh in shapes]
-    assert sorted(set(levels)) == [4, 5, 6] and T._num_levels((600, 1000, 3)) == 6 and T._num_levels((333, 500, 3)) == 6
+              (375, 500, 3), (45, 220, 3), (375, 500, 3)]
+    levels = [T._lockstep_ok(sh) for sh in shapes]
+    assert T._num_levels((600, 1000, 3)) == 6 and T._num_levels((333, 500, 3)) == 6 and T._num_levels((90, 120, 3)) == 4
+    assert levels.count(False) == 3 and not T._lockstep_ok((79, 500, 3)) and T._lockstep_ok((80, 500, 3))
     ims = [np.full(s, i, dtype=np.uint8) for i, s in enumerate(shapes)]
     batches, log = [], []
 
     def backbones(net, group, after=None):
-        assert len({T._num_levels(im.shape) for im in group}) == 1
+        assert len({T._lockstep_ok(im.shape) for im in group}) == 1
         h = {"shapes": [im.shape for im in group], "n": len(group), "ims": group, "convs": [("conv", int(im.flat[0])) for im in group],
              "after": after}
         log.append(("backbones", [int(im.flat[0]) for im in group]))
