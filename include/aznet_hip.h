@@ -224,9 +224,10 @@ void *az_last_stream(az_ctx *ctx);
 int az_batch_launch(az_ctx *ctx, int n, const az_params *p, const float *const *maps_nhwc_dev, int C, int H, int W);
 /* The same for images of SEVERAL shapes (a dataset mixes them: VOC has 500x375, 375x500, 500x333 ...): params[b] and the map
  * size H[b] x W[b] are image b's; every image keeps its own pre-pass, RoIPool clamps to its own map and its boxes are clipped
- * to its own size, the head passes are shared as before.  The images of a batch must walk the same number of levels
- * (K of lib/detect/test.py:365-368: the same floor(log2(min side / MIN_SIDE))) and share num_proposals, eps, min_side and the
- * flags; otherwise they are searched one by one (same results). */
+ * to its own size, the head passes are shared as before.  The trees may differ in depth (K of lib/detect/test.py:365-368):
+ * the batch runs as many level passes as its deepest tree has, an image's last level gets its final selection where the
+ * others go on.  The images of a batch share num_proposals, eps, min_side and the flags, and each has at least three levels
+ * (>= 80 px on the short side at MIN_SIDE 10); otherwise they are searched one by one (same results). */
 int az_batch_launch_shapes(az_ctx *ctx, int n, const az_params *params, const float *const *maps_nhwc_dev, int C,
                            const int *H, const int *W);
 int az_batch_fetch(az_ctx *ctx, int i, double *boxes_out, float *scores_out, int cap, int *n_out, az_stats *stats);
