@@ -514,6 +514,14 @@ class AzContext(object):
             out.append(r[0] if len(r) == 1 else tuple(r))
         return out
 
+    def batch_drain(self):
+        """Collect and drop every batch still in flight (after an error in the caller's loop: the context is usable again)."""
+        while getattr(self, "_batches", None):
+            try:
+                self.batch_fetch_all()
+            except AzError:
+                pass
+
     def batch_record_event(self):
         """A torch.cuda.Event recorded now on the stream of the batch launched last: behind that batch."""
         return self._batch_stream.record_event()

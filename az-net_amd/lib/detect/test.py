@@ -275,27 +275,33 @@ def _batched_proposals(net, images, num_images, nb, launch_ahead=True):
         return idx, [buf.pop(i) for i in idx]
 
     pend = None
-    while True:
-        g = next_group()
-        nxt = None
-        if g is not None:
-            nxt = _batch_backbones(net, g[1], after=(pend["done"] if pend is not None else None))
-            nxt["idx"] = g[0]
-            if launch_ahead:
-                nxt = _batch_launch(net, nxt)
-        if pend is not None:
-            for i in range(pend["n"]):
-                Y, line = _batch_finish(net, pend, i, quiet=True)
-                done[pend["idx"][i]] = (pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}, line)
-            while state["out"] in done:
-                im, Y, conv, line = done.pop(state["out"])
-                state["out"] += 1
-                print(line)
-                yield im, Y, conv
-        if nxt is None:
-            break
-        pend = nxt if launch_ahead else _batch_launch(net, nxt)
-    assert not done and state["out"] == num_images
+    try:
+        while True:
+            g = next_group()
+            nxt = None
+            if g is not None:
+                nxt = _batch_backbones(net, g[1], after=(pend["done"] if pend is not None else None))
+                nxt["idx"] = g[0]
+                if launch_ahead:
+                    nxt = _batch_launch(net, nxt)
+            if pend is not None:
+                for i in range(pend["n"]):
+                    Y, line = _batch_finish(net, pend, i, quiet=True)
+                    done[pend["idx"][i]] = (pend["ims"][i], Y, {name: pend["convs"][i] for name in cfg.SEAR.FRCNN_CONV}, line)
+                while state["out"] in done:
+                    im, Y, conv, line = done.pop(state["out"])
+                    state["out"] += 1
+                    print(line)
+                    yield im, Y, conv
+            if nxt is None:
+                break
+            pend = nxt if launch_ahead else _batch_launch(net, nxt)
+        assert not done and state["out"] == num_images
+    finally:
+        # (a loop that ends early -- an error, a caller that stops iterating -- leaves no batch in flight on the context)
+        hnet = net["full"] if isinstance(net, dict) else net
+        if hnet is not None and hasattr(getattr(hnet, "ctx", None), "batch_drain"):
+            hnet.ctx.batch_drain()
 
 
 def _prefetch_depth():
