@@ -553,7 +553,16 @@ int az_batch_launch_shapes(az_ctx *c, int n, const az_params *pa, const float *c
     if (L != c) { if (L->cal.state == 0 && c->cal.state != 0) L->cal = c->cal; }
     int not_taken = 0;
     rc = batch_launch_impl(L, B, n, B.slots.data(), pa, maps, Hs, Ws, &not_taken);
-    if (rc && !not_taken) { if (L != c) c->err = L->err; return rc; }
+    if (rc && !not_taken) {
+        // (a HIP call failed somewhere in the launch sequence: whatever was enqueued is waited for and dropped, so that the
+        //  slots do not sit on half a batch)
+        const std::string msg = L->err;
+        (void)hipStreamSynchronize(L->stream);
+        (void)hipGetLastError();
+        for (int b = 0; b < n; ++b) { B.slots[b]->pend.clear(); for (bool &sb : B.slots[b]->slot_busy) sb = false; }
+        c->err = msg;
+        return rc;
+    }
     B.lockstep = !not_taken;
     if (not_taken) {
         // this shape / these settings: one search per image, each on its slot's own stream, behind whatever the caller made
