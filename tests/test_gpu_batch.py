@@ -386,3 +386,42 @@ def test_images_of_several_shapes_in_one_batch(mods, tz):
     for (Y, S, st), w in zip(net.ctx.batch_fetch_all(want_scores=True, want_stats=True), (want[0], w_small, want[1])):
         assert np.array_equal(Y, w[0]) and np.array_equal(S, w[1])
         assert st.search_form != 5
+
+
+@pytest.mark.parametrize("lockstep", [True, False])
+def test_a_batch_staged_into_a_device_buffer(mods, lockstep):
+    """az_batch_stage_results_dev: the batch's result records go to rows of a device buffer (the RCCL send buffer of an
+    image-sharded run) in one strided copy -- complete when the images have been fetched, equal to what the fetch returns;
+    also for a batch that is searched image by image (a 40x60 image: one copy per image there)."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    if lockstep:
+        H, W, sc, tz = 600, 1000, 1.0, TZ_OBJ
+        fmaps = _object_set(synth, 5)
+    else:
+        H, W, sc, tz = 40, 60, 15.0, 0.3
+        fh, fw = synth.conv_out_size(int(round(H * sc))), synth.conv_out_size(int(round(W * sc)))
+        fmaps = [synth.make_scene_map(j, synth.SMALL_DIMS["C"], fh, fw) for j in range(5)]
+    net = HipAZNet(head, name="staged")
+    k = 100
+    prm = ffi.AzContext.make_params(H, W, sc, tz, num_proposals=k)
+    nbytes, n_off, b_off, s_off = ffi.AzContext.result_record_layout(k)
+    pitch = nbytes + 64
+    buf = torch.zeros((7, pitch), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ffi.AzError):
+        net.ctx.batch_stage_results(buf.data_ptr(), pitch, 7 * pitch)          # no batch in flight
+    net.ctx.batch_launch(prm, [_cl(torch, f) for f in fmaps], producer_done=True)
+    with pytest.raises(ffi.AzError):
+        net.ctx.batch_stage_results(buf.data_ptr(), nbytes - 4, 7 * pitch)     # rows too short
+    net.ctx.batch_stage_results(buf[1].data_ptr(), pitch, 6 * pitch)           # rows 1 .. 5
+    got = net.ctx.batch_fetch_all(want_scores=True, want_stats=True)
+    raw = buf.cpu().numpy()
+    assert not raw[0].any() and not raw[6].any()
+    for i, (Y, S, st) in enumerate(got):
+        assert (st.search_form == 5) == lockstep
+        r = raw[1 + i]
+        n = int(r[n_off:n_off + 4].view(np.int32)[0])
+        assert n == Y.shape[0]
+        assert np.array_equal(r[b_off:b_off + n * 32].view(np.float64).reshape(n, 4), Y)
+        assert np.array_equal(r[s_off:s_off + n * 4].view(np.float32), S)
+        assert not r[nbytes:].any()                                            # (the pitch's padding is not touched)
