@@ -537,6 +537,13 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     }
     const bool split = c->split_now && c->stream2 && c->ev_h6 && c->ev_i7;
     hipStream_t s2 = split ? c->stream2 : c->stream;
+    // Stage 1 of a staged search waits for the int7 of the previous one (ev_i7) -- RoIPool included: beside int7 the
+    // HBM-bound RoIPool of the next image costs that int7 40 us (70 -> 110) to hide 27 of its own, and the int6 behind it
+    // starts later for it.  Measured on one lane, three searches queued: 1.181 -> 1.128 ms per image (two queued: 1.135 ->
+    // 1.141: there the host's launch latency did the same by accident).  AZ_ROI_AFTER_I7=0: RoIPool does not wait (the
+    // round-5 first version; measurements).
+    static const int roi_after_i7 = getenv("AZ_ROI_AFTER_I7") ? atoi(getenv("AZ_ROI_AFTER_I7")) : 1;
+    if (roi_after_i7 && c->i7_live) { if (hipStreamWaitEvent(c->stream, c->ev_i7, 0) != hipSuccess) c->async_err = 1; c->i7_live = false; }
     { Timed t(c, "roi_pool", level);
       azk_roi_pool(c->stream, c->feat, d, c->spatial_scale, urois ? urois : c->urois, Uptr, c->maxR, c->pool5, c->pool5p,
                    azk_act_plane_elems(c->maxR, d.K6), c->gemm_parts, 0, coop_tail, c->gemm_parts == 2 ? c->gscale : nullptr); }
@@ -547,7 +554,7 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
         c->events.push_back({name, level, nullptr, nullptr, sl});
         return c->span_ring + 2 * (size_t)sl;
     };
-    // int6 waits for the int7 of the previous two-stage search of this context (the RoIPool above does not): h6, which this
+    // int6 waits for the int7 of the previous two-stage search of this context (as the RoIPool above by default): h6, which this
     // pass's slab sum writes, is that int7's operand -- and an int6 that starts while int7's workgroups still hold CUs runs
     // with stragglers to its end (one persistent workgroup per CU, work dealt statically: measured 1.13 -> 1.24 ms per image
     // when the two overlapped)
