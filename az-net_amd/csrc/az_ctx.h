@@ -541,7 +541,8 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     // HBM-bound RoIPool of the next image costs that int7 40 us (70 -> 110) to hide 27 of its own, and the int6 behind it
     // starts later for it.  Measured on one lane, three searches queued: 1.181 -> 1.128 ms per image (two queued: 1.135 ->
     // 1.141: there the host's launch latency did the same by accident).  AZ_ROI_AFTER_I7=0: RoIPool does not wait (the
-    // round-5 first version; measurements).
+    // round-5 first version; measurements).  The same order across the two lanes of a context (a lane's many-row RoIPool
+    // behind the OTHER lane's int7, an event both ways) was measured too: 1.114 -> 1.138 ms, not kept.
     static const int roi_after_i7 = getenv("AZ_ROI_AFTER_I7") ? atoi(getenv("AZ_ROI_AFTER_I7")) : 1;
     if (roi_after_i7 && c->i7_live) { if (hipStreamWaitEvent(c->stream, c->ev_i7, 0) != hipSuccess) c->async_err = 1; c->i7_live = false; }
     { Timed t(c, "roi_pool", level);
