@@ -1423,8 +1423,8 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
                     ctx.propose_launch(p, fmap=tmap, producer_done=True)
                     launched += 1
                 ctx.propose_fetch()
-        queued(6)
-        torch.cuda.synchronize()
+        queued(12)                                 # (both lanes' histories and plans for this shape settle: a plan built in
+        torch.cuda.synchronize()                   #  the timed region showed up once as 8.8 ms per image in a 10-image sample)
         t0 = time.perf_counter()
         queued(n_img)
         torch.cuda.synchronize()
