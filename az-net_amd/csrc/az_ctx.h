@@ -587,7 +587,14 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     c->profiling = prof_keep;
     { Timed t(c, "fc6_reduce", level);
       azk_fc_reduce(c->stream, c->part, c->b6, Uptr, c->maxR, d.n6, c->S6, c->h6, d.n6, 1); }
-    if (split) {
+    // int7 stays in stage 1 -- RoIPool, int6, slab sum, int7 back to back on `stream`: the chip-wide kernels of consecutive
+    // images follow each other without an event hop (each ~13 us on the critical path: slab sum -> int7 on the second
+    // stream, int7 -> the next image's RoIPool back on the first); stage 2 = the heads (+ geometry, or stage 3).  int7 writes
+    // its slabs where the previous search's heads read theirs: it waits for that search's stage 2, which ended ~1000 us
+    // before.  One lane, three queued: 1.130-1.135 -> 1.116 ms per image.  AZ_I7_STAGE1=0: int7 in stage 2 (measurements).
+    static const int i7s1 = getenv("AZ_I7_STAGE1") ? atoi(getenv("AZ_I7_STAGE1")) : 1;
+    const bool i7_first = split && i7s1 && c->part7;
+    if (split && !i7_first) {
         // stage 2 from here on: int7 behind the slab sum, everything the caller enqueues behind this pass behind int7
         if (hipEventRecord(c->ev_h6, c->stream) != hipSuccess || hipStreamWaitEvent(s2, c->ev_h6, 0) != hipSuccess) c->async_err = 1;
         c->gs = s2; c->ts = s2;
@@ -595,10 +602,16 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
     float *p7 = c->part7 ? c->part7 : c->part;
     unsigned long long *ts7 = span_slot("fc7_gemm");
     if (ts7) c->profiling &= ~(1 | 2);
+    if (i7_first && c->s2_live && hipStreamWaitEvent(c->stream, c->ev_s2, 0) != hipSuccess) c->async_err = 1;
+    if (i7_first && c->s3_live && !c->three_now && hipStreamWaitEvent(c->stream, c->ev_s3, 0) != hipSuccess) c->async_err = 1;
     { Timed t(c, "fc7_gemm", level, 1);
-      azk_fc_gemm(s2, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, p7, 1 << 30, ts7); }
+      azk_fc_gemm(i7_first ? c->stream : s2, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, p7, 1 << 30, ts7); }
     c->profiling = prof_keep;
-    if (split) { if (hipEventRecord(c->ev_i7, s2) != hipSuccess) c->async_err = 1; c->i7_live = true; }
+    if (i7_first) {
+        // stage 2 from here on: the heads behind int7
+        if (hipEventRecord(c->ev_h6, c->stream) != hipSuccess || hipStreamWaitEvent(s2, c->ev_h6, 0) != hipSuccess) c->async_err = 1;
+        c->gs = s2; c->ts = s2;
+    } else if (split) { if (hipEventRecord(c->ev_i7, s2) != hipSuccess) c->async_err = 1; c->i7_live = true; }
     const bool three = split && c->three_now && c->stream3 && c->ev_tail;
     // (three stages: the heads write the output set the geometry of the search before the previous one read)
     if (three && c->g_live[c->out_par]) {

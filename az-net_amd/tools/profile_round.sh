@@ -58,7 +58,7 @@ for s in $sets; do
     # (the search's first, history-less image takes the two-pass form: one stray pair of launches in the averages)
     main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
     # the same loop on ONE lane (az_set_lanes(1)): strictly one image at a time on the GPU -- rounds 1-3's `value`
-    onelane) run_set onelane "--steps 100 --warmup 10 $common --lanes 1 --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "onelane_" 2 ;;
+    onelane) run_set onelane "--steps 100 --warmup 10 $common --lanes 1 --queue-depth 3 --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "onelane_" 2 ;;
     # the level loop without the whole-tree pass (AZ_FULL_SPEC=0): 48-row pass (k_fc_splitk int6, int7), 670-row pass
     # (k_fc_splitk12 int6, int7) = 4
     twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "twopass_" 4 ;;
