@@ -7,6 +7,7 @@
 extern "C" {
 
 const char *az_version(void) { return AZ_VERSION_STR; }
+int az_abi_sizes(void) { return (int)(sizeof(az_params) & 0xffff) | (int)((sizeof(az_stats) & 0xffff) << 16); }
 
 int az_create(int device, az_ctx **out)
 {
@@ -70,11 +71,13 @@ int az_destroy(az_ctx *c)
         if (c->h_res[i]) hipHostFree(c->h_res[i]);
         if (c->ev_res[i]) hipEventDestroy(c->ev_res[i]);
     }
-    for (int i = 0; i < 2; ++i) {
-        if (c->io_host[i]) hipHostFree(c->io_host[i]);
-        if (c->io_dev[i]) hipFree(c->io_dev[i]);
-        if (c->io_ev[i]) hipEventDestroy(c->io_ev[i]);
+    for (auto &q : c->io) {
+        if (q.host) hipHostFree(q.host);
+        if (q.dev) hipFree(q.dev);
+        if (q.ev) hipEventDestroy(q.ev);
     }
+    c->io.clear();
+    if (c->spare.ev) { hipEventDestroy(c->spare.ev); c->spare.ev = nullptr; }
     if (c->ev_hand) hipEventDestroy(c->ev_hand);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->span_ring) hipFree(c->span_ring);
@@ -130,6 +133,7 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
     destroy_batch(c);
     free_all(c);
+    c->spare.ready = false; c->spare.ev_live = false;      // (its buffers were in the list free_all walked; the slots are gone)
     c->head_loaded = false;
     {
         int rg = ensure_geom(c);
@@ -272,6 +276,37 @@ int ensure_lane_head(az_ctx *t)
     HIPCHK(t, hipSetDevice(t->device));
     const size_t R = (size_t)t->maxR;
     const AzHeadDims &d = t->d;
+    if (t->batch_set && t->owner) {
+        // a batch slot: the owner's spare set (az_ctx.h: SpareHead), created at its first use
+        az_ctx *o = t->owner;
+        auto &sp = o->spare;
+        if (!sp.ready) {
+            auto bad = [&](int code) { t->err = o->err; return code; };
+#define A(p, n) if ((rc = dalloc(o, &sp.p, (n))) != AZ_OK) return bad(rc)
+            A(pool5, R * d.K6);
+            {
+                const size_t p6 = (size_t)t->S6 * R * d.n6, p7 = (size_t)t->S7 * R * d.n7;
+                A(part, p6 > p7 ? p6 : p7);
+            }
+            A(h6, R * d.n6); A(h7, R * d.n7);
+            A(part7, (size_t)t->S7 * R * d.n7);
+            if (t->gemm_parts) {
+                A(pool5p, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6)); A(gscale, 4);
+                if (hipMemsetAsync(sp.pool5p, 0, (size_t)t->gemm_parts * azk_act_plane_elems((int)R, d.K6) * 2, o->stream) != hipSuccess ||
+                    hipMemsetAsync(sp.gscale, 0, 4 * sizeof(float), o->stream) != hipSuccess || hipStreamSynchronize(o->stream) != hipSuccess)
+                    return fail(t, AZ_ERR_HIP, "batch slot: clearing the spare operand planes");
+            }
+#undef A
+            if (!sp.ev && hipEventCreateWithFlags(&sp.ev, hipEventDisableTiming) != hipSuccess)
+                return fail(t, AZ_ERR_HIP, "batch slot: the spare head set's event");
+            sp.ready = true; sp.ev_live = false;
+        }
+        t->pool5 = sp.pool5; t->part = sp.part; t->h6 = sp.h6; t->h7 = sp.h7; t->part7 = sp.part7;
+        t->pool5p = sp.pool5p; t->gscale = sp.gscale;
+        t->head_shared = true;
+        t->head_bufs = true;
+        return AZ_OK;
+    }
 #define A(p, n) if ((rc = dalloc(t, &t->p, (n))) != AZ_OK) return rc
     A(pool5, R * d.K6);
     {
@@ -535,6 +570,10 @@ int az_batch_launch_shapes(az_ctx *c, int n, const az_params *pa, const float *c
     int lane, rc;
     az_ctx *L = batch_lane(c, &lane, &rc);
     if (!L) return rc;
+    // (the batch's pre-pass and passes write the lane's counters and per-roi outputs: a search of the lane whose result block
+    //  is not on its way yet -- variable proposal count, the tuner's variant -- would lose them; launch_impl's rule for queueing)
+    if (!L->pend.empty() && !L->pend.back().copied)
+        return fail(c, AZ_ERR_STATE, "az_batch_launch: a search without a fixed proposal count is still unfetched on this lane");
     const int set = L->bset_turn;
     auto &B = L->bsets[set];
     if (B.n_live) return fail(c, AZ_ERR_STATE, "az_batch_launch: two batches per lane are already in flight, fetch one first");

@@ -205,6 +205,17 @@ struct az_ctx {
     std::deque<int> batch_order;              // (owner) lane | set << 1 of the batches in flight, oldest first
     int batch_next = 0;
     bool head_bufs = true;                    // false: a batch slot that has not needed pool5 / slabs / h6 / h7 yet
+    // A batch slot that searches on its own (its batch's pass overflowed, its shape is not taken in lockstep) does not get a
+    // head set of its own -- at max_regions 16384 and the VGG16 dims that is ~8.5 GB, times 32 slots, times two sets per
+    // lane -- but takes the OWNER's one spare set in turn: `ev` (recorded behind each such search) orders the next user's
+    // stream behind the previous one.  The searches were chip-wide one after the other anyway.
+    struct SpareHead {
+        float *pool5 = nullptr, *part = nullptr, *h6 = nullptr, *h7 = nullptr, *part7 = nullptr, *gscale = nullptr;
+        unsigned short *pool5p = nullptr;
+        bool ready = false, ev_live = false;
+        hipEvent_t ev = nullptr;
+    } spare;                                  // (owner)
+    bool head_shared = false;                 // (a batch slot) pool5 / part / h6 / h7 / part7 are the owner's spare set
     Batch *batch_set = nullptr;               // (a batch slot) the batch set it belongs to
     // (a batch slot) its counters / result block and its first host result slot are slices of the lane's arenas
     // (Batch::res_dev / res_host); the slot's own allocations stay in its lists and are freed with it
@@ -272,9 +283,13 @@ struct az_ctx {
     size_t ev_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // front-end on a caller's stream (az_image_blob_dev_on): two pinned host slots and two device slots for the uint8 image,
     // used in turn; a slot's event says its last upload + kernel are done
-    unsigned char *io_host[2] = {nullptr, nullptr}, *io_dev[2] = {nullptr, nullptr};
+    // upload slots of az_image_blob_dev_on (pinned host + device staging + "slot free" event).  Two to start with; a slot
+    // whose previous upload is still queued on the GPU (a lockstep batch's uploads wait behind the previous batch's search)
+    // makes the ring GROW, up to IO_SLOTS_MAX, instead of making the host wait.
+    static constexpr int IO_SLOTS_MAX = 40;
+    struct IoSlot { unsigned char *host = nullptr, *dev = nullptr; hipEvent_t ev = nullptr; };
+    std::vector<IoSlot> io;
     size_t io_cap = 0;
-    hipEvent_t io_ev[2] = {nullptr, nullptr};
     int io_turn = 0;
     // pinned host staging
     AzCounts *h_cnt = nullptr;

@@ -886,8 +886,22 @@ static int enqueue_search(az_ctx *c, const az_params *p, int K, int nlev, int k,
 }
 
 
+static int launch_impl_body(az_ctx *c, const az_params *p);
+
 // One search enqueued on THIS context's stream (the public az_propose_launch picks the lane first).
 int launch_impl(az_ctx *c, const az_params *p)
+{
+    const int rc = launch_impl_body(c, p);
+    // a batch slot on the owner's spare head set: the next slot to take the set waits for what this one enqueued (whatever
+    // became of the launch -- a failed one may have enqueued its first kernels)
+    if (c && c->head_shared && c->owner && c->owner->spare.ev) {
+        if (hipEventRecord(c->owner->spare.ev, c->stream) == hipSuccess) c->owner->spare.ev_live = true;
+        else { (void)hipGetLastError(); c->async_err = 1; }
+    }
+    return rc;
+}
+
+static int launch_impl_body(az_ctx *c, const az_params *p)
 {
     int rc = check_ready(c, true, false);          // (whether `stream` waits for the second stream is decided below)
     if (rc) return rc;
@@ -912,6 +926,8 @@ int launch_impl(az_ctx *c, const az_params *p)
     if ((int)c->pend.size() >= az_ctx::AZ_QUEUE_MAX)
         return fail(c, AZ_ERR_STATE, "az_propose_launch: three searches are already queued on this lane, fetch one first");
     if (!c->head_bufs && (rc = ensure_lane_head(c)) != AZ_OK) return rc;   // (a batch slot searching on its own for the first time)
+    if (c->head_shared && c->owner && c->owner->spare.ev_live)             // (... behind the slot that had the spare set before it)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->owner->spare.ev, 0));
     if (!c->pend.empty() && !(p->fixed_num && c->pend.back().copied))
         return fail(c, AZ_ERR_STATE, "az_propose_launch: queueing a search behind another needs a fixed proposal count for both");
     HIPCHK(c, hipSetDevice(c->device));
@@ -942,7 +958,7 @@ int launch_impl(az_ctx *c, const az_params *p)
     if (c->split_env < 0) { const char *e = getenv("AZ_TWO_STAGE"); c->split_env = e ? atoi(e) : 1; }
     const bool one_lane = !c->owner && c->lanes == 1;
     c->split_now = (c->split_env && (one_lane || c->split_env == 2) && (stat || c->last_full) && p->fixed_num && !c->use_graphs &&
-                    !tune && !Timed::trace()) ? 1 : 0;
+                    !tune && !Timed::trace() && !c->head_shared) ? 1 : 0;
     if (c->split_now && !c->stream2) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);

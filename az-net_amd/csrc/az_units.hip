@@ -841,29 +841,46 @@ int az_image_blob_dev_on(az_ctx *c, const uint8_t *im, int h, int w, const float
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     const size_t nin = (size_t)h * w * 3;
     if (nin > c->io_cap) {
-        // (grow: nothing may still be reading the old slots)
-        for (int i = 0; i < 2; ++i) if (c->io_ev[i]) HIPCHK(c, hipEventSynchronize(c->io_ev[i]));
-        for (int i = 0; i < 2; ++i) {
-            if (c->io_host[i]) hipHostFree(c->io_host[i]);
-            if (c->io_dev[i]) hipFree(c->io_dev[i]);
-            c->io_host[i] = nullptr; c->io_dev[i] = nullptr;
+        // (larger images: nothing may still be reading the old slots)
+        for (auto &q : c->io) {
+            if (q.ev) HIPCHK(c, hipEventSynchronize(q.ev));
+            if (q.host) hipHostFree(q.host);
+            if (q.dev) hipFree(q.dev);
+            if (q.ev) hipEventDestroy(q.ev);
         }
-        c->io_cap = 0;
-        const size_t cap = nin + nin / 4 + 256;
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(c, hipHostMalloc((void **)&c->io_host[i], cap));
-            HIPCHK(c, hipMalloc((void **)&c->io_dev[i], cap));
-            if (!c->io_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->io_ev[i], hipEventDisableTiming));
-        }
-        c->io_cap = cap;
+        c->io.clear();
+        c->io_cap = nin + nin / 4 + 256;
+        c->io_turn = 0;
     }
-    const int t = c->io_turn;
-    c->io_turn ^= 1;
-    HIPCHK(c, hipEventSynchronize(c->io_ev[t]));            // (the slot's previous image: two uploads ago, long done)
-    std::memcpy(c->io_host[t], im, nin);                    // the caller's array may go away as soon as this returns
-    HIPCHK(c, hipMemcpyAsync(c->io_dev[t], c->io_host[t], nin, hipMemcpyHostToDevice, s));
-    azk_image_blob(s, c->io_dev[t], h, w, means, 1.0 / scale, 1.0 / scale, oh, ow, blob_dev);
-    HIPCHK(c, hipEventRecord(c->io_ev[t], s));
+    auto add_slot = [&](size_t at) {
+        az_ctx::IoSlot q;
+        if (hipHostMalloc((void **)&q.host, c->io_cap) != hipSuccess || hipMalloc((void **)&q.dev, c->io_cap) != hipSuccess ||
+            hipEventCreateWithFlags(&q.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (q.host) hipHostFree(q.host);
+            if (q.dev) hipFree(q.dev);
+            if (q.ev) hipEventDestroy(q.ev);
+            return false;
+        }
+        c->io.insert(c->io.begin() + (long)at, q);
+        return true;
+    };
+    while (c->io.size() < 2)
+        if (!add_slot(c->io.size())) return fail(c, AZ_ERR_HIP, "az_image_blob_dev_on: upload slots");
+    if (c->io_turn >= (int)c->io.size()) c->io_turn = 0;
+    // the slot in turn holds the oldest upload: done long ago in a loop that fetches what it launches; still QUEUED when the
+    // caller enqueues a whole batch behind the previous batch's search -- then a fresh slot takes this image (it goes in
+    // front of the busy one: the ring stays oldest-first) rather than the host waiting for the GPU
+    if (hipEventQuery(c->io[c->io_turn].ev) == hipErrorNotReady && (int)c->io.size() < az_ctx::IO_SLOTS_MAX)
+        (void)add_slot((size_t)c->io_turn);
+    (void)hipGetLastError();
+    az_ctx::IoSlot &q = c->io[c->io_turn];
+    c->io_turn = (c->io_turn + 1) % (int)c->io.size();
+    HIPCHK(c, hipEventSynchronize(q.ev));                   // (a fresh slot's event was never recorded: returns at once)
+    std::memcpy(q.host, im, nin);                           // the caller's array may go away as soon as this returns
+    HIPCHK(c, hipMemcpyAsync(q.dev, q.host, nin, hipMemcpyHostToDevice, s));
+    azk_image_blob(s, q.dev, h, w, means, 1.0 / scale, 1.0 / scale, oh, ow, blob_dev);
+    HIPCHK(c, hipEventRecord(q.ev, s));
     HIPCHK(c, hipGetLastError());
     return AZ_OK;
 }

@@ -37,7 +37,7 @@ SYMBOLS = [
     "az_measure_box", "az_image_blob_dev_on", "az_set_lanes", "az_next_stream", "az_last_stream",
     "az_rccl_unique_id", "az_rccl_init", "az_gather_records", "az_rccl_destroy", "az_comm_stream",
     "az_bias_relu", "az_bias_relu_pool", "az_batch_launch", "az_batch_fetch", "az_batch_next_stream",
-    "az_batch_stage_results_dev", "az_batch_fetch_all", "az_batch_launch_shapes",
+    "az_batch_stage_results_dev", "az_batch_fetch_all", "az_batch_launch_shapes", "az_abi_sizes",
 ]
 
 
@@ -179,6 +179,14 @@ def load_library(path=None):
         if name not in ("az_version", "az_last_error", "az_stream", "az_next_stream", "az_last_stream", "az_comm_stream",
                         "az_batch_next_stream"):
             getattr(L, name).restype = ci
+    # the structs this module hands across the boundary have the library's layout (every fetch clears sizeof(az_stats) bytes
+    # of the caller's block: a binding built for another header must not get that far)
+    L.az_abi_sizes.argtypes = []
+    sizes = int(L.az_abi_sizes())
+    if (sizes & 0xffff, (sizes >> 16) & 0xffff) != (ctypes.sizeof(AzParams), ctypes.sizeof(AzStats)):
+        raise AzError(AZ_ERR_INVALID, "libaznet_hip.so %s has sizeof(az_params, az_stats) = (%d, %d), this binding (%d, %d): "
+                      "rebuild az-net_amd/csrc" % (L.az_version().decode(), sizes & 0xffff, (sizes >> 16) & 0xffff,
+                                                  ctypes.sizeof(AzParams), ctypes.sizeof(AzStats)))
     if path is None:
         _lib = L
     return L
@@ -450,12 +458,18 @@ class AzContext(object):
                     converted = True
                     ent = None                       # (a converted copy is made again every time: the source may have changed)
                 else:
-                    if len(ck) > 256:
-                        ck.clear()
-                    ent = ck[id(f)] = (ptr, tuple(int(x) for x in t.shape[1:]), weakref.ref(f), t)
+                    # (only the checks' outcome is remembered, never the tensor or a view of it: an entry must not keep a
+                    #  conv map alive -- a dataset loop hands over a fresh tensor per image; entries whose tensor has died
+                    #  are dropped as soon as a few have gathered)
+                    if len(ck) >= 64:
+                        for k in [k for k, e in ck.items() if e[2]() is None]:
+                            del ck[k]
+                        if len(ck) >= 256:
+                            ck.clear()
+                    ent = ck[id(f)] = (ptr, tuple(int(x) for x in t.shape[1:]), weakref.ref(f))
                 chw = tuple(int(x) for x in t.shape[1:])
             else:
-                t, chw = ent[3], ent[1]
+                t, chw = (f if f.dim() == 4 else f[None]), ent[1]
             per_image = isinstance(params, (list, tuple))
             assert per_image or shape in (None, chw), "the maps of a batch have one shape (or pass one AzParams per image)"
             assert shape is None or shape[0] == chw[0]

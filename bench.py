@@ -116,6 +116,90 @@ FLOOR_NOTE = ("t_min_us_per_image = BASELINE.md section 3: sum over the LEVELS o
               "exceed; per_level_floor_over_measured may exceed 1 for a search that merges levels")
 
 
+COMPACT_LIMIT = 4096          # bytes; the driver keeps 8 KB of stdout tail (round 5's 30 KB line was unreadable to it)
+
+
+def _r(x, nd=6):
+    """floats to `nd` significant digits (the compact line is for reading and parsing, the extras file keeps every bit)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    if isinstance(x, (np.floating,)):
+        return _r(float(x), nd)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(out, extras_file=None):
+    """The ONE line bench.py prints: the contract's keys, `roofline`, `cpu_baseline` and a handful of cross-checks -- strict
+    JSON, under COMPACT_LIMIT bytes whatever the side measurements produced (they live in the extras file)."""
+    cfg = out.get("config") or {}
+    rf = out.get("roofline") or {}
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    wl = str(cfg.get("workload_short") or cfg.get("workload") or "")
+    c = _pick(cfg, ("search_form", "rows_per_head_pass", "regions_per_level", "unique_rois_per_level", "image_hw",
+                    "num_proposals", "Tz", "parallelism", "lanes_per_context", "searches_run_twice_in_timed_region"))
+    c = dict({"workload": wl[:400]}, **c)
+    g = cfg.get("gather")
+    if g is not None:
+        c["gather"] = str(g)[:80]
+    line["config"] = c
+    line["rccl"] = _pick(out.get("rccl") or {}, ("backend", "world", "collectives", "error"))
+    r = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "frac_of_sustained", "traffic", "algorithmic_bytes",
+                   "flops_per_launch", "avg_launch_ms", "launches_per_step", "steps_timed"))
+    r["kernel"] = str(rf.get("kernel_short") or rf.get("kernel") or "")[:160]
+    line["roofline"] = r
+    if out.get("path_floor"):
+        line["path_floor"] = _pick(out["path_floor"], ("t_min_us_per_image", "merged_pass_t_min_us", "frac",
+                                                       "per_level_floor_over_measured", "head_passes"))
+    if out.get("value_200_steps"):
+        line["value_200_steps"] = _pick(out["value_200_steps"], ("steps", "ms_per_step", "value"))
+    if out.get("box"):
+        line["box"] = _pick(out["box"], ("sustained_fp32_mfma_tflops", "copy_tb_per_s"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        cc = _pick(cb, ("value", "unit", "cores", "kind", "host_cpus"))
+        cc["sample"] = str(cb.get("sample", ""))[:200]
+        line["cpu_baseline"] = cc
+        line["gpu_over_cpu"] = out.get("gpu_over_cpu")
+    if extras_file:
+        line["extras_file"] = extras_file
+    s = json.dumps(_r(line), allow_nan=False, separators=(", ", ": "))
+    if len(s) > COMPACT_LIMIT:            # (cannot happen with the fields above; a hard stop rather than an unreadable record)
+        for k in ("box", "path_floor", "value_200_steps"):
+            line.pop(k, None)
+        line["config"] = {"workload": wl[:200]}
+        s = json.dumps(_r(line), allow_nan=False, separators=(", ", ": "))
+    assert len(s) <= COMPACT_LIMIT, len(s)
+    return s
+
+
+def write_extras(out, path=None):
+    """Everything measured (the compact line's source and every side leg) as one JSON file; returns the paths written."""
+    paths = [path] if path else [os.path.join(REPO, "bench_extras.json")]
+    if not path and os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        paths.append(os.path.join(REPO, "gpurun_out", "bench_extras.json"))
+    done = []
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1, default=lambda o: _r(o))
+                f.write("\n")
+            done.append(p)
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (p, e))
+    return done
+
+
 def cpu_baseline(head, fmap, Tz, budget_s=20.0):
     """The oracle (kind "port") on the host, as SURVEY 8(d) specifies the CPU baseline: NumPy geometry exactly as
     lib/detect/test.py (one thread), C divide_region / RoIPool, and the fc head through torch CPU `addmm` as the stand-in for
@@ -215,11 +299,18 @@ def main():
                     help="the batch exchange as the library's own ncclAllGather on the ctx stream (az_gather_records) instead "
                          "of torch.distributed's all_gather_into_tensor")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", action="store_true",
+                    help="also run the side measurements (other search forms, Tz sweeps, streams of distinct images, BASELINE configs "
+                         "3 / 4, NMS sizes, backbone + search end to end, the CLI loop); every one of them lands in the extras "
+                         "file, never in the printed line.  The default run is the headline + roofline + cpu_baseline only")
+    ap.add_argument("--extras-file", default=None,
+                    help="where the full record goes (default: bench_extras.json beside this script, and a copy under gpurun_out/ "
+                         "when that directory exists)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--inflight", type=int, default=1,
                     help="images in flight per GPU in the timed region (each on its own az_ctx/stream); "
                          "1 = strictly one at a time, which keeps the per-kernel event timing clean")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra images-in-flight measurement")
+    ap.add_argument("--no-pipelined", action="store_true", help="(accepted and ignored: the three-context leg was retired in round 6)")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the level loop without the whole-tree pass (extra key)")
     ap.add_argument("--no-fast", action="store_true", help="skip the 16-bit-term modes (az_set_gemm_mode 2 / 3) measurement")
     ap.add_argument("--one-pass", action="store_true",
@@ -229,7 +320,7 @@ def main():
     ap.add_argument("--no-level-loop", action="store_true", help="(with --one-pass) skip the extra level-by-level measurement")
     ap.add_argument("--no-calibrated", action="store_true",
                     help="skip the extra data-dependent run (Tz = median zoom score of this image's regions)")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="az_set_lanes for the timed loops: 2 = the context's queued searches take turns between two streams, so "
                          "consecutive images overlap on the GPU (one context, queue-ahead); 1 = one stream, strictly one "
                          "image at a time on the GPU (reported as `one_lane` either way)")
@@ -253,6 +344,11 @@ def main():
                     help="HIP events around the fc GEMM launches of every n-th timed step (1: every step, ~30 us/step of stream time)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
     args = ap.parse_args()
+    if not args.extras:
+        # the side legs are opt-in (round 5's line with all of them was 30 KB; the driver keeps 8 KB of stdout)
+        for k in ("no_e2e", "no_pipelined", "no_two_pass", "no_fast", "no_one_pass", "no_level_loop", "no_calibrated",
+                  "no_one_lane", "no_stream", "no_sweep", "no_extras"):
+            setattr(args, k, True)
 
     if (args.gpus > 1 or args.launcher) and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: start the N ranks as fresh processes (one per GPU, RCCL) BEFORE this
@@ -523,6 +619,7 @@ def main():
         achieved = flops_per_image * n_timed_steps / (gemm_ms_total * 1e-3) / 1e12 if gemm_ms_total > 0 else 0.0
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # separate runs); cannot be collected live, so it is read from the committed summary.
+        prow_all = rows_per_pass(st) or []
         traffic, traffic_source = None, None
         tfile = os.path.join(REPO, "profiles", "roofline_traffic.json")
         if os.path.exists(tfile):
@@ -534,6 +631,9 @@ def main():
                                   % tj.get("source", "committed summary"))
             except Exception:
                 traffic = None
+        # SURVEY 8(d)'s algorithmic bytes of the fc GEMMs per launch: the weights of int6 / int7_1|int7_2 once per head pass
+        # (what the traffic counters are read against), averaged over the launches of a step like `traffic`
+        alg_bytes = (len(prow_all) * (25088 * 4096 + 4096 * 1280) * 4.0 / max(n_launch / max(n_timed_steps, 1), 1e-9)) if prow_all else None
         # the int6 launch shapes, each against ITS bound: max(weights / 8 TB/s, flops / 157.3 TF)
         fc6 = {}
         for n, l, ms in ktimes:
@@ -616,6 +716,10 @@ def main():
                                    "conv5_3 %s resident in HBM, %d distinct images rotated" %
                                    (args.tz, regions, uniq, form, NUM_PROPOSALS, st.n_candidates,
                                     [int(x) for x in conv.shape], len(convs)),
+                       "workload_short": "BASELINE config 2: VGG16 AZ proposal hot path, synthetic 600x1000 image (scale 1.0), "
+                                         "batch=1 per GPU, Tz=%g, top-%d of %d candidates; conv5_3 %s resident in HBM, %d images "
+                                         "rotated" % (args.tz, NUM_PROPOSALS, st.n_candidates, [int(x) for x in conv.shape], len(convs)),
+                       "regions_per_level": regions, "unique_rois_per_level": uniq,
                        "search_form": form_name, "rows_per_head_pass": prow,
                        "searches_run_twice_in_timed_region": reruns_timed,
                        "image_hw": [H_IM, W_IM], "num_proposals": NUM_PROPOSALS, "Tz": args.tz,
@@ -631,6 +735,8 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "fc GEMMs of the head passes: k_fc_splitk12 (int6 at >= 161 / 257 rows) and k_fc_splitk "
                                    "(int6 below, int7_1|int7_2); v_mfma_f32_32x32x2_f32",
+                         "kernel_short": "fc GEMMs of the head pass (k_fc_splitk12 int6 + k_fc_splitk int7), v_mfma_f32_32x32x2_f32",
+                         "algorithmic_bytes": alg_bytes,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          "frac_of_sustained": (achieved / box["sustained_fp32_mfma_tflops"]) if box else None,
@@ -759,33 +865,6 @@ def main():
                 "search_form": ffi.SEARCH_FORMS.get(int(stw.search_form), "?"),
                 "note": "Tz = 0 without the whole-tree pass: speculative rows, then level 4 + all children of level 4 -- the "
                         "form a dense pruned tree takes; bit-identical results"}
-    # ---- same work with three images in flight per GPU (three contexts / streams), for context ------
-    if not args.no_pipelined and args.inflight == 1:
-        NFL = 3
-        nets2 = [net] + [HipAZNet(head, backbone=backbone, device=local_rank, name=net.name, max_regions=4096)
-                         for _ in range(NFL - 1)]
-        for n in nets2[1:]:
-            n.set_conv(conv)
-            n.propose(params)
-        n_p = max(100, args.steps // 2)
-
-        def run2(k):
-            q = []
-            for i in range(k):
-                n = nets2[i % NFL]
-                if len(q) == NFL:
-                    q.pop(0).ctx.propose_fetch()
-                n.ctx.propose_launch(params)
-                q.append(n)
-            for m in q:
-                m.ctx.propose_fetch()
-        dp = timed_loop(run2, n_p)
-        if rank == 0:
-            out["pipelined"] = {"value": world * NUM_PROPOSALS * n_p / dp, "unit": "proposals/s",
-                                "ms_per_image": dp / n_p * 1e3, "images_in_flight_per_gpu": NFL,
-                                "note": "independent images overlapped on three az_ctx/streams: the latency-bound "
-                                        "geometry kernels of one image hide under the other's GEMMs"}
-        del nets2[1:]
     # ---- opt-in: int6 on the 16-bit matrix cores, fp32 operands as two fp16 / three bf16 terms (az_set_gemm_mode) -----
     if not args.no_fast and net.ctx.gemm_mode == 0:
         # error of the head's outputs against an f64 evaluation of the same head (numpy; pool5 from the RoIPool kernel,
@@ -1129,7 +1208,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        real_stdout.write(json.dumps(out) + "\n")
+        paths = write_extras(out, args.extras_file)
+        real_stdout.write(compact_line(out, extras_file=(os.path.relpath(paths[0], REPO) if paths else None)) + "\n")
         real_stdout.flush()
 
 
@@ -1399,50 +1479,60 @@ def extras(net, head, ffi, synth, HipDetNet, torch, args):
             by[nm] = by.get(nm, 0.0) + ms / n
         return sum(by.values()), by
 
-    # ---- config 4: 800x1200 original (scale 0.75 -> 600x900 input), K = 7 --------------------------------------
-    fmap = synth.make_feature_map(4, 512, synth.conv_out_size(600), synth.conv_out_size(900))
-    net.set_conv(fmap)
+    # ---- config 4: 800x1200 original, K = 7 -- at scale 0.75 (the reference's rule: 600-px short side, conv5_3 38x57) and at
+    #      scale 1.0 (an 800-px NETWORK short side, conv5_3 50x75: BASELINE config 4 read literally) --------------------
     n_img = max(10, min(40, args.steps // 5))
-    for form, static in (("level_loop", False), ("one_pass", True)):
-        p = ffi.AzContext.make_params(800, 1200, 0.75, 0.0, static_tree=static)
-        Yd, std = net.propose(p, want_stats=True)
-        ms = wall(lambda: net.propose(p), n_img)
-        Yd, std = net.propose(p, want_stats=True)          # (the passes of a search that has the context's history)
-        ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
-        fl = t_min_us(ud, int(fmap.size))
-        kms, by = kernel_ms(lambda: net.propose(p), 5)
-        # ... and as `value` is measured: searches queued ahead on the context's lanes (throughput; the figure above is one
-        # image at a time, i.e. latency)
-        tmap = torch.from_numpy(fmap).to("cuda:%d" % ctx.device).contiguous(memory_format=torch.channels_last)
-        dq = int(getattr(ctx, "lanes", 1)) + 1
 
-        def queued(k):
-            launched = 0
-            for i in range(k):
-                while launched < min(k, i + dq):
-                    ctx.propose_launch(p, fmap=tmap, producer_done=True)
-                    launched += 1
-                ctx.propose_fetch()
-        queued(12)                                 # (both lanes' histories and plans for this shape settle: a plan built in
-        torch.cuda.synchronize()                   #  the timed region showed up once as 8.8 ms per image in a 10-image sample)
-        t0 = time.perf_counter()
-        queued(n_img)
-        torch.cuda.synchronize()
-        ms_q = (time.perf_counter() - t0) / n_img * 1e3
+    def deep(scale, forms):
+        out_d = None
+        fmap = synth.make_feature_map(4, 512, synth.conv_out_size(int(round(800 * scale))), synth.conv_out_size(int(round(1200 * scale))))
         net.set_conv(fmap)
-        d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor": floors(std, int(fmap.size), ms * 1e3),
-             "path_floor_frac": floors(std, int(fmap.size), ms * 1e3)["frac"],
-             "queued": {"ms_per_image": ms_q, "proposals_per_s": 300e3 / ms_q, "searches_launched_and_unfetched": dq,
-                        "path_floor": floors(std, int(fmap.size), ms_q * 1e3),
-                        "note": "the same searches queued ahead on the context's lanes, as `value` is measured"},
-             "kernel_ms_per_image": kms, "rows_per_pass": [int(x) for x in list(std.pass_rows)[:int(std.n_passes)]]}
-        if form == "level_loop":
-            res["deep_tree"] = dict(d, workload="BASELINE config 4: 800x1200 image (scale 0.75), K = 7, Tz = 0",
-                                    regions_per_level=[int(std.level_regions[l]) for l in range(std.n_levels)],
-                                    unique_per_level=ud, candidates=int(std.n_candidates),
-                                    form="level by level (what a Tz > 0 search takes)")
-        else:
-            res["deep_tree"]["one_pass"] = d
+        for form, static in forms:
+            p = ffi.AzContext.make_params(800, 1200, scale, 0.0, static_tree=static)
+            Yd, std = net.propose(p, want_stats=True)
+            ms = wall(lambda: net.propose(p), n_img)
+            Yd, std = net.propose(p, want_stats=True)          # (the passes of a search that has the context's history)
+            ud = [int(std.level_unique[l]) for l in range(std.n_levels)]
+            fl = t_min_us(ud, int(fmap.size))
+            kms, by = kernel_ms(lambda: net.propose(p), 5)
+            # ... and as `value` is measured: searches queued ahead on the context's lanes (throughput; the figure above is one
+            # image at a time, i.e. latency)
+            tmap = torch.from_numpy(fmap).to("cuda:%d" % ctx.device).contiguous(memory_format=torch.channels_last)
+            dq = int(getattr(ctx, "lanes", 1)) + 1
+
+            def queued(k):
+                launched = 0
+                for i in range(k):
+                    while launched < min(k, i + dq):
+                        ctx.propose_launch(p, fmap=tmap, producer_done=True)
+                        launched += 1
+                    ctx.propose_fetch()
+            queued(12)                                 # (both lanes' histories and plans for this shape settle: a plan built in
+            torch.cuda.synchronize()                   #  the timed region showed up once as 8.8 ms per image in a 10-image sample)
+            t0 = time.perf_counter()
+            queued(n_img)
+            torch.cuda.synchronize()
+            ms_q = (time.perf_counter() - t0) / n_img * 1e3
+            net.set_conv(fmap)
+            d = {"ms_per_image": ms, "proposals_per_s": 300e3 / ms, "t_min_us": fl, "path_floor": floors(std, int(fmap.size), ms * 1e3),
+                 "path_floor_frac": floors(std, int(fmap.size), ms * 1e3)["frac"],
+                 "queued": {"ms_per_image": ms_q, "proposals_per_s": 300e3 / ms_q, "searches_launched_and_unfetched": dq,
+                            "path_floor": floors(std, int(fmap.size), ms_q * 1e3),
+                            "note": "the same searches queued ahead on the context's lanes, as `value` is measured"},
+                 "kernel_ms_per_image": kms, "kernels_ms": {k: round(v, 4) for k, v in sorted(by.items())},
+                 "rows_per_pass": [int(x) for x in list(std.pass_rows)[:int(std.n_passes)]]}
+            if out_d is None:
+                out_d = dict(d, workload="BASELINE config 4: 800x1200 image (scale %g, conv5_3 %dx%d), K = 7, Tz = 0"
+                                         % (scale, fmap.shape[-2], fmap.shape[-1]),
+                             regions_per_level=[int(std.level_regions[l]) for l in range(std.n_levels)],
+                             unique_per_level=ud, candidates=int(std.n_candidates),
+                             form="level by level (what a Tz > 0 search takes)" if not static else "one pass")
+            else:
+                out_d[form] = d
+        return out_d
+
+    res["deep_tree"] = deep(0.75, (("level_loop", False), ("one_pass", True)))
+    res["deep_tree_800px_network"] = deep(1.0, (("level_loop", False),))
     # ---- config 3: AZ proposals + Fast R-CNN head (fc6/fc7 4096, 21 classes) + per-class NMS on the shared map -------
     fmap = synth.make_feature_map(4, 512, 38, 63)
     net.set_conv(fmap)

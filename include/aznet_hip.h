@@ -127,6 +127,11 @@ typedef struct {
 
 /* ---- lifecycle ----------------------------------------------------------------- */
 const char *az_version(void);
+/* Layout check for bindings: sizeof(az_params) in the low 16 bits, sizeof(az_stats) in the next 16 (a caller built against
+ * another header would hand az_propose_fetch a block of the wrong size -- every fetch clears sizeof(az_stats) bytes -- so a
+ * binding compares this with its own structs when it loads the library; lib/aznet_hip/ffi.py does).  Nothing in the reference
+ * corresponds: its Cython modules are compiled against their caller. */
+int az_abi_sizes(void);
 /* Replaces caffe.set_mode_gpu(); caffe.set_device(id) (tools/prop_az.py:88-89). */
 int az_create(int device, az_ctx **out);
 int az_destroy(az_ctx *ctx);

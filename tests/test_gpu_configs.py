@@ -2,7 +2,8 @@
 (which tests/test_gpu_fullsize.py covers):
 
   * config 4 -- 800x1200 image (scale 0.75 -> 600x900 network input, conv5_3 38x57), K = 7, regions / level
-    [1, 8, 32, 128, 512, 2048]: Tz = 0 in the one-pass form and level by level, and a calibrated Tz;
+    [1, 8, 32, 128, 512, 2048]: Tz = 0 in the one-pass form and level by level, and a calibrated Tz; and the same image at
+    an 800-px network short side (scale 1.0, conv5_3 50x75);
   * images that are rescaled on the way in: 375x500 at scale 1.6 and 480x640 at 1.25 (lib/detect/test.py:27-59,
     61-97: the search runs in original-image pixels, only the rois are scaled);
   * experiments/cfgs/voc.yml:13-17 -- TEST.MAX_SIZE 800 (scale = min(600 / short, 800 / long)) and
@@ -56,6 +57,12 @@ CASES = [
     ("cfg4_tz0_one_pass", 800, 1200, 0.75, {}, "tz0"),
     ("cfg4_tz0_level_loop", 800, 1200, 0.75, {}, "tz0_level_loop"),
     ("cfg4_calibrated", 800, 1200, 0.75, {}, "calibrated"),
+    # BASELINE config 4 read literally: an 800-px NETWORK short side (TEST.SCALES = (800,), MAX_SIZE 1200 by the scale rule of
+    # lib/detect/test.py:27-59 -> scale 1.0, network input 800x1200, conv5_3 50x75): the same tree over a larger map, i.e. the
+    # RoIPool window range (up to 50x75 cells for the root) that the 38x57 cases do not reach
+    ("cfg4_800px_network_tz0_level_loop", 800, 1200, 1.0, {}, "tz0_level_loop"),
+    ("cfg4_800px_network_tz0_one_pass", 800, 1200, 1.0, {}, "tz0"),
+    ("cfg4_800px_network_calibrated", 800, 1200, 1.0, {}, "calibrated"),
     ("375x500_at_1.6_tz0", 375, 500, 1.6, {}, "tz0"),
     ("375x500_at_1.6_calibrated", 375, 500, 1.6, {}, "calibrated"),
     ("480x640_at_1.25_tz0_level_loop", 480, 640, 1.25, {}, "tz0_level_loop"),

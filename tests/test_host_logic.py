@@ -197,6 +197,39 @@ def test_bench_self_launch_relays_rank_failures():
         assert "torch.distributed" in r.stderr or "ChildFailedError" in r.stderr or "Error" in r.stderr
 
 
+def test_bench_line_is_compact_strict_json():
+    """The driver keeps 8 KB of stdout: bench.py's ONE printed line must be strict JSON well under that, carry the contract's
+    keys plus `roofline` and `cpu_baseline`, and stay small whatever the side legs put into the full record (round 5's
+    30 KB line came back `parsed: null`).  Run on round 5's full record and on one with hostile values."""
+    import json
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    full = json.load(open(os.path.join(repo, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 8192                      # the record that broke the driver
+    for rec in (full, dict(full, junk={"x": ["y" * 100] * 1000}, value=float(np.float32(2.5e5)),
+                          roofline=dict(full["roofline"], frac=float("nan"), note="n" * 20000),
+                          config=dict(full["config"], workload="w" * 50000, gather="g" * 5000),
+                          cpu_baseline=dict(full["cpu_baseline"], sample="s" * 9000))):
+        line = bench.compact_line(rec, extras_file="bench_extras.json")
+        assert "\n" not in line and len(line) < 4096 < 8192
+        got = json.loads(line, parse_constant=lambda c: pytest.fail("non-strict JSON constant %s" % c))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "gpu_over_cpu", "rccl"):
+            assert k in got, k
+        assert "workload" in got["config"] and "model" not in got["config"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+            assert k in got["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in got["cpu_baseline"], k
+        assert got["rccl"]["world"] == got["n_gpus"]
+        assert got["vs_baseline"] is None and got["unit"] == "proposals/s"
+    # the default run has no side legs: they are opt-in
+    src = open(os.path.join(repo, "bench.py")).read()
+    assert '"--extras"' in src and "write_extras(" in src
+
+
 def test_batched_proposals_groups_by_shape_and_keeps_dataset_order(monkeypatch, capsys):
     """detect.test._batched_proposals (cfg.TEST.BATCH_IMAGES): every image exactly once and in dataset order, a batch = at most
     nb images of any shapes and level counts, taken from a read-ahead window -- only images too small for the lockstep form
