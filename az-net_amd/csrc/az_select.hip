@@ -361,17 +361,33 @@ k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long 
     }
 }
 
-// One workgroup of 16 waves walks the 64-box chunks in order; the serial chain runs inside wave 0 alone.  Step c:
-//   wave 0     resolves the 64 x 64 diagonal block of chunk c (its words were requested a step ahead; only boxes still
-//              alive are visited: s_ff1 over the alive word), publishes the kept rows, and at once ORs THEIR words of
-//              chunk c + 1 -- one load per lane, all in flight together, a butterfly -- into removed[c + 1]: all that the
-//              next step's resolve still lacks;
-//   the others OR the kept rows of chunk c - 1 (published a step ago) into the words c + 1 .. W - 1 -- thread = (word,
-//              slot), slot takes every eighth kept row, eight neighbouring lanes meet with three shuffles;
-//   one barrier.
-// The chain per step is a register scan + ONE memory round trip (it was: diagonal round trip, scan, barrier, ~3 dependent
-// batches of row loads on a quarter of the threads, barrier).
+// The greedy scan: one workgroup of 16 waves, NO barrier in its loop.  mask[i][w] = the suppression word of sorted box i
+// against the 64 boxes of chunk w (row-major: a row's words lie side by side).
+//   wave 0 (the serial chain): for chunk c = 0, 1, ...: waits until every helper has applied chunks 0 .. c - 3 (a progress
+//     word per helper in LDS), resolves the 64 x 64 diagonal block in registers (only boxes still alive are visited: s_ff1
+//     over the alive word), publishes kept[c] in LDS, and ORs the kept rows' words of chunks c + 1, c + 2 into
+//     removed[c + 1], removed[c + 2] itself.  It issues no load from memory: its three blocks per chunk come out of an LDS
+//     ring that
+//   wave 1 (the loader) fills NMS_LB chunks at a time, up to NMS_RING chunks ahead of the chain.
+//   waves 2-15 (helpers): LANE = WORD.  Helper h takes rows h, h + 14, ... of every chunk j and, 64 words at a time, ORs
+//     those of its rows that were kept into its lanes' words -- two vector ALU instructions per row and 64 words (an OR
+//     ACROSS lanes, as a wave per 64 x 64 block needs it, costs ~40, and one CU's vector ALUs were then the bound: 8192
+//     blocks, 137 us) -- then ORs the lanes' words into removed[] with ONE LDS atomic.  A row's load does not depend on
+//     which rows were kept: all of a helper's rows are fetched, turns ahead of their use, and masked when kept[j] is out.
+// No wave waits for something that waits for it: wave 0 at chunk c needs chunks <= c - 3 applied, whose helpers need only
+// kept[j], published three or more steps ago, and ring data the loader fetches as soon as chunk c - NMS_RING is done; every
+// spin is on LDS, with s_sleep.
 constexpr int NMS_SCAN_NT = 1024;
+#ifndef AZ_NMS_NEAR
+#define AZ_NMS_NEAR 2
+#endif
+#ifndef AZ_NMS_SLEEP
+#define AZ_NMS_SLEEP 1
+#endif
+constexpr int NMS_NEAR = AZ_NMS_NEAR;             // words ahead that wave 0 serves itself
+constexpr int NMS_RING = 16, NMS_LB = 8;          // chunks in the LDS ring; chunks the loader fetches per round trip
+constexpr int NMS_SLOT_WORDS = 64 * (1 + NMS_NEAR);                   // u64 per ring slot (+ 64 ints of `order`)
+constexpr int NMS_NH = NMS_SCAN_NT / 64 - 2;      // helper waves
 __global__ void __launch_bounds__(NMS_SCAN_NT)
 k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ order, int n,
            unsigned long long *removed_g, long long *keep, int *nkeep, unsigned seq)
@@ -380,30 +396,67 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     // order (PCIe posted writes with relaxed ordering: a later word can pass an earlier one -- measured: a count visible
     // before the last keep entries, 5 calls in 27 600), so nothing is inferred from ORDER: every word carries the call's
     // sequence number in its upper half and the host takes a word only once it shows the current number.
-    __shared__ int s_nkept[2];                        // kept rows of the chunk resolved in this / the previous step
-    __shared__ int s_krow[2][64];                     // ... which rows (0..63), ascending
-    extern __shared__ unsigned long long removed[];   // W words
+    extern __shared__ unsigned long long nms_lds[];
     const int W = (n + 63) / 64;
+    unsigned long long *ring = nms_lds;                                       // [NMS_RING][1 + NMS_NEAR][64]
+    int *ring_o = reinterpret_cast<int *>(ring + NMS_RING * NMS_SLOT_WORDS);  // [NMS_RING][64]
+    unsigned long long *removed = reinterpret_cast<unsigned long long *>(ring_o + NMS_RING * 64);       // [W]
+    unsigned long long *kept_w = removed + W;                 // [W] kept rows of chunk c (valid once pub > c)
+    int *hdone = reinterpret_cast<int *>(kept_w + W);         // [64] chunks helper h has applied (lanes >= NMS_NH: "all")
+    int *pub = hdone + 64;                                    // chunks wave 0 has published
+    int *loaded = pub + 1;                                    // chunks whose blocks are in the ring
     (void)removed_g;
+    // (LDS words that another wave writes are read and written as relaxed workgroup-scope atomics -- ds_read / ds_write; a
+    //  `volatile` access through a generic pointer became a system-scope FLAT instruction with a vmcnt(0) wait behind it)
+    auto ld32 = [](int *q) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+    auto ld32a = [](int *q) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)); };
+    auto ld64u = [](unsigned long long *q) {                 // wave-uniform result in scalar registers
+        const unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    };
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int w = tid; w < W; w += NMS_SCAN_NT) removed[w] = 0ull;
-    if (tid < 2) s_nkept[tid] = 0;
-    int nk_total = 0;                                 // (wave 0) boxes kept so far
-    unsigned long long diag_next = (tid < 64 && lane < n) ? mask[(size_t)lane * W] : 0ull;
+    if (tid < 64) hdone[tid] = tid < NMS_NH ? 0 : 0x7fffffff;
+    if (tid == 0) { *pub = 0; *loaded = 0; }
     __syncthreads();
-    for (int c = 0; c < W; ++c) {
-        const int cur = c & 1;
-        if (tid < 64) {
-            const int row = c * 64 + lane;
-            const unsigned long long diag = diag_next;
-            const int rown = (c + 1) * 64 + lane;
-            diag_next = (c + 1 < W && rown < n) ? mask[(size_t)rown * W + (c + 1)] : 0ull;
+    // OR over the 64 lanes (wave-uniform result): data-parallel-primitive moves in the vector ALU -- a scan inside each row
+    // of 16 lanes, then the rows' last lanes handed on (row_bcast) -- instead of 12 LDS permutes per word
+    auto or32 = [&](unsigned x) -> unsigned {
+        int v = (int)x;
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+        return (unsigned)__builtin_amdgcn_readlane(v, 63);
+    };
+    auto or_reduce = [&](unsigned long long v) -> unsigned long long {
+        return ((unsigned long long)or32((unsigned)(v >> 32)) << 32) | or32((unsigned)v);
+    };
+    if (wave == 0) {
+        int nk_total = 0;
+        for (int c = 0; c < W; ++c) {
+            const int slot = c & (NMS_RING - 1);
+            if ((c & (NMS_LB - 1)) == 0)
+                while (ld32a(loaded) <= c) __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
+            const unsigned long long dg = ring[slot * NMS_SLOT_WORDS + lane];
+            unsigned long long ah[NMS_NEAR];
+#pragma unroll
+            for (int q = 0; q < NMS_NEAR; ++q) ah[q] = ring[slot * NMS_SLOT_WORDS + (1 + q) * 64 + lane];
+            const int og = ring_o[slot * 64 + lane];
+            const int need = c - NMS_NEAR > 0 ? c - NMS_NEAR : 0;
+            // every helper has applied chunks 0 .. need - 1 (lane h reads helper h's progress; the other lanes read "all")
+            while (__ballot(__hip_atomic_load(&hdone[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) != ~0ull)
+                __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
             const int nvalid = min(64, n - c * 64);
-            unsigned long long alive = ~removed[c];
+            unsigned long long alive = ~ld64u(&removed[c]);
             if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
             unsigned long long kept = 0ull;
-            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-            while (alive) {                           // (wave-uniform: alive comes from LDS and readlanes)
+            const unsigned dlo = (unsigned)dg, dhi = (unsigned)(dg >> 32);
+            while (alive) {                           // (wave-uniform: scalar registers)
                 const int b = __builtin_ctzll(alive);
                 const unsigned long long drow =
                     ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
@@ -411,59 +464,115 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
                 kept |= (1ull << b);
                 alive &= ~(drow | (1ull << b));
             }
-            const int nkc = __popcll(kept);
             const bool mine = (kept >> lane) & 1ull;
-            const int pos = __popcll(kept & ((1ull << lane) - 1ull));
-            if (mine) s_krow[cur][pos] = lane;
-            if (lane == 0) s_nkept[cur] = nkc;
-            // the kept rows' words of the NEXT chunk: lane q takes kept row q (the row lists above are this wave's own
-            // writes: krow of lane q is found with a ballot-free select below)
-            if (c + 1 < W) {
-                // lane `pos` of a kept lane is its index among the kept rows; invert with a permute through LDS written above
-                __builtin_amdgcn_wave_barrier();
-                unsigned long long v = lane < nkc ? mask[(size_t)(c * 64 + s_krow[cur][lane]) * W + (c + 1)] : 0ull;
+            // its own near words first (the next step's removed word), then the publication the helpers wait for
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)v, d, 64), hi = __shfl_xor((unsigned)(v >> 32), d, 64);
-                    v |= ((unsigned long long)hi << 32) | lo;
+            for (int q = 0; q < NMS_NEAR; ++q)
+                if (c + 1 + q < W) {
+                    const unsigned long long v = or_reduce(mine ? ah[q] : 0ull);
+                    if (lane == 0 && v) atomicOr(&removed[c + 1 + q], v);
                 }
-                if (lane == 0 && v) atomicOr(&removed[c + 1], v);      // (the helpers add chunk c - 1's share to the same word)
+            if (lane == 0) {
+                __hip_atomic_store(&kept_w[c], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(pub, c + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // append kept boxes (sorted positions -> original indices, visiting order)
-            if (mine) keep[nk_total + pos] = ((long long)seq << 32) | (unsigned)order[row];
-            nk_total += nkc;
-        } else if (c > 0) {
-            // helpers: chunk c - 1's kept rows into the words c + 1 ..: thread = (word, slot)
-            const int prev = cur ^ 1, nkp = s_nkept[prev], ht = tid - 64;
-            for (int w0 = c + 1; w0 < W; w0 += (NMS_SCAN_NT - 64) / 8) {
-                const int w = w0 + (ht >> 3), slot = ht & 7;
-                unsigned long long acc = 0ull;
-                if (w < W) {
-                    unsigned long long m[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int q = slot + 8 * j;
-                        m[j] = q < nkp ? mask[(size_t)((c - 1) * 64 + s_krow[prev][q]) * W + w] : 0ull;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc |= m[j];
-                }
-#pragma unroll
-                for (int d = 1; d < 8; d <<= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)acc, d, 64), hi = __shfl_xor((unsigned)(acc >> 32), d, 64);
-                    acc |= ((unsigned long long)hi << 32) | lo;
-                }
-                if (w < W && slot == 0 && acc) atomicOr(&removed[w], acc);
-            }
+            const int pos = __popcll(kept & ((1ull << lane) - 1ull));
+            if (mine) keep[nk_total + pos] = ((long long)seq << 32) | (unsigned)og;
+            nk_total += __popcll(kept);
         }
-        __syncthreads();
+        __threadfence_system();
+        if (lane == 0) {
+            if (seq) *reinterpret_cast<long long *>(nkeep) = ((long long)seq << 32) | (unsigned)nk_total;
+            else *nkeep = nk_total;
+        }
+        return;
     }
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (seq) *reinterpret_cast<long long *>(nkeep) = ((long long)seq << 32) | (unsigned)nk_total;
-        else *nkeep = nk_total;
+    const size_t last_row = (size_t)(n - 1);
+    if (wave == 1) {
+        // the loader: chunks c0 .. c0 + NMS_LB - 1 with one round trip (lane = row of the chunk; indices clamped, every
+        // load unconditional), into ring slots that wave 0 has left behind
+        for (int c0 = 0; c0 < W; c0 += NMS_LB) {
+            while (ld32(pub) < c0 + NMS_LB - NMS_RING) __builtin_amdgcn_s_sleep(2);
+            unsigned long long blk[NMS_LB][1 + NMS_NEAR];
+            int og[NMS_LB];
+#pragma unroll
+            for (int u = 0; u < NMS_LB; ++u) {
+                const size_t row = min((size_t)(c0 + u) * 64 + lane, last_row);
+#pragma unroll
+                for (int q = 0; q <= NMS_NEAR; ++q) blk[u][q] = mask[row * W + min(c0 + u + q, W - 1)];
+                og[u] = order[row];
+            }
+#pragma unroll
+            for (int u = 0; u < NMS_LB; ++u) {
+                const int slot = (c0 + u) & (NMS_RING - 1);
+#pragma unroll
+                for (int q = 0; q <= NMS_NEAR; ++q) ring[slot * NMS_SLOT_WORDS + q * 64 + lane] = blk[u][q];
+                ring_o[slot * 64 + lane] = og[u];
+            }
+            if (lane == 0) __hip_atomic_store(loaded, min(c0 + NMS_LB, W), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
     }
+    // helpers: a turn = (chunk j, GB groups of 64 words from group g0 on), HR rows x GB words per lane in registers, D turns
+    // requested ahead.  The first group of chunk j is the one that holds word j + 1.
+    constexpr int NH = NMS_NH, HR = (64 + NH - 1) / NH, GB = 2, D = 4;
+    const int h = wave - 2;
+    const int G = (W + 63) / 64;
+    int gj = 0, gg = 0;                                       // the turn generator: chunk, first group
+    int T = 0;                                                // (counted ahead: the loop's loads are unconditional)
+    for (int j = 0; j + 1 < W; ++j) T += (G - (j + 1) / 64 + GB - 1) / GB;
+    int tj[D], tg[D];
+    unsigned long long m[D][HR][GB];
+#define NMS_TURN_LOAD(slot)                                                                               \
+    do {                                                                                                  \
+        tj[slot] = gj; tg[slot] = gg;                                                                     \
+        _Pragma("unroll") for (int r = 0; r < HR; ++r) {                                                  \
+            const size_t row = min((size_t)min(gj, W - 1) * 64 + min(h + r * NH, 63), last_row);          \
+            _Pragma("unroll") for (int q = 0; q < GB; ++q)                                                \
+                m[slot][r][q] = mask[row * W + min((gg + q) * 64 + lane, W - 1)];                         \
+        }                                                                                                 \
+        gg += GB;                                                                                         \
+        if (gg >= G) { ++gj; gg = (gj + 1) / 64; }                                                        \
+    } while (0)
+#pragma unroll
+    for (int d = 0; d < D; ++d) NMS_TURN_LOAD(d);
+    int cur = 0;                                              // chunks this helper has applied and published
+    for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int j = tj[d], g0 = tg[d];
+            if (t0 + d < T) {
+                if (j > cur) {                                // (the turns of chunk j - 1 are behind us)
+                    if (lane == 0) __hip_atomic_store(&hdone[h], j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    cur = j;
+                }
+                while (ld32a(pub) <= j) __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
+                const unsigned long long kept = ld64u(&kept_w[j]);
+                unsigned long long acc[GB];
+#pragma unroll
+                for (int q = 0; q < GB; ++q) acc[q] = 0ull;
+#pragma unroll
+                for (int r = 0; r < HR; ++r) {
+                    const int rr = h + r * NH;
+                    if (rr < 64 && ((kept >> rr) & 1ull)) {  // (wave-uniform)
+#pragma unroll
+                        for (int q = 0; q < GB; ++q) acc[q] |= m[d][r][q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < GB; ++q) {
+                    const int w = (g0 + q) * 64 + lane;
+                    // (words up to j: the lower triangle of mask is never written; j + 1 .. j + NMS_NEAR: wave 0's own, OR-ed
+                    //  again here at no harm)
+                    if (w > j && w < W && acc[q]) atomicOr(&removed[w], acc[q]);
+                }
+            }
+            NMS_TURN_LOAD(d);
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&hdone[h], W, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#undef NMS_TURN_LOAD
 }
 
 // ---- many small NMS problems in one launch (apply_nms: one per class per image) ---------------
@@ -675,6 +784,13 @@ void azk_nms_one_small(hipStream_t s, const float *dets, int n, double thresh, l
                        keep, nkeep, (int *)nullptr, (int *)nullptr, 0, seq);
 }
 
+// LDS of the scan: the block ring, removed[W], kept[W] (8 bytes each), the helpers' progress words + two counters
+size_t azk_nms_scan_lds_bytes(int n)
+{
+    const size_t W = (size_t)(n + 63) / 64;
+    return (size_t)NMS_RING * (NMS_SLOT_WORDS * 8 + 64 * 4) + W * 16 + 66 * 4 + 16;
+}
+
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
              unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep, unsigned seq)
 {
@@ -686,6 +802,6 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
     hipLaunchKernelGGL(k_nms_rank_count, dim3(g, NMS_RANK_JS), dim3(256), 0, s, dets, n, rank);
     hipLaunchKernelGGL(k_nms_rank_place, dim3(g), dim3(256), 0, s, dets, n, rank, order, sdets);
     hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask);
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(NMS_SCAN_NT), (size_t)W * sizeof(unsigned long long), s, mask, order,
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(NMS_SCAN_NT), azk_nms_scan_lds_bytes(n), s, mask, order,
                        n, removed, keep, nkeep, seq);
 }

@@ -235,7 +235,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         int cap = 1024;
         while (cap < n) cap *= 2;
         const size_t W = (size_t)(cap + 63) / 64;
-        if (W * sizeof(unsigned long long) > 60000) return fail(c, AZ_ERR_CAPACITY, "az_nms: n too large");
+        if (azk_nms_scan_lds_bytes(cap) > 64000) return fail(c, AZ_ERR_CAPACITY, "az_nms: n too large");
         HIPCHK(c, hipMalloc((void **)&c->nms_dets, (size_t)cap * 5 * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_sdets, (size_t)cap * 5 * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_order, (size_t)cap * 4 + 16));

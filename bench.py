@@ -20,11 +20,13 @@ Images shard one-per-GPU (rank r owns image seeds r, r + N, ...; weak scaling); 
 RCCL all-gather per batch of images -- also on ONE GPU (a one-rank "nccl" group), so that N = 1 times the same
 code path as N = 8.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel (the
-fp32-MFMA fc GEMM, timed with HIP events on the ctx stream during the timed steps) and `cpu_baseline` (the
-oracle's NumPy/C/BLAS restatement on the host cores), and `box`: what THIS box sustains (register-only fp32 MFMA loop,
-float4 copy) with `roofline.frac_of_sustained` beside `roofline.frac`.  Extra keys: `one_pass`, `tz_sweep`,
-`calibrated_tz`, `deep_tree` (BASELINE config 4), `shared_detection` (config 3), `nms`, `pipelined`, `end_to_end`.
+Prints ONE compact JSON line on rank 0 (< 4 KB: the contract's keys, `roofline` for the dominant kernel -- the fp32-MFMA
+fc GEMMs, timed by the launches themselves during the timed steps --, `cpu_baseline` = the oracle's NumPy / C / BLAS
+restatement on the host cores, `path_floor`, `value_200_steps`, `box` = what THIS box sustains).  Everything else that is
+measured -- the kernel table, and with --extras the side legs: `one_pass`, `tz_sweep`, `calibrated_tz`, `stream_tz` (distinct
+images at a tuned threshold, lockstep batches), `deep_tree` (BASELINE config 4, both network scales), `shared_detection`
+(config 3), `nms`, `end_to_end`, `cli` -- goes to bench_extras.json beside this script (and gpurun_out/ when that exists),
+never into the printed line: round 5's 30 KB line came back from the driver as `parsed: null`.
 """
 import argparse
 import json
@@ -338,8 +340,8 @@ def main():
                     help="launch image i+1 only after image i has been fetched (the GPU then idles ~40 us per image while "
                          "the host turns around)")
     ap.add_argument("--queue-depth", type=int, default=0,
-                    help="searches the host keeps launched and unfetched (0 = lanes + 1: with two lanes the next image of a "
-                         "lane is already queued behind the one it works on, so the lane never waits for the host)")
+                    help="searches the host keeps launched and unfetched (0 = 3: a lane's queue holds three, so the next "
+                         "images' chip-wide kernels are already queued behind the one the GPU works on)")
     ap.add_argument("--event-every", type=int, default=5,
                     help="HIP events around the fc GEMM launches of every n-th timed step (1: every step, ~30 us/step of stream time)")
     ap.add_argument("--maps", type=int, default=4, help="distinct images (conv5_3 maps) per GPU rotated through the timed loop")
@@ -513,7 +515,9 @@ def main():
             m.ctx.propose_fetch(want_scores=True)
 
     # searches launched and not yet fetched in the loops below
-    depth = 1 if args.no_queue_ahead else (args.queue_depth if args.queue_depth > 0 else args.lanes + 1)
+    # (one lane: the lane's queue holds three -- its stage-1 kernels of the next two images sit behind the current one's, so
+    #  neither the host's turn-around nor the batch exchange ever leaves the stream empty: 1.156 -> 1.126 ms per image)
+    depth = 1 if args.no_queue_ahead else (args.queue_depth if args.queue_depth > 0 else 3)
     reruns = [0]                       # searches of the loop that had to be run twice (az_stats.n_reruns)
     ev_every = [0]                     # > 0: HIP events around the fc GEMM launches of every ev_every-th step
     step_trace = []                    # host-side wall time of every step of the loop (diagnostics: median / tail in the line)
