@@ -1,8 +1,8 @@
 #!/bin/bash
 # One profiling pass of bench.py for profiles/: kernel stats and the three separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
 # SQ/GRBM), each summarised with the tools beside this file, for three workloads:
-#   main     the search at Tz = 0 (bench.py's `value`: whole-tree pass, two lanes) -> <tag>_*
-#   onelane  the same on one lane (`one_lane`)                                   -> <tag>_onelane_*
+#   main     the search at Tz = 0 (bench.py's `value`: whole-tree pass, one lane, three searches queued) -> <tag>_*
+#   lanes2   the same on two lanes (az_set_lanes(ctx, 2))                        -> <tag>_lanes2_*
 #   twopass  the same with AZ_FULL_SPEC=0 (48-row pass + 670-row pass)          -> <tag>_twopass_*
 #   onepass  the Tz <= 0 one-pass form (`one_pass`)                             -> <tag>_onepass_*
 #   stream   bench.py's stream_tz leg (distinct images at a tuned threshold)          -> <tag>_stream_*
@@ -23,7 +23,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$repo"
 # the context's one-time measurement of head-pass costs (24 head passes at 48 .. 1408 rows, first launch) is kept out of the
 # per-kernel averages: with AZ_PASS_CAL=0 the form choice goes by the built-in figures (same forms at these workloads)
 export AZ_PASS_CAL=0
-common="--no-cpu-baseline --no-e2e --no-pipelined --no-fast --no-sweep --no-stream --no-box --no-one-lane"
+# (bench.py runs its side legs only with --extras; the sets that profile one of them switch the others off)
+common="--no-cpu-baseline --no-box"
+legs_off="--extras --no-e2e --no-fast --no-sweep --no-one-lane"
 
 run_set() {
   name=$1; args=$2; pfx=$3; period=$4
@@ -56,18 +58,18 @@ for s in $sets; do
   case $s in
     # kernels whose name contains k_fc_splitk per image: the whole-tree pass's int6 (k_fc_splitk12, 688 rows) and int7 = 2
     # (the search's first, history-less image takes the two-pass form: one stray pair of launches in the averages)
-    main)    run_set main "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "" 2 ;;
-    # the same loop on ONE lane (az_set_lanes(1)): strictly one image at a time on the GPU -- rounds 1-3's `value`
-    onelane) run_set onelane "--steps 100 --warmup 10 $common --lanes 1 --queue-depth 3 --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "onelane_" 2 ;;
+    main)    run_set main "--steps 100 --warmup 10 $common --no-rccl --event-every 1000" "" 2 ;;
+    # the same loop on TWO lanes (az_set_lanes(2)): round 4-5's `value`
+    lanes2)  run_set lanes2 "--steps 100 --warmup 10 $common --lanes 2 --no-rccl --event-every 1000" "lanes2_" 2 ;;
     # the level loop without the whole-tree pass (AZ_FULL_SPEC=0): 48-row pass (k_fc_splitk int6, int7), 670-row pass
     # (k_fc_splitk12 int6, int7) = 4
-    twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-calibrated --no-one-pass --no-extras --no-rccl --event-every 1000" "twopass_" 4 ;;
+    twopass) AZ_FULL_SPEC=0 run_set twopass "--steps 100 --warmup 10 $common --no-rccl --event-every 1000" "twopass_" 4 ;;
     # one pass: k_fc_splitk12 (int6, 688 rows), k_fc_splitk (int7) = 2
-    onepass) run_set onepass "--steps 100 --warmup 10 $common --no-calibrated --no-level-loop --no-extras --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
-    extras)  run_set extras "--steps 10 --warmup 2 $common --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;
+    onepass) run_set onepass "--steps 100 --warmup 10 $common --no-rccl --one-pass --event-every 1000" "onepass_" 2 ;;
+    extras)  run_set extras "--steps 10 --warmup 2 $common $legs_off --no-stream --no-one-pass --no-rccl --event-every 1000" "extras_" 0 ;;
     # stream_tz: distinct images in dataset order at a threshold tuned over the set (the small, weight-streaming-bound passes
     # of pruned trees: k_fc_splitk at 9 .. ~200 rows, the single-workgroup geometry kernels, the early ends)
-    stream)  run_set stream "--steps 10 --warmup 2 ${common/--no-stream/} --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "stream_" 0 ;;
+    stream)  run_set stream "--steps 10 --warmup 2 $common $legs_off --lanes 2 --no-calibrated --no-one-pass --no-two-pass --no-extras --no-rccl --event-every 1000" "stream_" 0 ;;
   esac
 done
 ls -la "$out"

@@ -318,6 +318,52 @@ def test_batch_entry_points_refuse_what_they_cannot_do(mods):
     ctx.batch_launch(prm, tm, producer_done=True)
     for i, (Y, S) in enumerate(ctx.batch_fetch_all(want_scores=True)):
         assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
+    # a launched, unfetched search WITHOUT a fixed proposal count (its counters are still on the device: the batch's pre-pass
+    # and passes would overwrite them) refuses the batch, as launch_impl refuses to queue a search behind it; fetched, it
+    # has its own result and the batch goes through
+    net.set_conv(tm[0])
+    ctx.propose_launch(var)
+    assert rc(3, ctypes.byref(prm), ptrs, C, 38, 63) == ffi.AZ_ERR_STATE
+    Yv = ctx.propose_fetch()
+    ref = HipAZNet(head, name="errs_ref2")
+    ref.set_conv(tm[0])
+    assert np.array_equal(Yv, ref.propose(var))
+    ctx.batch_launch(prm, tm, producer_done=True)
+    for i, (Y, S) in enumerate(ctx.batch_fetch_all(want_scores=True)):
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1])
+
+
+def test_slots_searching_on_their_own_share_one_head_set(mods):
+    """A batch whose images are searched one by one (here: a level outgrows max_regions, every image is rerun by
+    batch_fetch; then a shape the lockstep form does not take) must not allocate a head-buffer set per slot -- at the CLI's
+    max_regions and the VGG16 dims that is ~8.5 GB per slot, 32 slots per set, two sets per lane: the slots take the
+    context's ONE spare set in turn.  Device memory in use grows by less than two sets' worth over a 6-image batch."""
+    torch, ffi, synth, HipAZNet, orc = mods
+    dims = dict(C=64, n6=2048, n71=256, n72=64)         # (a head set of 334 MB at 2048 regions: six of them would show)
+    head = synth.make_head(seed=77, **dims)
+    H, W, sc = 600, 1000, 1.0
+    R = 2048
+    fmaps = [synth.make_scene_map(j, dims["C"], 38, 63) for j in range(6)]
+    ref = HipAZNet(head, name="spare_ref", max_regions=R)
+    want = _reference(ffi, ref, H, W, sc, 0.0, fmaps)
+    net = HipAZNet(head, name="spare", max_regions=R)
+    net.set_conv(fmaps[0])
+    net.propose(ffi.AzContext.make_params(H, W, sc, 0.0, static_tree=False))     # (the context's own buffers, plans, calibration)
+    K6, n6, n7 = dims["C"] * 49, dims["n6"], dims["n71"] + dims["n72"]
+    one_set = 4 * R * (K6 + 16 * n6 + n6 + n7 + 8 * n7)                            # pool5 + slabs + h6 + h7 + int7's slabs
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    net.ctx.batch_launch(ffi.AzContext.make_params(H, W, sc, 0.0, static_tree=False), [_cl(torch, f) for f in fmaps], producer_done=True)
+    for i in range(6):
+        Y, S, st = net.ctx.batch_fetch(i, want_scores=True, want_stats=True)
+        assert np.array_equal(Y, want[i][0]) and np.array_equal(S, want[i][1]), i
+        assert st.n_reruns == 1                       # every image ran again on its own
+    torch.cuda.synchronize()
+    grown = free0 - torch.cuda.mem_get_info()[0]
+    # (the six slots' geometry buffers and result blocks are theirs -- a few MB each at these limits; six head sets would be
+    #  6 x one_set on top)
+    assert grown < 2 * one_set + 6 * (64 << 20), (grown, one_set)
+    assert 2 * 6 * one_set > 3 * (2 * one_set + 6 * (64 << 20))  # (the bound separates one set from six at these dims)
 
 
 @pytest.mark.parametrize("tz", [0.0, 0.3, 0.5])
@@ -425,3 +471,27 @@ def test_a_batch_staged_into_a_device_buffer(mods, lockstep):
         assert np.array_equal(r[b_off:b_off + n * 32].view(np.float64).reshape(n, 4), Y)
         assert np.array_equal(r[s_off:s_off + n * 4].view(np.float32), S)
         assert not r[nbytes:].any()                                            # (the pitch's padding is not touched)
+
+
+def test_the_map_cache_of_batch_launch_does_not_keep_maps_alive(mods):
+    """batch_launch remembers the outcome of a tensor's layout checks per tensor object; the entry must not hold the tensor
+    (nor a view of it): a dataset loop hands over a fresh conv map per image, and 256 pinned 600x1000 maps are 1.25 GB.
+    Once a batch is fetched and the caller drops its maps, nothing of them is left."""
+    import gc
+    import weakref
+    torch, ffi, synth, HipAZNet, orc = mods
+    head = synth.make_object_head(seed=77, **synth.SMALL_DIMS)
+    net = HipAZNet(head, name="cache")
+    prm = ffi.AzContext.make_params(600, 1000, 1.0, TZ_OBJ)
+    refs = []
+    for rep in range(3):
+        tm = [_cl(torch, f) for f in _object_set(synth, 4)]           # 4-D channels_last: the layout the batch reads in place
+        tm3 = [t[0] for t in tm[:2]]                                   # ... and two of them handed over as 3-D views
+        maps = tm3 + tm[2:]
+        net.ctx.batch_launch(prm, maps, producer_done=True)
+        net.ctx.batch_fetch_all()
+        refs += [weakref.ref(t) for t in tm]
+        del tm, tm3, maps
+    gc.collect()
+    assert all(r() is None for r in refs)
+    assert len(net.ctx._bmap_cache) <= 64
