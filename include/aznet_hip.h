@@ -89,6 +89,25 @@ typedef struct {
                                  ~35 us -- and is run again in full if this tree goes on; same bits)                 */
 } az_params;
 
+/* The bits of az_params.reserved by name.  A caller that just wants the search passes 0.  AZ_P_TUNE is the ONLY bit that
+ * changes a result (it selects the tuner's variant of the search, lib/detect/tune.py:256-316); every other bit picks among
+ * forms of the same search that give the same bits -- they exist for the parity tests (each form against the plain level
+ * loop) and for A/B measurements, and the context's own choice (all bits 0) is what bench.py and the tools run. */
+enum {
+    AZ_P_NO_SPECULATION      = 1,     /* levels 1-3 one head pass each                                  */
+    AZ_P_UNFUSED_FIRST_LEVELS = 2,    /* their geometry as separate launches                            */
+    AZ_P_TUNE                = 4,     /* the tuner's variant (K levels, no forced root, anchor history) */
+    AZ_P_RADIX_SELECT        = 8,     /* final top-k by the single-workgroup radix select               */
+    AZ_P_UNFUSED_LEVELS      = 16,    /* geometry of the later levels as separate launches              */
+    AZ_P_LEVEL_LOOP_AT_TZ0   = 32,    /* no one-pass plan for Tz <= 0                                   */
+    AZ_P_NO_PAIR_ROWS        = 64,    /* never carry the next level's rows in a pass                    */
+    AZ_P_PAIR_ROWS_ALWAYS    = 128,   /* ... at every eligible level                                    */
+    AZ_P_NO_WHOLE_TREE       = 256,   /* never the whole-tree / closure pass                            */
+    AZ_P_WHOLE_TREE_ALWAYS   = 512,   /* ... whenever the image shape allows                            */
+    AZ_P_CLOSURE_ROWS        = 1024,  /* with AZ_P_WHOLE_TREE_ALWAYS: the closure rows                  */
+    AZ_P_NO_EARLY_END        = 4096   /* enqueue every level whatever the last search of the shape did  */
+};
+
 /* What the reference prints per image (test.py:408-409) plus per-level sizes. */
 typedef struct {
     int32_t n_proposals;
