@@ -129,6 +129,8 @@ int az_load_head(az_ctx *c, int C, int n6, int n71, int n72, const float *W6, co
     if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
     if (c->stream3) HIPCHK(c, hipStreamSynchronize(c->stream3));
     c->s2_live = false; c->i7_live = false; c->part7 = nullptr;
+    for (float *&q : c->part7_ring) q = nullptr;          // (freed with the head's other buffers below)
+    c->part7_turn = 0;
     c->s3_live = false; c->g_live[0] = c->g_live[1] = false;
     destroy_twin(c);                          // (the second lane reads this head's buffers: rebuilt at the next launch)
     destroy_batch(c);

@@ -176,6 +176,12 @@ struct az_ctx {
     bool i7_live = false, s2_live = false;
     int split_env = -1, split_now = 0, async_err = 0;
     float *part7 = nullptr;                   // int7's split-K slabs [S7][maxR][n7]
+    // Staged searches write int7's slabs into THREE buffers in turn (ring[0] = part7): the heads of search i - 3 -- the last
+    // reader of the buffer search i writes -- ran before that search was fetched, and a lane never holds more than
+    // AZ_QUEUE_MAX = 3 unfetched searches, so int7 needs no event wait for the previous search's heads any more (each wait on
+    // the main stream is a ~6 us bubble between two chip-wide kernels).  AZ_P7_RING=0: one buffer + the wait (measurements).
+    float *part7_ring[3] = {nullptr, nullptr, nullptr};
+    int part7_turn = 0, part7_ring_env = -1;
     az_ctx *twin = nullptr, *owner = nullptr;
     // A batch of images searched in lockstep (az_batch_launch; az_search.hip: batch_launch_impl, az_batch.hip).  Held by the
     // lane whose head buffers the batch's passes run in (the context, or its twin for every other batch when two lanes are
@@ -615,9 +621,24 @@ void launch_head(az_ctx *c, const int *Uptr, int level, int im_h, int im_w, doub
         c->gs = s2; c->ts = s2;
     }
     float *p7 = c->part7 ? c->part7 : c->part;
+    bool ring = false;
+    if (i7_first) {
+        if (c->part7_ring_env < 0) { const char *e = getenv("AZ_P7_RING"); c->part7_ring_env = (e && !atoi(e)) ? 0 : 1; }
+        if (c->part7_ring_env && !c->part7_ring[1]) {
+            c->part7_ring[0] = c->part7;
+            for (int q = 1; q < 3 && c->part7_ring_env; ++q)
+                if (dalloc(c, &c->part7_ring[q], (size_t)c->S7 * c->maxR * d.n7) != AZ_OK) { c->err.clear(); (void)hipGetLastError(); c->part7_ring_env = 0; }
+            if (!c->part7_ring_env) c->part7_ring[1] = c->part7_ring[2] = nullptr;     // (no room: one buffer + the wait)
+        }
+        if (c->part7_ring_env && c->part7_ring[2] && c->part7_ring[0] == c->part7) {
+            p7 = c->part7_ring[c->part7_turn];
+            c->part7_turn = (c->part7_turn + 1) % 3;
+            ring = true;
+        }
+    }
     unsigned long long *ts7 = span_slot("fc7_gemm");
     if (ts7) c->profiling &= ~(1 | 2);
-    if (i7_first && c->s2_live && hipStreamWaitEvent(c->stream, c->ev_s2, 0) != hipSuccess) c->async_err = 1;
+    if (i7_first && !ring && c->s2_live && hipStreamWaitEvent(c->stream, c->ev_s2, 0) != hipSuccess) c->async_err = 1;
     if (i7_first && c->s3_live && !c->three_now && hipStreamWaitEvent(c->stream, c->ev_s3, 0) != hipSuccess) c->async_err = 1;
     { Timed t(c, "fc7_gemm", level, 1);
       azk_fc_gemm(i7_first ? c->stream : s2, c->h6, d.n6, c->W7, d.n6, Uptr, c->maxR, d.n7, d.n6, c->S7, p7, 1 << 30, ts7); }
