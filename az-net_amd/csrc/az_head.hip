@@ -349,14 +349,20 @@ __device__ __forceinline__ void mtile_rows(int strips, int mt, int t, int &strip
 // instructions, k slots (0,4,1,5) then (2,6,3,7) (both instructions are bitwise sequential fmaf
 // chains over their k slots: dev/mfma_f32_16x16x4_probe.hip), so a row's bits do not depend on which
 // kind of strip it lands in.
-template <int NRT, bool HALF>
+// QUART: the tile ends with a QUARTER strip instead -- rows NRT*32 .. NRT*32+7, for the <= 8 rows a launch has past its last
+// full strip (the 40-row speculative pass of every pruned tree: 8 + 32 rois, the root deferred).  It runs on
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4 x 4 blocks per instruction, K = 1, arranged here as 2 row blocks x 8 column
+// blocks = exactly 8 rows x 32 columns, eight instructions per 8-wide k group in the order 0,4,1,5,2,6,3,7 -- bitwise the
+// fmaf chain of the other two shapes (dev/mfma_f32_4x4x1_probe.hip), at a quarter of a padded strip's matrix-pipe time.
+template <int NRT, bool HALF, bool QUART = false>
 __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, const float *__restrict__ Wt,
                                         int ldw, int M, int N, int m0, int n0, int k0, int kend,
                                         float *__restrict__ slab, float (*sA)[BM * LDT], float (*sB)[BN * LDT])
 {
-    static_assert(!HALF || NRT <= 3, "the half strip lives in the tile's fourth strip of LDS rows");
-    static_assert(NRT > 0 || HALF, "a tile has at least a half strip");
-    constexpr int NLA = NRT + (HALF ? 1 : 0);    // activation float4s per thread per K-step
+    static_assert(!(HALF && QUART), "a tile ends with a half strip or a quarter strip, not both");
+    static_assert(!(HALF || QUART) || NRT <= 3, "the half / quarter strip lives in the tile's fourth strip of LDS rows");
+    static_assert(NRT > 0 || HALF || QUART, "a tile has at least a half strip");
+    constexpr int NLA = NRT + ((HALF || QUART) ? 1 : 0);    // activation float4s per thread per K-step
     constexpr int NA = NRT > 0 ? NRT : 1;        // (NRT = 0: the tile IS the half strip; arrays keep one unused slot)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -383,7 +389,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 #pragma unroll
     for (int i = 0; i < NRT; ++i) voA[i] = (unsigned)((min(srow + 32 * i, M - 1 - m0) * ldx + sc4) * 4);
     // half strip: 16 rows x 8 float4 -- threads t and t + 128 stage the same vector (same value, same place)
-    if constexpr (HALF) voA[NRT] = (unsigned)((min(NRT * 32 + (srow & 15), M - 1 - m0) * ldx + sc4) * 4);
+    if constexpr (HALF || QUART) voA[NRT] = (unsigned)((min(NRT * 32 + (srow & 15), M - 1 - m0) * ldx + sc4) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) voB[i] = (unsigned)(((srow + 32 * i) * BK + sc4) * 4);
     auto gload = [&](int kt, float4 (&ra)[NLA], float4 (&rb)[4]) {
@@ -399,7 +405,7 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
 #pragma unroll
         for (int i = 0; i < NRT; ++i)
             *reinterpret_cast<float4 *>(&sA[buf][(srow + 32 * i) * LDT + sc4]) = zero_tail(ra[i], ok);
-        if constexpr (HALF)
+        if constexpr (HALF || QUART)
             *reinterpret_cast<float4 *>(&sA[buf][(NRT * 32 + (srow & 15)) * LDT + sc4]) = zero_tail(ra[NRT], ok);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -407,11 +413,21 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
     };
     // half-strip fragments of one 8-wide k group: lane = (row or column lane & 15, k slot lane >> 4);
     // slot s feeds k = {0,4,1,5}[s] to the first instruction and k + 2 to the second
-    struct HalfFrag { float a1, a2, b1[2], b2[2]; };
+    // quarter-strip fragments: lane = (block lane >> 2 = (row block, column block), t = lane & 3): the 8 k of the group of
+    // ITS activation row and of ITS weight row (two 16-byte LDS reads each)
+    struct HalfFrag { float a1, a2, b1[2], b2[2]; float4 qa[2], qb[2]; };
+    floatx4 accq = {0.f, 0.f, 0.f, 0.f};
+    const float *qa_base = &sA[0][(NRT * 32 + (lane >> 5) * 4 + (lane & 3)) * LDT];
+    const float *qb_base = &sB[0][(wave * 32 + ((lane >> 2) & 7) * 4 + (lane & 3)) * LDT];
     const int hk = ((lane >> 4) & 1) * 4 + (lane >> 5);
     const float *ha_base = &sA[0][(NRT * 32 + (lane & 15)) * LDT + hk];
     const float *hb_base = &sB[0][(wave * 32 + (lane & 15)) * LDT + hk];
     auto hfrag = [&](int buf, int g8, HalfFrag &f) {
+        if constexpr (QUART) {
+            const float *pa = qa_base + buf * (BM * LDT) + g8 * 8, *pb = qb_base + buf * (BN * LDT) + g8 * 8;
+            f.qa[0] = *reinterpret_cast<const float4 *>(pa); f.qa[1] = *reinterpret_cast<const float4 *>(pa + 4);
+            f.qb[0] = *reinterpret_cast<const float4 *>(pb); f.qb[1] = *reinterpret_cast<const float4 *>(pb + 4);
+        }
         if constexpr (HALF) {
             const float *pa = ha_base + buf * (BM * LDT) + g8 * 8;
             f.a1 = pa[0]; f.a2 = pa[2];
@@ -423,6 +439,16 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         }
     };
     auto hmfma = [&](const HalfFrag &f) {
+        if constexpr (QUART) {
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[0].x, f.qb[0].x, accq, 0, 0, 0);      // k = 0
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[1].x, f.qb[1].x, accq, 0, 0, 0);      // 4
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[0].y, f.qb[0].y, accq, 0, 0, 0);      // 1
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[1].y, f.qb[1].y, accq, 0, 0, 0);      // 5
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[0].z, f.qb[0].z, accq, 0, 0, 0);      // 2
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[1].z, f.qb[1].z, accq, 0, 0, 0);      // 6
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[0].w, f.qb[0].w, accq, 0, 0, 0);      // 3
+            accq = __builtin_amdgcn_mfma_f32_4x4x1f32(f.qa[1].w, f.qb[1].w, accq, 0, 0, 0);      // 7
+        }
         if constexpr (HALF) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) acch[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1, f.b1[h], acch[h], 0, 0, 0);
@@ -473,7 +499,8 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
         hfrag(0, 0, h0);
         hfrag(0, 1, h1);
         // with a half strip every phase has 4 more (short) MFMAs and up to 6 more 4-byte DS reads
-        constexpr int HM = HALF ? 4 : 0, HD = HALF ? 3 : 0;
+        // (a quarter strip: 8 short MFMAs and 4 16-byte DS reads)
+        constexpr int HM = HALF ? 4 : (QUART ? 8 : 0), HD = HALF ? 3 : (QUART ? 2 : 0);
         constexpr int REM01_ = 4 * NRT + HM - (NLA + 4) - (NRT + 1) - HD, REM01 = REM01_ > 0 ? REM01_ : 0;
         auto step = [&](int kt, int buf, float4 (&rl_a)[NLA], float4 (&rl_b)[4], const float4 (&rw_a)[NLA],
                         const float4 (&rw_b)[4]) {
@@ -620,6 +647,16 @@ __device__ __forceinline__ void fc_tile(const float *__restrict__ X, int ldx, co
                 if (row < M) slab[(size_t)row * N + col] = acc[r][e];
             }
     }
+    if constexpr (QUART) {
+        // C/D layout of the 4x4 MFMA blocks: block = lane >> 2 = (row block lane >> 5, column block (lane >> 2) & 7);
+        // VGPR e = row e of the block, lane & 3 = its column
+        const int qcol = n0 + wave * 32 + ((lane >> 2) & 7) * 4 + (lane & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = m0 + NRT * 32 + (lane >> 5) * 4 + e;
+            if (qcol < N && row < M) slab[(size_t)row * N + qcol] = accq[e];
+        }
+    }
     if constexpr (HALF) {
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
 #pragma unroll
@@ -705,6 +742,8 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
         mtile_rows(st2, mt2, mt2 - 1, s0, nrt_last);
         if (mt2 >= 2 && nrt_last <= 3) { strips = st2; mt = mt2; half_last = true; }
     }
+    // (half_enabled bit 4: no quarter strips -- AZ_GEMM_QUART=0, measurements)
+    const bool quart_last = half_last && (M & 31) <= 8 && !(half_enabled & 16);
     const int nitems = mloop ? G : G * mt;
     // Two tiles per group on a full grid: workgroups b and b + 8 -- the same XCD, hence the same L2 -- take the two tiles
     // of ONE group at the same time (the group's weight panel comes from memory once); b and b + 256 tend to share a CU
@@ -736,7 +775,12 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
             else { strip0 = strips - 1; n_rt = 1; }
             const int m0 = strip0 * 32;
 #define FC_TILE(NRT_, HALF_) fc_tile<NRT_, HALF_>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB)
-            if (half_last && mtile == mt - 1) {
+#define FC_TILE_Q(NRT_) fc_tile<NRT_, false, true>(X, ldx, Wt, ldw, M, N, m0, n0, k0, kend, slab, sA, sB)
+            if (quart_last && mtile == mt - 1 && n_rt <= 1) {
+                // (<= 8 rows past the last full strip, behind at most one strip -- the 40-row speculative pass of a pruned
+                //  tree --: a quarter strip; behind two or three strips the half strip stays: its registers are there)
+                if (n_rt == 0) FC_TILE_Q(0); else FC_TILE_Q(1);
+            } else if (half_last && mtile == mt - 1) {
                 switch (n_rt) {
                 case 0: FC_TILE(0, true); break;
                 case 1: FC_TILE(1, true); break;
@@ -752,6 +796,7 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
                 }
             }
 #undef FC_TILE
+#undef FC_TILE_Q
         }
     }
 }
@@ -1090,7 +1135,8 @@ void azk_fc_gemm(hipStream_t s, const float *x, int ldx, const float *W, int ldw
     static int half = -1;                  // AZ_GEMM_HALF=0: pad the last rows to a full strip instead (measurements)
     if (half < 0) {
         const char *e = getenv("AZ_GEMM_HALF"), *f = getenv("AZ_GEMM_BALANCED"), *g = getenv("AZ_GEMM_PAIR");     // (bit 2: balanced tiles, bit 3: no pair rotation: measurements)
-        half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0) | ((g && !atoi(g)) ? 8 : 0);
+        const char *q = getenv("AZ_GEMM_QUART");
+        half = ((e ? atoi(e) : 1) ? 1 : 0) | ((f && atoi(f)) ? 4 : 0) | ((g && !atoi(g)) ? 8 : 0) | ((q && !atoi(q)) ? 16 : 0);
     }
     hipLaunchKernelGGL(k_fc_splitk, dim3(gemm_grid()), dim3(256), 0, s, x, ldx, W, ldw, Mptr, capM, N, K, S,
                        fc_chunk(K, S), part, max_strips, half, ts);
