@@ -180,6 +180,7 @@ struct az_ctx {
     // reader of the buffer search i writes -- ran before that search was fetched, and a lane never holds more than
     // AZ_QUEUE_MAX = 3 unfetched searches, so int7 needs no event wait for the previous search's heads any more (each wait on
     // the main stream is a ~6 us bubble between two chip-wide kernels).  AZ_P7_RING=0: one buffer + the wait (measurements).
+    static_assert(AZ_QUEUE_MAX <= 3, "the int7 slab ring has one buffer per search a lane may hold unfetched");
     float *part7_ring[3] = {nullptr, nullptr, nullptr};
     int part7_turn = 0, part7_ring_env = -1;
     az_ctx *twin = nullptr, *owner = nullptr;
