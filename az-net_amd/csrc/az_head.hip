@@ -802,6 +802,9 @@ k_fc_splitk(const float *__restrict__ X, int ldx, const float *__restrict__ Wt, 
 }
 
 // y = act(sum_s part[s] + b): partial sums added in chunk order (fixed), then the bias.
+#ifndef AZ_REDUCE_NT
+#define AZ_REDUCE_NT 1
+#endif
 #ifndef AZ_REDUCE_BATCH
 #define AZ_REDUCE_BATCH 8       /* (16 in flight: 32.8 -> 34.4 us at 670 rows: the kernel runs at memory speed either way) */
 #endif
@@ -824,7 +827,15 @@ k_fc_reduce(const float *__restrict__ part, const float *__restrict__ bias, cons
         for (int s0 = 0; s0 < S; s0 += RB) {
             float4 t[RB];
 #pragma unroll
-            for (int j = 0; j < RB; ++j) t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S - 1) * slab);
+            for (int j = 0; j < RB; ++j) {
+#if AZ_REDUCE_NT
+                // (every slab word is read exactly once: a non-temporal load does not park it in L2 -- 38.0 -> 33.9 us at 688 rows)
+                const floatx4 v = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p + (size_t)min(s0 + j, S - 1) * slab));
+                t[j] = make_float4(v.x, v.y, v.z, v.w);
+#else
+                t[j] = *reinterpret_cast<const float4 *>(p + (size_t)min(s0 + j, S - 1) * slab);
+#endif
+            }
 #pragma unroll
             for (int j = 0; j < RB; ++j)
                 if (s0 + j < S) {
