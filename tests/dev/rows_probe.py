@@ -8,7 +8,7 @@ head = synth.make_head(seed=1234, **synth.FULL_DIMS)
 net = HipAZNet(head, name="rows", max_regions=4096)
 net.set_conv(synth.make_feature_map(3, 512, 38, 63))
 rng = np.random.RandomState(1)
-for rows in (32, 33, 36, 40, 41, 48, 64, 72, 104):
+for rows in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "32,33,36,40,41,48,64,72,104".split(","))]:
     x1 = rng.uniform(0, 900, rows); y1 = rng.uniform(0, 500, rows)
     rr = np.stack([np.zeros(rows), x1, y1, x1 + rng.uniform(16, 300, rows), y1 + rng.uniform(16, 300, rows)], 1).astype(np.float32)
     for _ in range(5): net.ctx.head_forward(rr)
