@@ -396,8 +396,10 @@ void azk_gather_sel(hipStream_t s, const int *sel_idx, const int *nsel, int cap,
 // word is 64 bits, (seq << 32) | n_kept -- the host accepts a word only when it carries the call's sequence number
 // removed: n ints of scratch that are zero on entry (and left zero): the chip-wide rank counts
 size_t azk_nms_scan_lds_bytes(int n);       // dynamic LDS of the scan kernel (bounds n)
+size_t azk_nms_band_words(int n);           // words of `band` for up to n boxes
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
-             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep, unsigned seq = 0);
+             unsigned long long *mask, unsigned long long *band, unsigned long long *removed, long long *keep, int *nkeep,
+             unsigned seq = 0);
 // many groups of <= azk_nms_small_max() boxes in one launch: group g = dets[goff[g] .. goff[g+1]); gsel lists
 // the groups to process; keep[goff[g] ..] gets the kept group-local indices, nkeep[g] their number
 void azk_nms_small(hipStream_t s, const float *dets, const int *goff, const int *gsel, int n_sel, double thresh,

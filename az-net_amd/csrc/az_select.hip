@@ -327,71 +327,119 @@ __global__ void __launch_bounds__(256) k_nms_rank_place(const float *__restrict_
     o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = w * h;      // areas, nms.pyx:24
 }
 
+// OR over the 64 lanes (wave-uniform result): data-parallel-primitive moves in the vector ALU -- a scan inside each row of
+// 16 lanes, then the rows' last lanes handed on (row_bcast) -- instead of 12 LDS permutes per 64-bit word
+__device__ __forceinline__ unsigned wave_or32(unsigned x)
+{
+    int v = (int)x;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned long long or_reduce(unsigned long long v)
+{
+    return ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+}
+
 __global__ void __launch_bounds__(256)
-k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long long *mask)
+k_nms_mask(const float *__restrict__ sdets, int n, double thresh, unsigned long long *mask, unsigned long long *band,
+           int near)
 {
     const int W = (n + 63) / 64;
     const int cb = blockIdx.x, rb = blockIdx.y;
     if (cb < rb) return;                       // every j in this word <= every i: nothing to suppress
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // (the wave number in a scalar register: the row's box then comes in with scalar loads, requested rows ahead)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = cb * 64 + lane;
     float jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0, jarea = 0;
     if (j < n) {
         const float *d = sdets + 5 * (size_t)j;
         jx1 = d[0]; jy1 = d[1]; jx2 = d[2]; jy2 = d[3]; jarea = d[4];
     }
-    for (int rr = wave; rr < 64; rr += 4) {
-        const int i = rb * 64 + rr;
-        if (i >= n) break;
-        const float *d = sdets + 5 * (size_t)i;
-        const float ix1 = d[0], iy1 = d[1], ix2 = d[2], iy2 = d[3], iarea = d[4];
-        const float xx1 = ix1 >= jx1 ? ix1 : jx1;          // nms.pyx:11-15 max/min
-        const float yy1 = iy1 >= jy1 ? iy1 : jy1;
-        const float xx2 = ix2 <= jx2 ? ix2 : jx2;
-        const float yy2 = iy2 <= jy2 ? iy2 : jy2;
-        float tw = xx2 - xx1; tw = tw + 1.0f;
-        float th = yy2 - yy1; th = th + 1.0f;
-        const float w = 0.0f >= tw ? 0.0f : tw;
-        const float h = 0.0f >= th ? 0.0f : th;
-        const float inter = w * h;
-        float den = iarea + jarea; den = den - inter;
-        const float ovr = inter / den;
-        const bool sup = (j < n) && (j > i) && ((double)ovr >= thresh);
-        const unsigned long long word = __ballot(sup);
-        if (lane == 0) mask[(size_t)i * W + cb] = word;
+    // the wave's 16 rows, four at a time: their boxes requested together (scalar loads: the addresses are wave-uniform)
+    const int nrow = min(64, n - rb * 64);
+    for (int q0 = 0; q0 < 16; q0 += 4) {
+        float bx[4][5];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *d = sdets + 5 * (size_t)(rb * 64 + min(wave + 4 * (q0 + u), nrow - 1));
+#pragma unroll
+            for (int f = 0; f < 5; ++f) bx[u][f] = d[f];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = wave + 4 * (q0 + u);
+            if (rr >= nrow) break;
+            const int i = rb * 64 + rr;
+            const float ix1 = bx[u][0], iy1 = bx[u][1], ix2 = bx[u][2], iy2 = bx[u][3], iarea = bx[u][4];
+            const float xx1 = ix1 >= jx1 ? ix1 : jx1;          // nms.pyx:11-15 max/min
+            const float yy1 = iy1 >= jy1 ? iy1 : jy1;
+            const float xx2 = ix2 <= jx2 ? ix2 : jx2;
+            const float yy2 = iy2 <= jy2 ? iy2 : jy2;
+            float tw = xx2 - xx1; tw = tw + 1.0f;
+            float th = yy2 - yy1; th = th + 1.0f;
+            const float w = 0.0f >= tw ? 0.0f : tw;
+            const float h = 0.0f >= th ? 0.0f : th;
+            const float inter = w * h;
+            float den = iarea + jarea; den = den - inter;
+            const float ovr = inter / den;
+            // (the DIAGONAL block is written symmetric -- bit j also for j < i: the scan resolves a chunk from every box's
+            //  EARLIER overlapping boxes, which is this word below its own bit; IoU is symmetric bit for bit: max / min / + / *
+            //  commute.  Off the diagonal only j > i exists.)
+            const bool sup = (j < n) && (cb == rb ? j != i : j > i) && ((double)ovr >= thresh);
+            const unsigned long long word = __ballot(sup);
+            if (lane == 0) {
+                mask[(size_t)i * W + cb] = word;
+                // the chunk's diagonal block and the `near` blocks right of it once more, block by block (64 row words side
+                // by side): what the scan's chain needs per chunk comes in with coalesced 512-byte loads
+                if (cb - rb <= near) band[((size_t)rb * (1 + near) + (cb - rb)) * 64 + rr] = word;
+            }
+        }
     }
 }
 
 // The greedy scan: one workgroup of 16 waves, NO barrier in its loop.  mask[i][w] = the suppression word of sorted box i
-// against the 64 boxes of chunk w (row-major: a row's words lie side by side).
-//   wave 0 (the serial chain): for chunk c = 0, 1, ...: waits until every helper has applied chunks 0 .. c - 3 (a progress
-//     word per helper in LDS), resolves the 64 x 64 diagonal block in registers (only boxes still alive are visited: s_ff1
-//     over the alive word), publishes kept[c] in LDS, and ORs the kept rows' words of chunks c + 1, c + 2 into
-//     removed[c + 1], removed[c + 2] itself.  It issues no load from memory: its three blocks per chunk come out of an LDS
-//     ring that
-//   wave 1 (the loader) fills NMS_LB chunks at a time, up to NMS_RING chunks ahead of the chain.
-//   waves 2-15 (helpers): LANE = WORD.  Helper h takes rows h, h + 14, ... of every chunk j and, 64 words at a time, ORs
-//     those of its rows that were kept into its lanes' words -- two vector ALU instructions per row and 64 words (an OR
-//     ACROSS lanes, as a wave per 64 x 64 block needs it, costs ~40, and one CU's vector ALUs were then the bound: 8192
-//     blocks, 137 us) -- then ORs the lanes' words into removed[] with ONE LDS atomic.  A row's load does not depend on
-//     which rows were kept: all of a helper's rows are fetched, turns ahead of their use, and masked when kept[j] is out.
-// No wave waits for something that waits for it: wave 0 at chunk c needs chunks <= c - 3 applied, whose helpers need only
-// kept[j], published three or more steps ago, and ring data the loader fetches as soon as chunk c - NMS_RING is done; every
-// spin is on LDS, with s_sleep.
+// against the 64 boxes of chunk w (row-major: a row's words lie side by side); band[c][q][r] = the same words of chunk c's
+// rows for the chunks c .. c + NMS_NEAR, block by block (k_nms_mask writes both).
+//   wave 0 (the serial chain): for chunk c = 0, 1, ...: waits until the helpers have applied chunks 0 .. c - NMS_NEAR - 1 (a
+//     progress word per helper in LDS), resolves the chunk in ROUNDS from every box's earlier overlapping boxes (the
+//     diagonal block is symmetric), publishes kept[c] in LDS, and ORs the kept rows' words of chunks c + 1 .. c + NMS_NEAR
+//     into removed[] itself.  It issues no load from memory: its blocks come out of an LDS ring that
+//   wave 1 (the loader) fills NMS_LB chunks at a time from `band`, up to NMS_RING chunks ahead of the chain.
+//   waves 2-13 (helpers, NMS_TEAMS teams of NMS_TEAM): LANE = WORD.  Team t takes the chunks t, t + NMS_TEAMS, ...; its
+//     members share the chunk's rows; once kept[j] is published a member fetches the words of ITS KEPT rows (64 words per
+//     load, far words only: j + NMS_NEAR + 1 on), ORs them in-lane and ORs the lanes' words into removed[] with ONE LDS
+//     atomic per 64 words.  The loads depend on kept[j], so a chunk costs its team one memory round trip -- which it has:
+//     the words are needed NMS_NEAR + 1 steps after the publication, and the other teams take the chunks in between.
+//     (Earlier forms fetched ALL rows ahead of the publication, 72 KB per chunk through ONE CU's L1: that, not the chain,
+//     set the pace -- 1.5 us per chunk; a wave per 64 x 64 block with an OR ACROSS lanes was bound by one CU's vector ALUs.)
+// No wave waits for something that waits for it: wave 0 at chunk c needs chunks <= c - NMS_NEAR - 1 applied, whose teams
+// need only kept[j], published NMS_NEAR + 1 or more steps ago, and ring data the loader fetches as soon as chunk
+// c - NMS_RING is done; every spin is on LDS, with s_sleep.
 constexpr int NMS_SCAN_NT = 1024;
 #ifndef AZ_NMS_NEAR
-#define AZ_NMS_NEAR 2
+#define AZ_NMS_NEAR 4
 #endif
 #ifndef AZ_NMS_SLEEP
 #define AZ_NMS_SLEEP 1
 #endif
+#ifndef AZ_NMS_TEAMS
+#define AZ_NMS_TEAMS 3
+#endif
 constexpr int NMS_NEAR = AZ_NMS_NEAR;             // words ahead that wave 0 serves itself
 constexpr int NMS_RING = 16, NMS_LB = 8;          // chunks in the LDS ring; chunks the loader fetches per round trip
 constexpr int NMS_SLOT_WORDS = 64 * (1 + NMS_NEAR);                   // u64 per ring slot (+ 64 ints of `order`)
-constexpr int NMS_NH = NMS_SCAN_NT / 64 - 2;      // helper waves
+constexpr int NMS_TEAMS = AZ_NMS_TEAMS, NMS_TEAM = 12 / NMS_TEAMS;   // helper teams; helpers per team
+constexpr int NMS_NH = NMS_TEAMS * NMS_TEAM;      // helper waves (waves 2 .. NMS_NH + 1)
+static_assert(NMS_NH <= NMS_SCAN_NT / 64 - 2 && NMS_TEAM >= 1, "the helpers are waves 2 .. 15 at most");
 __global__ void __launch_bounds__(NMS_SCAN_NT)
-k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ order, int n,
-           unsigned long long *removed_g, long long *keep, int *nkeep, unsigned seq)
+k_nms_scan(const unsigned long long *__restrict__ mask, const unsigned long long *__restrict__ band,
+           const int *__restrict__ order, int n, unsigned long long *removed_g, long long *keep, int *nkeep, unsigned seq)
 {
     // seq != 0: keep / nkeep are host-mapped memory the host polls.  Writes of one wave to host memory may land out of
     // order (PCIe posted writes with relaxed ordering: a later word can pass an earlier one -- measured: a count visible
@@ -403,7 +451,7 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     int *ring_o = reinterpret_cast<int *>(ring + NMS_RING * NMS_SLOT_WORDS);  // [NMS_RING][64]
     unsigned long long *removed = reinterpret_cast<unsigned long long *>(ring_o + NMS_RING * 64);       // [W]
     unsigned long long *kept_w = removed + W;                 // [W] kept rows of chunk c (valid once pub > c)
-    int *hdone = reinterpret_cast<int *>(kept_w + W);         // [64] chunks helper h has applied (lanes >= NMS_NH: "all")
+    int *hdone = reinterpret_cast<int *>(kept_w + W);         // [64] the next chunk helper h takes (lanes >= NMS_NH: "all")
     int *pub = hdone + 64;                                    // chunks wave 0 has published
     int *loaded = pub + 1;                                    // chunks whose blocks are in the ring
     (void)removed_g;
@@ -419,24 +467,9 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int w = tid; w < W; w += NMS_SCAN_NT) removed[w] = 0ull;
-    if (tid < 64) hdone[tid] = tid < NMS_NH ? 0 : 0x7fffffff;
+    if (tid < 64) hdone[tid] = tid < NMS_NH ? tid / NMS_TEAM : 0x7fffffff;    // (a helper's first chunk = its team's number)
     if (tid == 0) { *pub = 0; *loaded = 0; }
     __syncthreads();
-    // OR over the 64 lanes (wave-uniform result): data-parallel-primitive moves in the vector ALU -- a scan inside each row
-    // of 16 lanes, then the rows' last lanes handed on (row_bcast) -- instead of 12 LDS permutes per word
-    auto or32 = [&](unsigned x) -> unsigned {
-        int v = (int)x;
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
-        v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
-        return (unsigned)__builtin_amdgcn_readlane(v, 63);
-    };
-    auto or_reduce = [&](unsigned long long v) -> unsigned long long {
-        return ((unsigned long long)or32((unsigned)(v >> 32)) << 32) | or32((unsigned)v);
-    };
     if (wave == 0) {
         int nk_total = 0;
         for (int c = 0; c < W; ++c) {
@@ -449,27 +482,33 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
             for (int q = 0; q < NMS_NEAR; ++q) ah[q] = ring[slot * NMS_SLOT_WORDS + (1 + q) * 64 + lane];
             const int og = ring_o[slot * 64 + lane];
             const int need = c - NMS_NEAR > 0 ? c - NMS_NEAR : 0;
-            // every helper has applied chunks 0 .. need - 1 (lane h reads helper h's progress; the other lanes read "all")
+            // every helper is past the chunks 0 .. need - 1 of its team (lane h reads helper h's word; the others read "all")
             while (__ballot(__hip_atomic_load(&hdone[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) != ~0ull)
                 __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
             const int nvalid = min(64, n - c * 64);
             unsigned long long alive = ~ld64u(&removed[c]);
             if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
-            unsigned long long kept = 0ull;
-            const unsigned dlo = (unsigned)dg, dhi = (unsigned)(dg >> 32);
-            while (alive) {                           // (wave-uniform: scalar registers)
-                const int b = __builtin_ctzll(alive);
-                const unsigned long long drow =
-                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                    (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-                kept |= (1ull << b);
-                alive &= ~(drow | (1ull << b));
+            // Greedy inside the chunk, in rounds instead of box by box: a box still undecided whose earlier overlapping boxes
+            // are all decided-and-dropped is kept (the sequential walk would keep it: nothing kept lies before it that
+            // suppresses it); a box with a kept earlier overlapping box is dropped.  Every round decides at least the first
+            // undecided box; the rounds needed are the longest chain of overlaps, a handful -- against one dependent
+            // s_ff1 / v_readlane step per KEPT box (~24 per chunk at 8129 boxes).  Same kept set: the greedy one is unique.
+            unsigned long long kept = 0ull, und = alive;                         // (wave-uniform: scalar registers)
+            const unsigned long long pred = dg & ((1ull << lane) - 1ull);        // earlier boxes of the chunk that overlap this one
+            while (und) {
+                const bool in_und = (und >> lane) & 1ull;
+                const unsigned long long newk = __ballot(in_und && (pred & (und | kept)) == 0ull);
+                kept |= newk;
+                const unsigned long long gone = __ballot(in_und && (pred & kept) != 0ull);
+                und &= ~(newk | gone);
             }
             const bool mine = (kept >> lane) & 1ull;
-            // its own near words first (the next step's removed word), then the publication the helpers wait for
+            // its own near words first (the next steps' removed words), then the publication the helpers wait for
 #pragma unroll
             for (int q = 0; q < NMS_NEAR; ++q)
                 if (c + 1 + q < W) {
+                    // (an OR across the lanes, then ONE LDS atomic; every kept lane OR-ing its own word into LDS -- the unit
+                    //  serialises a wave's atomics on one address -- measured the same: 126 against 123 us)
                     const unsigned long long v = or_reduce(mine ? ah[q] : 0ull);
                     if (lane == 0 && v) atomicOr(&removed[c + 1 + q], v);
                 }
@@ -491,18 +530,18 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
     }
     const size_t last_row = (size_t)(n - 1);
     if (wave == 1) {
-        // the loader: chunks c0 .. c0 + NMS_LB - 1 with one round trip (lane = row of the chunk; indices clamped, every
-        // load unconditional), into ring slots that wave 0 has left behind
+        // the loader: chunks c0 .. c0 + NMS_LB - 1 with one round trip of coalesced loads (lane = row of the block; chunk
+        // indices clamped, every load unconditional), into ring slots that wave 0 has left behind
         for (int c0 = 0; c0 < W; c0 += NMS_LB) {
             while (ld32(pub) < c0 + NMS_LB - NMS_RING) __builtin_amdgcn_s_sleep(2);
             unsigned long long blk[NMS_LB][1 + NMS_NEAR];
             int og[NMS_LB];
 #pragma unroll
             for (int u = 0; u < NMS_LB; ++u) {
-                const size_t row = min((size_t)(c0 + u) * 64 + lane, last_row);
+                const int cc = min(c0 + u, W - 1);
 #pragma unroll
-                for (int q = 0; q <= NMS_NEAR; ++q) blk[u][q] = mask[row * W + min(c0 + u + q, W - 1)];
-                og[u] = order[row];
+                for (int q = 0; q <= NMS_NEAR; ++q) blk[u][q] = band[((size_t)cc * (1 + NMS_NEAR) + q) * 64 + lane];
+                og[u] = order[min((size_t)cc * 64 + lane, last_row)];
             }
 #pragma unroll
             for (int u = 0; u < NMS_LB; ++u) {
@@ -515,65 +554,47 @@ k_nms_scan(const unsigned long long *__restrict__ mask, const int *__restrict__ 
         }
         return;
     }
-    // helpers: a turn = (chunk j, GB groups of 64 words from group g0 on), HR rows x GB words per lane in registers, D turns
-    // requested ahead.  The first group of chunk j is the one that holds word j + 1.
-    constexpr int NH = NMS_NH, HR = (64 + NH - 1) / NH, GB = 2, D = 4;
-    const int h = wave - 2;
+    if (wave >= 2 + NMS_NH) return;
+    // helpers: team = h / NMS_TEAM takes the chunks team, team + NMS_TEAMS, ...; member k = h % NMS_TEAM the rows k, k +
+    // NMS_TEAM, ... of each; GB groups of 64 words per pass over its kept rows
+    constexpr int HR = (64 + NMS_TEAM - 1) / NMS_TEAM, GB = 2;
+    const int h = wave - 2, team = h / NMS_TEAM, k = h - team * NMS_TEAM;
     const int G = (W + 63) / 64;
-    int gj = 0, gg = 0;                                       // the turn generator: chunk, first group
-    int T = 0;                                                // (counted ahead: the loop's loads are unconditional)
-    for (int j = 0; j + 1 < W; ++j) T += (G - (j + 1) / 64 + GB - 1) / GB;
-    int tj[D], tg[D];
-    unsigned long long m[D][HR][GB];
-#define NMS_TURN_LOAD(slot)                                                                               \
-    do {                                                                                                  \
-        tj[slot] = gj; tg[slot] = gg;                                                                     \
-        _Pragma("unroll") for (int r = 0; r < HR; ++r) {                                                  \
-            const size_t row = min((size_t)min(gj, W - 1) * 64 + min(h + r * NH, 63), last_row);          \
-            _Pragma("unroll") for (int q = 0; q < GB; ++q)                                                \
-                m[slot][r][q] = mask[row * W + min((gg + q) * 64 + lane, W - 1)];                         \
-        }                                                                                                 \
-        gg += GB;                                                                                         \
-        if (gg >= G) { ++gj; gg = (gj + 1) / 64; }                                                        \
-    } while (0)
-#pragma unroll
-    for (int d = 0; d < D; ++d) NMS_TURN_LOAD(d);
-    int cur = 0;                                              // chunks this helper has applied and published
-    for (int t0 = 0; t0 < T; t0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int j = tj[d], g0 = tg[d];
-            if (t0 + d < T) {
-                if (j > cur) {                                // (the turns of chunk j - 1 are behind us)
-                    if (lane == 0) __hip_atomic_store(&hdone[h], j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    cur = j;
-                }
-                while (ld32a(pub) <= j) __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
-                const unsigned long long kept = ld64u(&kept_w[j]);
-                unsigned long long acc[GB];
-#pragma unroll
-                for (int q = 0; q < GB; ++q) acc[q] = 0ull;
+    for (int j = team; j < W; j += NMS_TEAMS) {
+        const int w_lo = j + 1 + NMS_NEAR;                   // the first word that is not wave 0's own
+        if (w_lo < W) {
+            while (ld32a(pub) <= j) __builtin_amdgcn_s_sleep(AZ_NMS_SLEEP);
+            const unsigned long long kept = ld64u(&kept_w[j]);
+            for (int g0 = w_lo / 64; g0 < G; g0 += GB) {
+                // (all the loads first -- one round trip --, the ORs behind them)
+                unsigned long long v[HR][GB], acc[GB];
 #pragma unroll
                 for (int r = 0; r < HR; ++r) {
-                    const int rr = h + r * NH;
-                    if (rr < 64 && ((kept >> rr) & 1ull)) {  // (wave-uniform)
+                    const int rr = k + r * NMS_TEAM;
 #pragma unroll
-                        for (int q = 0; q < GB; ++q) acc[q] |= m[d][r][q];
+                    for (int q = 0; q < GB; ++q) v[r][q] = 0ull;
+                    if (rr < 64 && ((kept >> rr) & 1ull)) {  // (wave-uniform)
+                        const unsigned long long *row = mask + ((size_t)j * 64 + rr) * W;
+#pragma unroll
+                        for (int q = 0; q < GB; ++q) v[r][q] = row[min((g0 + q) * 64 + lane, W - 1)];
                     }
                 }
 #pragma unroll
+                for (int q = 0; q < GB; ++q) acc[q] = 0ull;
+#pragma unroll
+                for (int r = 0; r < HR; ++r)
+#pragma unroll
+                    for (int q = 0; q < GB; ++q) acc[q] |= v[r][q];
+#pragma unroll
                 for (int q = 0; q < GB; ++q) {
                     const int w = (g0 + q) * 64 + lane;
-                    // (words up to j: the lower triangle of mask is never written; j + 1 .. j + NMS_NEAR: wave 0's own, OR-ed
-                    //  again here at no harm)
-                    if (w > j && w < W && acc[q]) atomicOr(&removed[w], acc[q]);
+                    if (w >= w_lo && w < W && acc[q]) atomicOr(&removed[w], acc[q]);
                 }
             }
-            NMS_TURN_LOAD(d);
         }
+        if (lane == 0) __hip_atomic_store(&hdone[h], j + NMS_TEAMS, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    if (lane == 0) __hip_atomic_store(&hdone[h], W, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#undef NMS_TURN_LOAD
+    if (lane == 0) __hip_atomic_store(&hdone[h], 0x7fffffff, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- many small NMS problems in one launch (apply_nms: one per class per image) ---------------
@@ -635,12 +656,14 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
         const bool jin = j < n;
         const float jx1 = jin ? sd[j][0] : 0.f, jy1 = jin ? sd[j][1] : 0.f, jx2 = jin ? sd[j][2] : 0.f,
                     jy2 = jin ? sd[j][3] : 0.f, jarea = jin ? sd[j][4] : 0.f;
-        // (rows r >= (cb + 1) * 64 suppress nothing in this block: j > r never holds)
+        // (rows r >= (cb + 1) * 64 suppress nothing in this block: j > r never holds, and it is not their own chunk)
         const int rend = min(n, (cb + 1) * 64);
         for (int r = wave; r < rend; r += NWV) {
             const float ix1 = sd[r][0], iy1 = sd[r][1], ix2 = sd[r][2], iy2 = sd[r][3], iarea = sd[r][4];
             bool sup = false;
-            if (jin && j > r) {
+            // (the block of the row's own chunk is symmetric -- bit j also for j < r --: the scan below resolves a chunk from
+            //  every box's EARLIER overlapping boxes)
+            if (jin && ((r >> 6) == cb ? j != r : j > r)) {
                 const float xx1 = ix1 >= jx1 ? ix1 : jx1;
                 const float yy1 = iy1 >= jy1 ? iy1 : jy1;
                 const float xx2 = ix2 <= jx2 ? ix2 : jx2;
@@ -677,13 +700,16 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
                 const int nvalid = min(64, n - c * 64);
                 unsigned long long alive = ~rem[c];
                 if (nvalid < 64) alive &= ((1ull << nvalid) - 1ull);
-                unsigned long long kept = 0ull;
-                const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-                for (int b = 0; b < nvalid; ++b) {
-                    const unsigned long long drow =
-                        ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, b) << 32) |
-                        (unsigned)__builtin_amdgcn_readlane((int)dlo, b);
-                    if ((alive >> b) & 1ull) { kept |= (1ull << b); alive &= ~drow; }
+                // in rounds (as k_nms_scan): an undecided box none of whose earlier overlapping boxes is undecided or kept is
+                // kept, one with a kept earlier overlapping box is dropped -- the greedy set, a few rounds instead of 64 steps
+                unsigned long long kept = 0ull, und = alive;
+                const unsigned long long pred = diag & ((1ull << lane) - 1ull);
+                while (und) {
+                    const bool in_und = (und >> lane) & 1ull;
+                    const unsigned long long newk = __ballot(in_und && (pred & (und | kept)) == 0ull);
+                    kept |= newk;
+                    const unsigned long long gone = __ballot(in_und && (pred & kept) != 0ull);
+                    und &= ~(newk | gone);
                 }
                 const bool mine = (kept >> lane) & 1ull;
                 if (mine) keep[o + nk + __popcll(kept & ((1ull << lane) - 1ull))] = ((long long)seq << 32) | (unsigned)sorder[row];
@@ -691,13 +717,7 @@ k_nms_small(const float *__restrict__ dets, const int *__restrict__ goff, const 
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     if (w > c && w < W) {
-                        unsigned long long v = mine ? smask[row][w] : 0ull;
-#pragma unroll
-                        for (int dd = 32; dd > 0; dd >>= 1) {
-                            const unsigned lo = __shfl_xor((unsigned)v, dd, 64), hi = __shfl_xor((unsigned)(v >> 32), dd, 64);
-                            v |= ((unsigned long long)hi << 32) | lo;
-                        }
-                        rem[w] |= v;
+                        rem[w] |= or_reduce(mine ? smask[row][w] : 0ull);
                     }
                 }
             }
@@ -792,8 +812,12 @@ size_t azk_nms_scan_lds_bytes(int n)
     return (size_t)NMS_RING * (NMS_SLOT_WORDS * 8 + 64 * 4) + W * 16 + 66 * 4 + 16;
 }
 
+// words of the band array (the diagonal + near blocks of every chunk, block by block) for up to n boxes
+size_t azk_nms_band_words(int n) { return ((size_t)(n + 63) / 64) * (1 + NMS_NEAR) * 64; }
+
 void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order, float *sdets,
-             unsigned long long *mask, unsigned long long *removed, long long *keep, int *nkeep, unsigned seq)
+             unsigned long long *mask, unsigned long long *band, unsigned long long *removed, long long *keep, int *nkeep,
+             unsigned seq)
 {
     if (n <= 0) { hipMemsetAsync(nkeep, 0, sizeof(int), s); return; }
     const int W = (n + 63) / 64;
@@ -802,7 +826,17 @@ void azk_nms(hipStream_t s, const float *dets, int n, double thresh, int *order,
     int *rank = reinterpret_cast<int *>(removed);
     hipLaunchKernelGGL(k_nms_rank_count, dim3(g, g < NMS_RANK_JS ? g : NMS_RANK_JS), dim3(256), 0, s, dets, n, rank);
     hipLaunchKernelGGL(k_nms_rank_place, dim3(g), dim3(256), 0, s, dets, n, rank, order, sdets);
-    hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask);
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(NMS_SCAN_NT), azk_nms_scan_lds_bytes(n), s, mask, order,
+    hipLaunchKernelGGL(k_nms_mask, dim3(W, W), dim3(256), 0, s, sdets, n, thresh, mask, band, NMS_NEAR);
+    // (more than the default 64 KB of dynamic LDS from ~100 000 boxes on: opted in once per process and device)
+    if (azk_nms_scan_lds_bytes(n) > 60000) {
+        static bool opted[64] = {false};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !opted[dev]) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_nms_scan), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            opted[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(NMS_SCAN_NT), azk_nms_scan_lds_bytes(n), s, mask, band, order,
                        n, removed, keep, nkeep, seq);
 }

@@ -235,11 +235,11 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         int cap = 1024;
         while (cap < n) cap *= 2;
         const size_t W = (size_t)(cap + 63) / 64;
-        if (azk_nms_scan_lds_bytes(cap) > 64000) return fail(c, AZ_ERR_CAPACITY, "az_nms: n too large");
+        if (azk_nms_scan_lds_bytes(cap) > 150000) return fail(c, AZ_ERR_CAPACITY, "az_nms: n too large");
         HIPCHK(c, hipMalloc((void **)&c->nms_dets, (size_t)cap * 5 * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_sdets, (size_t)cap * 5 * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_order, (size_t)cap * 4 + 16));
-        HIPCHK(c, hipMalloc((void **)&c->nms_mask, (size_t)cap * W * 8));
+        HIPCHK(c, hipMalloc((void **)&c->nms_mask, ((size_t)cap * W + azk_nms_band_words(cap)) * 8));      // mask, then band
         HIPCHK(c, hipMalloc((void **)&c->nms_rank, (size_t)cap * 4));
         HIPCHK(c, hipMemset(c->nms_rank, 0, (size_t)cap * 4));
         HIPCHK(c, hipMalloc((void **)&c->nms_keep, (size_t)cap * 8 + 16));
@@ -264,7 +264,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         long long *hk = (long long *)(c->h_nmsg + 64);                 // (tag << 32) | index
         const unsigned tag = nms_next_tag(c);
         *hn = 0;
-        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, (unsigned long long *)c->nms_rank, hk, (int *)c->h_nmsg, tag);
+        azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, c->nms_mask + (size_t)c->nms_cap * ((c->nms_cap + 63) / 64), (unsigned long long *)c->nms_rank, hk, (int *)c->h_nmsg, tag);
         bool got = false;
         for (long spin = 0; spin < 4000000 && !got; ++spin) got = (unsigned)((unsigned long long)*hn >> 32) == tag;
         if (got) got = nms_keep_tagged(hk, (int)(*hn & 0xFFFFFFFFll), tag, 200000);
@@ -279,7 +279,7 @@ int az_nms(az_ctx *c, const float *dets, int n, double thresh, int64_t *keep, in
         return AZ_OK;
     }
     { Timed t(c, "nms", n);
-      azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, (unsigned long long *)c->nms_rank, c->nms_keep, nk); }
+      azk_nms(s, c->nms_dets, n, thresh, c->nms_order, c->nms_sdets, c->nms_mask, c->nms_mask + (size_t)c->nms_cap * ((c->nms_cap + 63) / 64), (unsigned long long *)c->nms_rank, c->nms_keep, nk); }
     int h_nk = 0;
     HIPCHK(c, hipMemcpyAsync(&h_nk, nk, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

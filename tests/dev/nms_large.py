@@ -11,6 +11,6 @@ for n in (20000, 50000, 100000):
     t0 = time.time(); got = list(ctx.nms(dets, 0.5)); t1 = time.time(); want = list(orc.nms(dets, 0.5)); t2 = time.time()
     print(n, "ok" if got == want else "MISMATCH", len(got), "gpu %.1f ms cpu %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
 try:
-    ctx.nms(np.zeros((200000, 5), np.float32), 0.5)
+    ctx.nms(np.zeros((600000, 5), np.float32), 0.5)
 except Exception as e:
-    print("200000:", e)
+    print("600000:", e)
